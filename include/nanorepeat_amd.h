@@ -1,0 +1,200 @@
+/*
+ * nanorepeat_amd.h -- C ABI of the MI355X-native NanoRepeat repeat-size scorer.
+ *
+ * This is the drop-in boundary for NanoRepeat's per-read repeat-size estimation
+ * hot path.  The reference (WGLab/NanoRepeat 1.8.3) has no FFI: its boundary is
+ * the string call `pyminimap2.main(cmd) -> (stdout, stderr)` with FASTA files on
+ * disk, issued once per read (1D) or once per grid cell (2D).  Each entry point
+ * below replaces one reference function together with the aligner calls it
+ * makes; the file:line it replaces is cited on the declaration.
+ *
+ * Conventions: extern "C", plain pointers and sizes, caller-owned buffers,
+ * returns 0 on success and a negative NRA_E_* code on failure (message via
+ * nra_last_error(), thread-local).  Nothing throws across the boundary.  The
+ * library must not be initialised before fork(); use one process per GPU.
+ *
+ * The scoring model is minimap2's documented `-x map-ont` objective
+ * (match +2, mismatch -4, two-piece affine gap min(4+2l, 24+l), N = -1),
+ * solved as an *optimal* local alignment.  See DESIGN.md for the exact
+ * recurrences and tie-break rules; oracle/nr_oracle.c is the CPU restatement
+ * the HIP kernels must match bit for bit.
+ */
+#ifndef NANOREPEAT_AMD_H
+#define NANOREPEAT_AMD_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define NRA_ABI_VERSION 1
+
+/* error codes */
+#define NRA_OK            0
+#define NRA_E_ARG        -1   /* bad argument (null pointer, negative size, window too large ...) */
+#define NRA_E_DEVICE     -2   /* HIP runtime error / no device */
+#define NRA_E_RANGE      -3   /* a sequence exceeds what the int16/int32 score packing can hold */
+#define NRA_E_NOMEM      -4
+
+/* per-read status (1D and 2D) */
+#define NRA_READ_OK        0  /* at least one best-scoring record passed the selector */
+#define NRA_READ_FALLBACK  1  /* 1D only: records exist but no top-score record passes the flank
+                                 test -> caller keeps round2_repeat_size (nanoRepeat_bam.py:433) */
+#define NRA_READ_NO_RECORD 2  /* no candidate reached min_dp_score: the reference gets an empty PAF
+                                 and leaves the read's size unset (nanoRepeat_bam.py:421) */
+#define NRA_READ_SKIPPED   3  /* kmin > kmax on input: read has no round-2 estimate
+                                 (nanoRepeat_bam.py:460) */
+
+/* flags */
+#define NRA_F_ALL_EXTENTS  1  /* compute tstart/tend for every candidate, not only the top-score ties */
+
+/* Scoring parameters: minimap2 `-x map-ont` defaults.
+ * A gap of length l costs min(gap_open1 + l*gap_ext1, gap_open2 + l*gap_ext2). */
+typedef struct nra_scoring {
+    int32_t match;        /* +2  */
+    int32_t mismatch;     /*  4  (penalty, positive) */
+    int32_t gap_open1;    /*  4  */
+    int32_t gap_ext1;     /*  2  */
+    int32_t gap_open2;    /* 24  */
+    int32_t gap_ext2;     /*  1  */
+    int32_t sc_ambi;      /*  1  (penalty for N against anything) */
+    int32_t min_dp_score; /* 80  records with a lower score are absent (minimap2 -s) */
+} nra_scoring_t;
+
+/* One 1D repeat region.  Candidate k is the sequence left + unit*k + right
+ * (nanoRepeat_bam.py:478-481).  Sequences are ASCII (ACGTN, either case). */
+typedef struct nra_region {
+    const char* left;
+    const char* unit;
+    const char* right;
+    int32_t left_len;
+    int32_t unit_len;
+    int32_t right_len;
+} nra_region_t;
+
+/* One joint (two adjacent motifs) region.  Candidate (k1,k2) is
+ * left + unit1*k1 + mid + unit2*k2 + right (nanoRepeat_joint.py:499-505). */
+typedef struct nra_joint_region {
+    const char* left;
+    const char* unit1;
+    const char* mid;
+    const char* unit2;
+    const char* right;
+    int32_t left_len;
+    int32_t unit1_len;
+    int32_t mid_len;
+    int32_t unit2_len;
+    int32_t right_len;
+} nra_joint_region_t;
+
+/* Work and timing counters of the last run of a batch. */
+typedef struct nra_stats {
+    int64_t n_alignments;     /* (read, candidate) pairs scored */
+    int64_t algorithmic_cells;/* sum of qlen * tlen over those pairs */
+    int64_t executed_cells;   /* DP cells the kernels actually updated (padding included) */
+    int64_t algorithmic_bytes;/* HBM bytes the algorithm must move (packed reads + flanks + results) */
+    int64_t n_extent_tasks;   /* alignments re-run by the extents kernel (top-score ties) */
+    double  score_kernel_ms;  /* dominant kernel: sum of its launches, HIP events on the batch stream */
+    double  extent_kernel_ms; /* second-pass kernel (1D extents) */
+    double  total_ms;         /* first launch -> last launch of the run, HIP events */
+    int32_t n_score_launches;
+    int32_t reserved;
+} nra_stats_t;
+
+typedef struct nra_batch nra_batch_t;   /* device-resident inputs + outputs of one call */
+
+/* ---- library ------------------------------------------------------------------ */
+int         nra_abi_version(void);
+const char* nra_version(void);
+const char* nra_last_error(void);
+int         nra_device_count(void);              /* < 0 on error */
+void        nra_default_scoring(nra_scoring_t* sc);
+
+/* ---- 1D: replaces round3_estimation(data_type, fast_mode, repeat_region, num_cpu)
+ *      nanoRepeat_bam.py:446-450 (= round3_align :452-500, one pymm2.main call per
+ *      read at :497, + round3_estimation_from_alignment :436-444) ---------------------
+ *
+ * Inputs: n_regions regions; n_reads oriented core sequences concatenated in `seqs`
+ * with offsets seq_off[n_reads+1]; read_region[i] = region index of read i (NULL when
+ * n_regions == 1); candidate window kmin[i]..kmax[i] inclusive (kmin > kmax = skipped).
+ *
+ * Per-read outputs (all caller-allocated, n_reads entries):
+ *   best_score  max AS over the read's candidates (0 when no record)
+ *   sum_k,n_ties  sum and count of k over the records tied at best_score that pass
+ *               tstart < left_len && tlen - tend < right_len  (nanoRepeat_bam.py:426-428);
+ *               the repeat size is sum_k / n_ties in float64 (= np.mean at :431)
+ *   status      NRA_READ_*
+ * Optional per-candidate outputs (NULL to skip), sum_i max(0, kmax-kmin+1) entries in
+ * read order then k order: cand_score (AS, or -1 when below min_dp_score), cand_tstart,
+ * cand_tend (-1 unless the candidate ties the best score or NRA_F_ALL_EXTENTS is set). */
+int nra_round3_1d(int device,
+                  const nra_region_t* regions, int32_t n_regions,
+                  int32_t n_reads, const char* seqs, const int64_t* seq_off,
+                  const int32_t* read_region,
+                  const int32_t* kmin, const int32_t* kmax,
+                  const nra_scoring_t* sc, int32_t flags,
+                  int32_t* best_score, int64_t* sum_k, int32_t* n_ties, uint8_t* status,
+                  int32_t* cand_score, int32_t* cand_tstart, int32_t* cand_tend);
+
+/* ---- 2D: replaces the aligner loop + selector of
+ *      round2_estimation_of_repeat_size nanoRepeat_joint.py:397-421 and
+ *      round3_estimation_of_repeat_size nanoRepeat_joint.py:315-347 (one pymm2.main
+ *      call per grid cell at :417 / :341), followed by
+ *      estimate_two_repeats_from_paf :427-478 and the CIGAR window rescoring
+ *      tk.target_region_alignment_stats_from_cigar tk.py:435-500 ----------------------
+ *
+ * Inputs: one joint region; n_reads full reads (either strand); a list of n_cells
+ * (read, k1, k2) grid cells, grouped by read (cell_read non-decreasing).
+ * read_strand (n_reads, in/out, may be NULL): 0 = choose the strand with the higher DP
+ * score against the read's first listed cell (ties -> '+'), +1 / -1 = forced; on return
+ * holds the strand used.
+ *
+ * Per-cell outputs (optional): cell_score = AS (-1 when below min_dp_score),
+ * cell_wscore = window score over [max(0,L-10), min(tlen, L+m1*k1+mid+m2*k2+10))
+ * (nanoRepeat_joint.py:445-449).  Per-read outputs: best_wscore, sum_k1, sum_k2, n_ties
+ * over the cells tied at the maximum window score (:458-476), status OK / NO_RECORD. */
+int nra_joint_2d(int device,
+                 const nra_joint_region_t* region,
+                 int32_t n_reads, const char* seqs, const int64_t* seq_off,
+                 int8_t* read_strand,
+                 int64_t n_cells, const int32_t* cell_read,
+                 const int32_t* cell_k1, const int32_t* cell_k2,
+                 const nra_scoring_t* sc, int32_t flags,
+                 int32_t* cell_score, int32_t* cell_wscore,
+                 int32_t* best_wscore, int64_t* sum_k1, int64_t* sum_k2,
+                 int32_t* n_ties, uint8_t* status);
+
+/* ---- device-resident batches (what bench.py times): create = encode + H2D,
+ *      run = kernels only (asynchronous on the batch's own stream), fetch = D2H ------- */
+int  nra_batch1d_create(int device,
+                        const nra_region_t* regions, int32_t n_regions,
+                        int32_t n_reads, const char* seqs, const int64_t* seq_off,
+                        const int32_t* read_region,
+                        const int32_t* kmin, const int32_t* kmax,
+                        const nra_scoring_t* sc, int32_t flags,
+                        nra_batch_t** out);
+int  nra_batch2d_create(int device,
+                        const nra_joint_region_t* region,
+                        int32_t n_reads, const char* seqs, const int64_t* seq_off,
+                        const int8_t* read_strand,
+                        int64_t n_cells, const int32_t* cell_read,
+                        const int32_t* cell_k1, const int32_t* cell_k2,
+                        const nra_scoring_t* sc, int32_t flags,
+                        nra_batch_t** out);
+int  nra_batch_run(nra_batch_t* b);      /* enqueue every kernel of the path; returns at once */
+int  nra_batch_sync(nra_batch_t* b);     /* wait for the batch stream */
+int  nra_batch_stats(nra_batch_t* b, nra_stats_t* st);   /* after sync */
+int  nra_batch1d_fetch(nra_batch_t* b,
+                       int32_t* best_score, int64_t* sum_k, int32_t* n_ties, uint8_t* status,
+                       int32_t* cand_score, int32_t* cand_tstart, int32_t* cand_tend);
+int  nra_batch2d_fetch(nra_batch_t* b, int8_t* read_strand,
+                       int32_t* cell_score, int32_t* cell_wscore,
+                       int32_t* best_wscore, int64_t* sum_k1, int64_t* sum_k2,
+                       int32_t* n_ties, uint8_t* status);
+void nra_batch_destroy(nra_batch_t* b);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* NANOREPEAT_AMD_H */

@@ -1,0 +1,485 @@
+#!/usr/bin/env python3
+"""Generate the golden fixtures under tests/golden/ from the reference's own Python.
+
+Run in the build container only (needs /root/reference):
+
+    PYTHONPATH=/root/reference/src python3 -B tests/golden/make_golden.py
+
+The reference's drivers import pysam / pyminimap2 / Levenshtein, none of which exist
+offline; empty placeholder modules are registered for them so the pure
+Python around the aligner becomes callable.  Where a driver calls the aligner
+(`pymm2.main(cmd)`), a stand-in is installed that either records the call (routing
+fixtures) or answers with PAF text produced by this repo's CPU oracle (end-to-end
+fixtures: they pin everything AROUND the aligner -- window rule, bank construction,
+selectors, grid routing, CIGAR window rescoring, tie averaging -- not the aligner).
+
+Fixtures hold inputs and expected outputs only; no reference source is copied.
+"""
+import hashlib
+import json
+import os
+import random
+import shutil
+import sys
+import tempfile
+import types
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+REPO = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, REPO)
+sys.dont_write_bytecode = True
+
+for _name in ("pysam", "pyminimap2", "Levenshtein"):
+    sys.modules.setdefault(_name, types.ModuleType(_name))
+
+import numpy as np  # noqa: E402
+from NanoRepeat import tk, paf as ref_paf, repeat_region as ref_rr  # noqa: E402
+from NanoRepeat import nanoRepeat_bam as ref_bam, nanoRepeat_joint as ref_joint  # noqa: E402
+from NanoRepeat import split_alleles as ref_split  # noqa: E402
+from oracle import oracle as O  # noqa: E402
+
+tk.eprint = lambda *a, **k: None
+ref_joint.tk.eprint = tk.eprint
+RNG = random.Random(20260116)
+
+
+def rand_seq(n, rng=RNG):
+    return "".join(rng.choice("ACGT") for _ in range(n))
+
+
+def mutate(s, sub, ins, dele, rng=RNG):
+    out = []
+    for c in s:
+        x = rng.random()
+        if x < dele:
+            continue
+        if x < dele + sub:
+            out.append(rng.choice([b for b in "ACGT" if b != c]))
+        else:
+            out.append(c)
+        if rng.random() < ins:
+            out.append(rng.choice("ACGT"))
+    return "".join(out)
+
+
+def revcomp(s):
+    return s[::-1].translate(str.maketrans("ACGTN", "TGCAN"))
+
+
+def fnum(x):
+    return None if x is None else float(x)
+
+
+# --------------------------------------------------------------------------- aligner stand-ins
+class Recorder:
+    """pymm2.main stand-in: records each call; optionally answers through `answer`."""
+
+    def __init__(self, answer=None):
+        self.calls = []
+        self.answer = answer
+
+    def __call__(self, cmd):
+        toks = cmd.split()
+        rec = {"cmd": cmd}
+        files = [t for t in toks if os.path.exists(t)]
+        rec["files"] = files
+        self.calls.append(rec)
+        if self.answer:
+            return self.answer(cmd, toks, rec)
+        return "", ""
+
+
+def read_fasta(path):
+    recs, name, seq = [], None, []
+    for line in open(path):
+        line = line.rstrip("\n")
+        if line.startswith(">"):
+            if name is not None:
+                recs.append((name, "".join(seq)))
+            name, seq = line[1:], []
+        else:
+            seq.append(line)
+    if name is not None:
+        recs.append((name, "".join(seq)))
+    return recs
+
+
+def read_fastx_names_seqs(path):
+    lines = open(path).read().split("\n")
+    out = []
+    if lines and lines[0].startswith(">"):
+        return read_fasta(path)
+    for i in range(0, len(lines) - 3, 4):
+        if lines[i].startswith("@"):
+            out.append((lines[i][1:].split()[0], lines[i + 1]))
+    return out
+
+
+def paf_line(qname, qlen, strand, tname, tlen, r):
+    nm = sum(int(x[:-1]) for x in __import__("re").findall(r"\d+=", r["cigar"]))
+    alen = sum(int(x[:-1]) for x in __import__("re").findall(r"\d+[=XID]", r["cigar"]))
+    if strand == "+":
+        qs, qe = r["qstart"], r["qend"]
+    else:
+        qs, qe = qlen - r["qend"], qlen - r["qstart"]
+    return "\t".join(map(str, [qname, qlen, qs, qe, strand, tname, tlen, r["tstart"], r["tend"],
+                               nm, alen, 60, "tp:A:P", f"AS:i:{r['score']}", f"cg:Z:{r['cigar']}"]))
+
+
+def oracle_aligner(min_score=80, both_strands=False):
+    """Answers an aligner call with PAF text from the CPU oracle (optimal local DP)."""
+
+    def answer(cmd, toks, rec):
+        tfile, qfile = rec["files"][-2], rec["files"][-1]
+        out = []
+        for qname, qseq in read_fastx_names_seqs(qfile):
+            for tname, tseq in read_fasta(tfile):
+                best = None
+                for strand, s in (("+", qseq), ("-", revcomp(qseq))) if both_strands else (("+", qseq),):
+                    r = O.align_cigar(s, tseq)
+                    if r["score"] >= min_score and (best is None or r["score"] > best[1]["score"]):
+                        best = (strand, r)
+                if best:
+                    out.append(paf_line(qname, len(qseq), best[0], tname, len(tseq), best[1]))
+        text = "\n".join(out) + ("\n" if out else "")
+        if "-o" in toks:
+            with open(toks[toks.index("-o") + 1], "a") as f:
+                f.write(text)
+            return "", ""
+        return text, ""
+
+    return answer
+
+
+# --------------------------------------------------------------------------- 1D fixtures
+def make_region(left, unit, right, tmp):
+    rr = ref_rr.RepeatRegion()
+    rr.left_anchor_seq, rr.right_anchor_seq = left, right
+    rr.left_anchor_len, rr.right_anchor_len = len(left), len(right)
+    rr.repeat_unit_seq = unit
+    rr.chrom, rr.start_pos, rr.end_pos = "chrT", 1000, 1100
+    rr.temp_out_dir = tmp
+    rr.read_dict = dict()
+    rr.read_core_seq_dict = dict()
+    return rr
+
+
+def add_read(rr, name, core, r2):
+    rd = ref_rr.Read()
+    rd.read_name = name
+    rd.round2_repeat_size = r2
+    rr.read_dict[name] = rd
+    rr.read_core_seq_dict[name] = core
+
+
+def gen_1d(tmp):
+    fx = {}
+    # -- window rule + bank content (nanoRepeat_bam.py:452-500) with a recording stand-in
+    left, unit, right = rand_seq(40), "TATTG", rand_seq(40)
+    cases = []
+    for r2, fast in [(19.4, False), (19.9, False), (3.0, False), (0.0, False), (14.99, False),
+                     (15.0, False), (299.99, False), (300.0, False), (319.9, False), (400.0, False),
+                     (2999.0, False), (3000.0, False), (4000.0, False), (4000.0, True),
+                     (19.4, True), (7.5, True), (None, False), (123.456, False), (1e-9, False)]:
+        d = os.path.join(tmp, "w"); shutil.rmtree(d, ignore_errors=True); os.makedirs(d)
+        rr = make_region(left, unit, right, d)
+        add_read(rr, "r0", "ACGT" * 10, r2)
+        rec = Recorder()
+        ref_bam.pymm2.main = rec
+        ref_bam.round3_align(4, fast, rr, "ont_q20")
+        c = {"r2": r2, "fast_mode": fast, "n_calls": len(rec.calls)}
+        if rec.calls:
+            bank = read_fasta(rec.calls[0]["files"][0])
+            ks = [int(n) for n, _ in bank]
+            c.update(kmin=ks[0], kmax=ks[-1], n_templates=len(ks), contiguous=ks == list(range(ks[0], ks[-1] + 1)),
+                     bank_ok=all(s == left + unit * k + right for (n, s), k in zip(bank, ks)),
+                     cmd_flags=rec.calls[0]["cmd"].split(rec.calls[0]["files"][0])[0])
+            rd = read_fasta(rec.calls[0]["files"][1])
+            c["read_fasta"] = rd
+        cases.append(c)
+    fx["window_rule"] = {"left": left, "unit": unit, "right": right, "cases": cases}
+
+    # -- selector on canned PAF records (nanoRepeat_bam.py:408-434)
+    sel = []
+    rng = random.Random(7)
+
+    def run_selector(ll, rl, r2, recs):
+        rr = make_region("A" * ll, "TATTG", "C" * rl, tmp)
+        add_read(rr, "x", "ACGT", r2)
+        lines = []
+        for (k, AS, ts, te, tl) in recs:
+            lines.append("\t".join(map(str, ["x", 500, 0, 500, "+", k, tl, ts, te, 400, 500, 60,
+                                             "tp:A:P", f"AS:i:{AS}", "cg:Z:500="])))
+        rr.read_dict["x"].round3_paf_text = "\n".join(lines) + "\n" if lines else ""
+        ref_bam.round3_estimation_from_alignment(rr)
+        return fnum(rr.read_dict["x"].round3_repeat_size)
+
+    fixed = [
+        (1000, 1000, 19.4, [(19, 560, 905, 1190, 2095), (20, 572, 905, 1195, 2100),
+                            (21, 572, 905, 1200, 2105), (22, 580, 1001, 1205, 2110)]),
+        (1000, 1000, 19.4, [(19, 560, 905, 1190, 2095), (20, 572, 905, 1195, 2100),
+                            (21, 572, 905, 1200, 2105)]),
+        (1000, 1000, 5.5, []),
+        (1000, 1000, 5.5, [(5, 100, 999, 1026, 2025)]),
+        (1000, 1000, 5.5, [(5, 100, 1000, 1026, 2025)]),
+        (1000, 1000, 5.5, [(5, 100, 999, 1025, 2025)]),
+        (1000, 1000, 5.5, [(5, 100, 999, 1026, 2025), (6, 100, 999, 1031, 2030), (7, 100, 999, 1036, 2035)]),
+    ]
+    for ll, rl, r2, recs in fixed:
+        sel.append({"left_len": ll, "right_len": rl, "r2": r2, "records": recs,
+                    "result": run_selector(ll, rl, r2, recs)})
+    for _ in range(200):
+        ll, rl = rng.choice([50, 1000]), rng.choice([50, 1000])
+        r2 = round(rng.uniform(0, 60), 2)
+        recs = []
+        base = rng.randint(80, 900)
+        for k in rng.sample(range(0, 60), rng.randint(0, 8)):
+            AS = base - rng.choice([0, 0, 0, 2, 6, 10])
+            tl = ll + 5 * k + rl
+            ts = rng.choice([ll - 1, ll, ll + 1, max(0, ll - 40), 0])
+            te = rng.choice([ll + 5 * k, ll + 5 * k + 1, tl, tl - 1, ll + 5 * k + 20])
+            te = min(te, tl)
+            recs.append((k, AS, ts, te, tl))
+        sel.append({"left_len": ll, "right_len": rl, "r2": r2, "records": recs,
+                    "result": run_selector(ll, rl, r2, recs)})
+    fx["selector"] = sel
+
+    # -- PAF record parsing (paf.py:32-79)
+    pafs = []
+    for line in [
+        "rd1\t500\t10\t480\t+\t17\t2085\t905\t1380\t450\t480\t60\ttp:A:P\tcm:i:5\tAS:i:812\tcg:Z:470=",
+        "rd2\t500\t10\t480\t-\t9-4\t2085\t905\t1380\t450\t480\t0\ttp:A:S\tAS:i:-3\tcg:Z:30=2I70=",
+        "rd3\t123\t0\t123\t+\t0\t2000\t940\t1063\t123\t123\t60",
+    ]:
+        p = ref_paf.PAF(line.split("\t"))
+        pafs.append({"line": line, "fields": {k: getattr(p, k) for k in
+                     ("qname", "qlen", "qstart", "qend", "strand", "tname", "tlen", "tstart", "tend",
+                      "n_match", "align_len", "mapq", "is_primary", "align_score", "cigar")}})
+    fx["paf"] = pafs
+
+    # -- end to end: reference round3_estimation with the oracle answering the aligner
+    e2e = []
+    for case_id, (unit, alleles, errs, nreads, flank, fast) in enumerate([
+        ("TATTG", (8, 21), (0.02, 0.01, 0.02), 10, 60, False),
+        ("CAG", (12, 30), (0.03, 0.02, 0.03), 10, 50, True),
+        ("AT", (0, 9), (0.01, 0.01, 0.01), 6, 60, False),
+        ("GGCCCC", (5, 14), (0.0, 0.0, 0.0), 4, 60, False),
+    ]):
+        left, right = rand_seq(150), rand_seq(150)
+        d = os.path.join(tmp, f"e{case_id}"); shutil.rmtree(d, ignore_errors=True); os.makedirs(d)
+        rr = make_region(left, unit, right, d)
+        reads = []
+        for i in range(nreads):
+            kt = alleles[i % 2]
+            core = mutate(left[-flank:] + unit * kt + right[:flank], *errs)
+            r2 = max(0.0, kt + RNG.choice([-1.2, -0.4, 0.0, 0.3, 1.7]))
+            if i == nreads - 1:
+                r2 = None                      # skipped read (nanoRepeat_bam.py:460)
+            if i == nreads - 2:
+                core = rand_seq(90)            # junk: nothing reaches min score -> empty PAF
+            add_read(rr, f"read{i}", core, r2)
+            reads.append({"name": f"read{i}", "core": core, "r2": r2})
+        ref_bam.pymm2.main = Recorder(oracle_aligner(80))
+        ref_bam.round3_estimation("ont", fast, rr, 4)
+        res = {n: fnum(rd.round3_repeat_size) for n, rd in rr.read_dict.items()}
+        # text output (split_alleles.py:536-558)
+        rr.out_prefix = os.path.join(d, "out"); rr.no_details = False
+        ref_split.output_repeat_size_1d(rr)
+        txt = open(rr.out_prefix + ".repeat_size.txt").read()
+        e2e.append({"left": left, "unit": unit, "right": right, "fast_mode": fast, "reads": reads,
+                    "round3": res, "repeat_size_txt": txt, "unique_id": rr.to_unique_id()})
+    fx["e2e"] = e2e
+    return fx
+
+
+# --------------------------------------------------------------------------- 2D fixtures
+def make_repeat(chrom, start, end, unit, max_size):
+    return ref_joint.Repeat().init_from_string(f"{chrom}:{start}:{end}:{unit}:{max_size}")
+
+
+def gen_2d(tmp):
+    fx = {}
+    rng = random.Random(11)
+    # -- CIGAR window rescoring (tk.py:435-500), exact-match counter (tk.py:405-431)
+    cases = [("50=1X10=2I20=3D30=", 100, 214, 120, 200)]
+    ops = "=XID"
+    for _ in range(300):
+        n = rng.randint(1, 12)
+        cig, last, tl = "", "", 0
+        for _ in range(n):
+            op = rng.choice([o for o in ops if o != last]); last = op
+            l = rng.randint(1, 30)
+            cig += f"{l}{op}"
+            if op in "=XD":
+                tl += l
+        ts = rng.randint(0, 60)
+        a = rng.randint(0, ts + tl + 10); b = a + rng.randint(0, tl + 20)
+        cases.append((cig, ts, ts + tl, a, b))
+    # CIGARs from the oracle's own traceback on noisy repeat reads
+    for _ in range(60):
+        L, R = rand_seq(60, rng), rand_seq(60, rng)
+        u = rng.choice(["CAG", "TATTG", "AT", "CCG"]); k = rng.randint(0, 15)
+        t = L + u * k + R
+        q = mutate(L[-30:] + u * rng.randint(0, 15) + R[:30], 0.04, 0.03, 0.04, rng)
+        r = O.align_cigar(q, t)
+        if r["score"] > 0:
+            cases.append((r["cigar"], r["tstart"], r["tend"], max(0, 50), min(len(t), 60 + len(u) * k + 10)))
+    out = []
+    for cig, ts, te, a, b in cases:
+        e = tk.target_region_alignment_stats_from_cigar(cig, ts, te, a, b)
+        out.append({"cigar": cig, "tstart": ts, "tend": te, "a": a, "b": b, "score": e.score,
+                    "num_match": e.num_match, "num_mismatch": e.num_mismatch,
+                    "num_ins": e.num_ins, "num_del": e.num_del})
+    fx["cigar_stats"] = out
+    fx["exact_match"] = [{"cigar": c, "tstart": ts, "ref_start": rs, "m": m,
+                          "result": tk.calculate_repeat_size_from_exact_match(c, ts, rs, m)}
+                         for c, ts, rs, m in [("40=1X30=2D9=", 90, 100, 3), ("100=", 0, 50, 3),
+                                              ("10=2I30=1X9=", 95, 100, 5), ("7=", 100, 100, 3)]]
+
+    # -- step size (nanoRepeat_joint.py:351-374)
+    steps = []
+    for _ in range(60):
+        m = rng.randint(1, 60)
+        rep = ref_joint.Repeat(); rep.repeat_unit_size = m
+        d = {f"r{i}": (a, a + rng.randint(0, 80)) for i, a in enumerate(rng.sample(range(0, 200), rng.randint(1, 6)))}
+        steps.append({"m": m, "ranges": list(d.values()), "step": int(ref_joint.choose_best_step_size(rep, d))})
+    rep = ref_joint.Repeat(); rep.repeat_unit_size = 3
+    steps.append({"m": 3, "ranges": [(0, 25), (2, 30)],
+                  "step": int(ref_joint.choose_best_step_size(rep, {"a": (0, 25), "b": (2, 30)}))})
+    fx["step_size"] = steps
+
+    # -- anchors + template (nanoRepeat_joint.py:480-507)
+    Lf, Rf = rand_seq(1200, rng), rand_seq(1100, rng)
+    mid = "CAACAGCCGCCAC"
+    chrom = Lf + "CAG" * 19 + mid + "CCG" * 7 + Rf
+    r1 = make_repeat("chr4", len(Lf), len(Lf) + 57, "CAG", 200)
+    r2 = make_repeat("chr4", len(Lf) + 57 + 13, len(Lf) + 57 + 13 + 21, "CCG", 20)
+    la, ma, ra = ref_joint.extract_anchor_seq_for_two_repeats(chrom, r1, r2, 1000)
+    tf = os.path.join(tmp, "t.fa")
+    ref_joint.build_fasta_template_for_two_repeats(la, ma, ra, r1, r2, 3, 2, tf)
+    fx["template"] = {"chrom_sha1": hashlib.sha1(chrom.encode()).hexdigest(),
+                      "left_len": len(la), "mid": ma, "right_len": len(ra),
+                      "left_tail": la[-20:], "right_head": ra[:20],
+                      "template_k3_k2": open(tf).read().replace(la, "<L>").replace(ra, "<R>")}
+
+    # -- selector on canned PAF (nanoRepeat_joint.py:427-478)
+    pf = os.path.join(tmp, "c.paf")
+    lines = [
+        "x\t300\t0\t100\t+\t10-5\t2060\t950\t1050\t100\t100\t60\tAS:i:200\tcg:Z:100=",
+        "x\t300\t0\t100\t+\t11-5\t2063\t950\t1050\t100\t100\t60\tAS:i:180\tcg:Z:100=",
+        "x\t300\t0\t100\t+\t12-6\t2069\t950\t1050\t99\t100\t60\tAS:i:190\tcg:Z:60=1X39=",
+        "y\t300\t0\t102\t-\t7-3\t2045\t960\t1060\t100\t102\t60\tAS:i:170\tcg:Z:30=2I70=",
+        "y\t300\t0\t102\t-\t8-3\t2048\t960\t1063\t100\t105\t60\tAS:i:160\tcg:Z:30=3D70=",
+    ]
+    open(pf, "w").write("\n".join(lines) + "\n")
+    rp1 = ref_joint.Repeat(); rp1.repeat_unit_size = 3
+    rp2 = ref_joint.Repeat(); rp2.repeat_unit_size = 3
+    est = ref_joint.estimate_two_repeats_from_paf(pf, 1000, 13, rp1, rp2)
+    fx["selector"] = {"lines": lines, "left_len": 1000, "mid_len": 13, "m1": 3, "m2": 3,
+                      "k1": {k: fnum(v) for k, v in est.repeat1_count_dict.items()},
+                      "k2": {k: fnum(v) for k, v in est.repeat2_count_dict.items()}}
+
+    # -- grid routing with a recording stand-in (nanoRepeat_joint.py:376-425, 275-349)
+    def routing(ranges1, ranges2, maxs, r2sizes=None, step=None):
+        d = os.path.join(tmp, "rt"); shutil.rmtree(d, ignore_errors=True); os.makedirs(d)
+        init = ref_joint.Round1Estimation()
+        init.repeat1_count_range_dict = dict(ranges1)
+        init.repeat2_count_range_dict = dict(ranges2)
+        fq = {n: f"@{n}\nACGT\n+\n!!!!\n" for n in ranges1}
+        a = make_repeat("chr4", len(Lf), len(Lf) + 57, "CAG", maxs[0])
+        b = make_repeat("chr4", len(Lf) + 70, len(Lf) + 91, "CCG", maxs[1])
+        a.round1_min_size = min(v[0] for v in ranges1.values()); a.round1_max_size = min(maxs[0], max(v[1] for v in ranges1.values()))
+        b.round1_min_size = min(v[0] for v in ranges2.values()); b.round1_max_size = min(maxs[1], max(v[1] for v in ranges2.values()))
+        rec = Recorder(lambda cmd, toks, r: (r.update(reads=[n for n, _ in read_fastx_names_seqs(r["files"][-1])],
+                                                     tname=read_fasta(r["files"][-2])[0][0]), ("", ""))[1])
+        ref_joint.pymm2.main = rec
+        if r2sizes is None:
+            est = ref_joint.round2_estimation_of_repeat_size(init, fq, chrom, a, b, "ont", 4, d)
+            return {"round": 2, "ranges1": ranges1, "ranges2": ranges2,
+                    "round1_min1": a.round1_min_size, "round1_max1": a.round1_max_size,
+                    "round1_min2": b.round1_min_size, "round1_max2": b.round1_max_size,
+                    "step1": int(est.step_size1), "step2": int(est.step_size2),
+                    "calls": [[c["tname"], c["reads"]] for c in rec.calls],
+                    "cmd0": rec.calls[0]["cmd"].replace(d, "<D>") if rec.calls else None}
+        r2e = ref_joint.RepeatSize()
+        r2e.repeat1_count_dict = {k: v[0] for k, v in r2sizes.items()}
+        r2e.repeat2_count_dict = {k: v[1] for k, v in r2sizes.items()}
+        r2e.step_size1, r2e.step_size2 = step
+        ref_joint.round3_estimation_of_repeat_size(init, r2e, fq, chrom, a, b, "ont", 4, d)
+        return {"round": 3, "ranges1": ranges1, "ranges2": ranges2, "r2sizes": r2sizes, "step": list(step),
+                "calls": [[c["tname"], c["reads"]] for c in rec.calls]}
+
+    rts = [routing({"x": (5, 30), "y": (20, 70)}, {"x": (0, 15), "y": (2, 14)}, (210, 30))]
+    rts.append(routing({"x": (5, 30), "y": (20, 70)}, {"x": (0, 15), "y": (2, 14)}, (210, 30),
+                       r2sizes={"x": (17.0, 10.0), "y": (54.5, 7.0)}, step=(4, 2)))
+    rts.append(routing({"a": (0, 25), "b": (2, 30), "c": (10, 12)}, {"a": (3, 9), "b": (0, 4), "c": (5, 6)}, (60, 40)))
+    rts.append(routing({"a": (0, 25), "b": (2, 30), "c": (10, 12)}, {"a": (3, 9), "b": (0, 4), "c": (5, 6)}, (60, 40),
+                       r2sizes={"a": (1.0, 3.5), "b": (29.0, 0.0), "c": (10.5, 5.0)}, step=(3, 2)))
+    fx["routing"] = rts
+
+    # -- end to end: round 2 (+3) with the oracle answering the aligner
+    e2e = []
+    for cid, (u1, u2, mid_s, alleles, errs, nreads, flank) in enumerate([
+        ("CAG", "CCG", "CAACAGCCGCCAC", ((17, 10), (30, 7)), (0.02, 0.01, 0.02), 6, 70),
+        ("TATTG", "AC", "GGT", ((6, 12), (11, 3)), (0.01, 0.01, 0.01), 4, 70),
+    ]):
+        d = os.path.join(tmp, f"j{cid}"); shutil.rmtree(d, ignore_errors=True); os.makedirs(d)
+        Lx, Rx = rand_seq(160, rng), rand_seq(160, rng)
+        kref1, kref2 = 5, 4
+        chrom2 = Lx + u1 * kref1 + mid_s + u2 * kref2 + Rx
+        s1 = len(Lx); e1 = s1 + len(u1) * kref1; s2 = e1 + len(mid_s); e2_ = s2 + len(u2) * kref2
+        a = make_repeat("chrJ", s1, e1, u1, 40); b = make_repeat("chrJ", s2, e2_, u2, 20)
+        a.max_size += 10; b.max_size += 10
+        init = ref_joint.Round1Estimation()
+        reads = []
+        for i in range(nreads):
+            k1t, k2t = alleles[i % 2]
+            s = mutate(Lx[-flank:] + u1 * k1t + mid_s + u2 * k2t + Rx[:flank], *errs, rng)
+            strand = 1
+            if i % 3 == 2:
+                s = revcomp(s); strand = -1
+            name = f"jr{i}"
+            init.repeat1_count_range_dict[name] = (max(0, k1t - 9), k1t + 4)
+            init.repeat2_count_range_dict[name] = (max(0, k2t - 6), k2t + 3)
+            reads.append({"name": name, "seq": s, "strand": strand,
+                          "range1": list(init.repeat1_count_range_dict[name]),
+                          "range2": list(init.repeat2_count_range_dict[name])})
+        fqp = os.path.join(d, "in.fastq")
+        with open(fqp, "w") as f:
+            for r in reads:
+                f.write(f"@{r['name']}\n{r['seq']}\n+\n{'!' * len(r['seq'])}\n")
+        ref_joint.pymm2.main = Recorder(oracle_aligner(80, both_strands=True))
+        # fine_tune_read_count computes the global ranges, runs round 2 and (maybe) round 3
+        final = ref_joint.fine_tune_read_count(init, fqp, chrom2, a, b, "ont", 4, d)
+        txt_prefix = os.path.join(d, "out")
+        ref_split.tk.eprint = tk.eprint
+        ref_split.output_repeat_size_2d("in.fastq", a.repeat_id, b.repeat_id, txt_prefix,
+                                        final.repeat1_count_dict, final.repeat2_count_dict)
+        e2e.append({"chrom": chrom2, "repeat1": f"chrJ:{s1}:{e1}:{u1}:40", "repeat2": f"chrJ:{s2}:{e2_}:{u2}:20",
+                    "reads": reads,
+                    "round1_min1": a.round1_min_size, "round1_max1": a.round1_max_size,
+                    "round1_min2": b.round1_min_size, "round1_max2": b.round1_max_size,
+                    "final_step": [int(final.step_size1), int(final.step_size2)],
+                    "k1": {k: fnum(v) for k, v in final.repeat1_count_dict.items()},
+                    "k2": {k: fnum(v) for k, v in final.repeat2_count_dict.items()},
+                    "repeat_size_txt": open(txt_prefix + ".repeat_size.txt").read()})
+    fx["e2e"] = e2e
+    return fx
+
+
+def main():
+    tmp = tempfile.mkdtemp(prefix="nr_golden_")
+    try:
+        one = gen_1d(tmp)
+        two = gen_2d(tmp)
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+    for name, fx in (("ref_1d.json", one), ("ref_2d.json", two)):
+        with open(os.path.join(HERE, name), "w") as f:
+            json.dump(fx, f, indent=1, sort_keys=True)
+            f.write("\n")
+        print("wrote", name, os.path.getsize(os.path.join(HERE, name)), "bytes")
+
+
+if __name__ == "__main__":
+    main()
