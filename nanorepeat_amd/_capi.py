@@ -1,0 +1,313 @@
+"""ctypes binding of the C ABI declared in include/nanorepeat_amd.h.
+
+There is no CPU path: if libnanorepeat_amd.so is missing, or no HIP device is visible,
+the compute entry points raise.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libnanorepeat_amd.so")
+_LIB = None
+
+READ_OK, READ_FALLBACK, READ_NO_RECORD, READ_SKIPPED = 0, 1, 2, 3
+F_ALL_EXTENTS = 1
+
+# every symbol include/nanorepeat_amd.h declares
+EXPORTS = ("nra_abi_version", "nra_version", "nra_last_error", "nra_device_count",
+           "nra_default_scoring", "nra_round3_1d", "nra_joint_2d", "nra_batch1d_create",
+           "nra_batch2d_create", "nra_batch_run", "nra_batch_sync", "nra_batch_stats",
+           "nra_batch1d_fetch", "nra_batch2d_fetch", "nra_batch_destroy")
+
+
+class NraError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__(f"nanorepeat_amd error {code}: {msg}")
+        self.code = code
+
+
+class Scoring(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in
+                ("match", "mismatch", "gap_open1", "gap_ext1", "gap_open2", "gap_ext2",
+                 "sc_ambi", "min_dp_score")]
+
+
+class Region(C.Structure):
+    _fields_ = [("left", C.c_char_p), ("unit", C.c_char_p), ("right", C.c_char_p),
+                ("left_len", C.c_int32), ("unit_len", C.c_int32), ("right_len", C.c_int32)]
+
+
+class JointRegion(C.Structure):
+    _fields_ = [("left", C.c_char_p), ("unit1", C.c_char_p), ("mid", C.c_char_p),
+                ("unit2", C.c_char_p), ("right", C.c_char_p),
+                ("left_len", C.c_int32), ("unit1_len", C.c_int32), ("mid_len", C.c_int32),
+                ("unit2_len", C.c_int32), ("right_len", C.c_int32)]
+
+
+class Stats(C.Structure):
+    _fields_ = [("n_alignments", C.c_int64), ("algorithmic_cells", C.c_int64),
+                ("executed_cells", C.c_int64), ("algorithmic_bytes", C.c_int64),
+                ("n_extent_tasks", C.c_int64), ("score_kernel_ms", C.c_double),
+                ("extent_kernel_ms", C.c_double), ("total_ms", C.c_double),
+                ("n_score_launches", C.c_int32), ("reserved", C.c_int32)]
+
+    def as_dict(self):
+        return {n: getattr(self, n) for n, _ in self._fields_ if n != "reserved"}
+
+
+def load():
+    """Load the shared library (raises if it has not been built)."""
+    global _LIB
+    if _LIB is not None:
+        return _LIB
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            f"{LIB_PATH} not found: build it with `python -m nanorepeat_amd.build` "
+            "(hipcc --offload-arch=gfx950).  nanorepeat_amd has no CPU fallback.")
+    lib = C.CDLL(LIB_PATH)
+    p8 = C.POINTER(C.c_uint8)
+    pi8 = C.POINTER(C.c_int8)
+    pi32 = C.POINTER(C.c_int32)
+    pi64 = C.POINTER(C.c_int64)
+    vp = C.c_void_p
+    lib.nra_abi_version.restype = C.c_int
+    lib.nra_version.restype = C.c_char_p
+    lib.nra_last_error.restype = C.c_char_p
+    lib.nra_device_count.restype = C.c_int
+    lib.nra_default_scoring.argtypes = [C.POINTER(Scoring)]
+    lib.nra_round3_1d.restype = C.c_int
+    lib.nra_round3_1d.argtypes = [C.c_int, C.POINTER(Region), C.c_int32, C.c_int32, C.c_char_p, pi64,
+                                  pi32, pi32, pi32, C.POINTER(Scoring), C.c_int32,
+                                  pi32, pi64, pi32, p8, pi32, pi32, pi32]
+    lib.nra_joint_2d.restype = C.c_int
+    lib.nra_joint_2d.argtypes = [C.c_int, C.POINTER(JointRegion), C.c_int32, C.c_char_p, pi64, pi8,
+                                 C.c_int64, pi32, pi32, pi32, C.POINTER(Scoring), C.c_int32,
+                                 pi32, pi32, pi32, pi64, pi64, pi32, p8]
+    lib.nra_batch1d_create.restype = C.c_int
+    lib.nra_batch1d_create.argtypes = [C.c_int, C.POINTER(Region), C.c_int32, C.c_int32, C.c_char_p,
+                                       pi64, pi32, pi32, pi32, C.POINTER(Scoring), C.c_int32,
+                                       C.POINTER(vp)]
+    lib.nra_batch2d_create.restype = C.c_int
+    lib.nra_batch2d_create.argtypes = [C.c_int, C.POINTER(JointRegion), C.c_int32, C.c_char_p, pi64,
+                                       pi8, C.c_int64, pi32, pi32, pi32, C.POINTER(Scoring),
+                                       C.c_int32, C.POINTER(vp)]
+    for f in (lib.nra_batch_run, lib.nra_batch_sync):
+        f.restype = C.c_int
+        f.argtypes = [vp]
+    lib.nra_batch_stats.restype = C.c_int
+    lib.nra_batch_stats.argtypes = [vp, C.POINTER(Stats)]
+    lib.nra_batch1d_fetch.restype = C.c_int
+    lib.nra_batch1d_fetch.argtypes = [vp, pi32, pi64, pi32, p8, pi32, pi32, pi32]
+    lib.nra_batch2d_fetch.restype = C.c_int
+    lib.nra_batch2d_fetch.argtypes = [vp, pi8, pi32, pi32, pi32, pi64, pi64, pi32, p8]
+    lib.nra_batch_destroy.restype = None
+    lib.nra_batch_destroy.argtypes = [vp]
+    _LIB = lib
+    return lib
+
+
+def _check(rc):
+    if rc != 0:
+        raise NraError(rc, load().nra_last_error().decode(errors="replace"))
+
+
+def default_scoring(**over):
+    sc = Scoring()
+    load().nra_default_scoring(C.byref(sc))
+    for k, v in over.items():
+        setattr(sc, k, v)
+    return sc
+
+
+def device_count():
+    n = load().nra_device_count()
+    if n < 0:
+        raise NraError(n, load().nra_last_error().decode(errors="replace"))
+    return n
+
+
+def _ptr(a, ty):
+    return None if a is None else a.ctypes.data_as(C.POINTER(ty))
+
+
+def pack_reads(reads):
+    bs = [r.encode() if isinstance(r, str) else bytes(r) for r in reads]
+    off = np.zeros(len(bs) + 1, dtype=np.int64)
+    if bs:
+        off[1:] = np.cumsum([len(b) for b in bs])
+    return b"".join(bs), off
+
+
+def _regions(regions):
+    arr = (Region * max(len(regions), 1))()
+    keep = []
+    for i, (l, u, r) in enumerate(regions):
+        lb, ub, rb = l.encode(), u.encode(), r.encode()
+        keep += [lb, ub, rb]
+        arr[i] = Region(lb, ub, rb, len(lb), len(ub), len(rb))
+    return arr, keep
+
+
+def _joint_region(region):
+    parts = [x.encode() for x in region]
+    return JointRegion(*parts, *[len(x) for x in parts]), parts
+
+
+def _outputs_1d(n, ncand):
+    return dict(best_score=np.zeros(n, np.int32), sum_k=np.zeros(n, np.int64),
+                n_ties=np.zeros(n, np.int32), status=np.zeros(n, np.uint8),
+                cand_score=np.zeros(ncand, np.int32), cand_tstart=np.zeros(ncand, np.int32),
+                cand_tend=np.zeros(ncand, np.int32))
+
+
+def _outputs_2d(n, nc):
+    return dict(read_strand=np.zeros(n, np.int8), cell_score=np.zeros(nc, np.int32),
+                cell_wscore=np.zeros(nc, np.int32), best_wscore=np.zeros(n, np.int32),
+                sum_k1=np.zeros(n, np.int64), sum_k2=np.zeros(n, np.int64),
+                n_ties=np.zeros(n, np.int32), status=np.zeros(n, np.uint8))
+
+
+def round3_1d(regions, reads, kmin, kmax, read_region=None, sc=None, flags=0, device=0,
+              per_candidate=True):
+    """One-shot nra_round3_1d.  regions = [(left, unit, right)], reads = [str]."""
+    lib = load()
+    sc = sc or default_scoring()
+    n = len(reads)
+    seqs, off = pack_reads(reads)
+    kmin = np.ascontiguousarray(kmin, np.int32)
+    kmax = np.ascontiguousarray(kmax, np.int32)
+    rr = None if read_region is None else np.ascontiguousarray(read_region, np.int32)
+    regs, keep = _regions(regions)
+    ncand = int(np.maximum(kmax.astype(np.int64) - kmin + 1, 0).sum()) if per_candidate else 0
+    out = _outputs_1d(n, ncand)
+    pc = per_candidate
+    _check(lib.nra_round3_1d(device, regs, len(regions), n, seqs, _ptr(off, C.c_int64),
+                             _ptr(rr, C.c_int32), _ptr(kmin, C.c_int32), _ptr(kmax, C.c_int32),
+                             C.byref(sc), flags,
+                             _ptr(out["best_score"], C.c_int32), _ptr(out["sum_k"], C.c_int64),
+                             _ptr(out["n_ties"], C.c_int32), _ptr(out["status"], C.c_uint8),
+                             _ptr(out["cand_score"], C.c_int32) if pc else None,
+                             _ptr(out["cand_tstart"], C.c_int32) if pc else None,
+                             _ptr(out["cand_tend"], C.c_int32) if pc else None))
+    return out
+
+
+def joint_2d(region, reads, cell_read, cell_k1, cell_k2, read_strand=None, sc=None, flags=0,
+             device=0):
+    """One-shot nra_joint_2d.  region = (left, unit1, mid, unit2, right)."""
+    lib = load()
+    sc = sc or default_scoring()
+    n = len(reads)
+    seqs, off = pack_reads(reads)
+    jr, keep = _joint_region(region)
+    cr = np.ascontiguousarray(cell_read, np.int32)
+    k1 = np.ascontiguousarray(cell_k1, np.int32)
+    k2 = np.ascontiguousarray(cell_k2, np.int32)
+    out = _outputs_2d(n, len(cr))
+    if read_strand is not None:
+        out["read_strand"][:] = np.asarray(read_strand, np.int8)
+    _check(lib.nra_joint_2d(device, C.byref(jr), n, seqs, _ptr(off, C.c_int64),
+                            _ptr(out["read_strand"], C.c_int8), len(cr), _ptr(cr, C.c_int32),
+                            _ptr(k1, C.c_int32), _ptr(k2, C.c_int32), C.byref(sc), flags,
+                            _ptr(out["cell_score"], C.c_int32), _ptr(out["cell_wscore"], C.c_int32),
+                            _ptr(out["best_wscore"], C.c_int32), _ptr(out["sum_k1"], C.c_int64),
+                            _ptr(out["sum_k2"], C.c_int64), _ptr(out["n_ties"], C.c_int32),
+                            _ptr(out["status"], C.c_uint8)))
+    return out
+
+
+class Batch:
+    """Device-resident batch: create = encode + H2D, run = kernels only, fetch = D2H."""
+
+    def __init__(self, handle, kind, n_reads, n_cand):
+        self._h = handle
+        self.kind = kind
+        self.n_reads = n_reads
+        self.n_cand = n_cand
+
+    @classmethod
+    def create_1d(cls, regions, reads, kmin, kmax, read_region=None, sc=None, flags=0, device=0):
+        lib = load()
+        sc = sc or default_scoring()
+        seqs, off = pack_reads(reads)
+        kmin = np.ascontiguousarray(kmin, np.int32)
+        kmax = np.ascontiguousarray(kmax, np.int32)
+        rr = None if read_region is None else np.ascontiguousarray(read_region, np.int32)
+        regs, keep = _regions(regions)
+        h = C.c_void_p()
+        _check(lib.nra_batch1d_create(device, regs, len(regions), len(reads), seqs,
+                                      _ptr(off, C.c_int64), _ptr(rr, C.c_int32),
+                                      _ptr(kmin, C.c_int32), _ptr(kmax, C.c_int32), C.byref(sc),
+                                      flags, C.byref(h)))
+        ncand = int(np.maximum(kmax.astype(np.int64) - kmin + 1, 0).sum())
+        return cls(h, 1, len(reads), ncand)
+
+    @classmethod
+    def create_2d(cls, region, reads, cell_read, cell_k1, cell_k2, read_strand=None, sc=None,
+                  flags=0, device=0):
+        lib = load()
+        sc = sc or default_scoring()
+        seqs, off = pack_reads(reads)
+        jr, keep = _joint_region(region)
+        cr = np.ascontiguousarray(cell_read, np.int32)
+        k1 = np.ascontiguousarray(cell_k1, np.int32)
+        k2 = np.ascontiguousarray(cell_k2, np.int32)
+        st = None if read_strand is None else np.ascontiguousarray(read_strand, np.int8)
+        h = C.c_void_p()
+        _check(lib.nra_batch2d_create(device, C.byref(jr), len(reads), seqs, _ptr(off, C.c_int64),
+                                      _ptr(st, C.c_int8), len(cr), _ptr(cr, C.c_int32),
+                                      _ptr(k1, C.c_int32), _ptr(k2, C.c_int32), C.byref(sc), flags,
+                                      C.byref(h)))
+        return cls(h, 2, len(reads), len(cr))
+
+    def run(self):
+        _check(load().nra_batch_run(self._h))
+
+    def sync(self):
+        _check(load().nra_batch_sync(self._h))
+
+    def stats(self):
+        st = Stats()
+        _check(load().nra_batch_stats(self._h, C.byref(st)))
+        return st.as_dict()
+
+    def fetch(self, per_candidate=True):
+        lib = load()
+        if self.kind == 1:
+            out = _outputs_1d(self.n_reads, self.n_cand if per_candidate else 0)
+            pc = per_candidate
+            _check(lib.nra_batch1d_fetch(self._h, _ptr(out["best_score"], C.c_int32),
+                                         _ptr(out["sum_k"], C.c_int64), _ptr(out["n_ties"], C.c_int32),
+                                         _ptr(out["status"], C.c_uint8),
+                                         _ptr(out["cand_score"], C.c_int32) if pc else None,
+                                         _ptr(out["cand_tstart"], C.c_int32) if pc else None,
+                                         _ptr(out["cand_tend"], C.c_int32) if pc else None))
+            return out
+        out = _outputs_2d(self.n_reads, self.n_cand if per_candidate else 0)
+        pc = per_candidate
+        _check(lib.nra_batch2d_fetch(self._h, _ptr(out["read_strand"], C.c_int8),
+                                     _ptr(out["cell_score"], C.c_int32) if pc else None,
+                                     _ptr(out["cell_wscore"], C.c_int32) if pc else None,
+                                     _ptr(out["best_wscore"], C.c_int32), _ptr(out["sum_k1"], C.c_int64),
+                                     _ptr(out["sum_k2"], C.c_int64), _ptr(out["n_ties"], C.c_int32),
+                                     _ptr(out["status"], C.c_uint8)))
+        return out
+
+    def close(self):
+        if self._h:
+            load().nra_batch_destroy(self._h)
+            self._h = None
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

@@ -1,0 +1,800 @@
+// nra_host.cpp -- host side of the C ABI (include/nanorepeat_amd.h): encoding, 2-bit
+// packing, task bucketing, kernel sequencing on a private HIP stream, HIP-event timing.
+//
+// Replaces, in the reference, the per-read `pymm2.main(...)` loop of round3_align
+// (nanoRepeat_bam.py:452-500) + its selector (:408-450), and the per-grid-cell loop +
+// selector of the joint rounds (nanoRepeat_joint.py:315-347, 397-421, 427-478).
+// No CPU fallback exists: without a HIP device every compute entry point fails.
+#include "nanorepeat_amd.h"
+#include "nra_internal.h"
+
+#include <algorithm>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <memory>
+#include <string>
+#include <vector>
+
+#define NRA_VERSION_STR "nanorepeat_amd 0.1.0 (gfx950)"
+
+namespace {
+
+thread_local std::string g_err;
+
+int fail(int code, const std::string& msg)
+{
+    g_err = msg;
+    return code;
+}
+
+#define HIP_TRY(expr)                                                                            \
+    do {                                                                                         \
+        hipError_t e_ = (expr);                                                                  \
+        if (e_ != hipSuccess)                                                                    \
+            return fail(NRA_E_DEVICE, std::string(#expr) + ": " + hipGetErrorString(e_));        \
+    } while (0)
+
+// NRA_DEBUG=1 in the environment: synchronise after every launch and trace it on stderr
+static const bool g_debug = getenv("NRA_DEBUG") != nullptr;
+
+#define LAUNCH_TRY(expr)                                                                         \
+    do {                                                                                         \
+        if (g_debug) fprintf(stderr, "[nra] launch %.60s ...\n", #expr);                         \
+        int e_ = (expr);                                                                         \
+        if (e_ != 0)                                                                             \
+            return fail(NRA_E_DEVICE, std::string(#expr) + ": " + hipGetErrorString((hipError_t)e_)); \
+        if (g_debug) {                                                                           \
+            hipError_t s_ = hipDeviceSynchronize();                                              \
+            fprintf(stderr, "[nra]   done: %s\n", hipGetErrorString(s_));                        \
+        }                                                                                        \
+    } while (0)
+
+const int kRList[] = {
+#define X(r) r,
+    NRA_R_LIST(X)
+#undef X
+};
+const int kNumR = (int)(sizeof(kRList) / sizeof(kRList[0]));
+
+int rows_for_qlen(int qlen)   // index into kRList, -1 if too long
+{
+    for (int i = 0; i < kNumR; ++i)
+        if (64 * kRList[i] >= qlen) return i;
+    return -1;
+}
+
+inline uint8_t encode_base(char c)
+{
+    switch (c) {
+    case 'A': case 'a': return 0;
+    case 'C': case 'c': return 1;
+    case 'G': case 'g': return 2;
+    case 'T': case 't': case 'U': case 'u': return 3;
+    default: return NRA_CODE_N;
+    }
+}
+
+template <class T>
+struct DevBuf {
+    T* p = nullptr;
+    size_t n = 0;
+    ~DevBuf() { if (p) (void)hipFree(p); }
+    hipError_t alloc(size_t count)
+    {
+        n = count;
+        if (count == 0) count = 1;
+        return hipMalloc((void**)&p, count * sizeof(T));
+    }
+    hipError_t upload(const std::vector<T>& v)
+    {
+        hipError_t e = alloc(v.size());
+        if (e != hipSuccess || v.empty()) return e;
+        return hipMemcpy(p, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice);
+    }
+};
+
+struct Bucket {
+    int R = 0;
+    int n_pair = 0;            // pk16 tasks (1D score / 2D strand probe)
+    size_t pair_off = 0;       // offset into pair_tasks
+    int n_queue = 0;           // payload tasks prebuilt on the host (ALL_EXTENTS / 2D cells)
+    size_t queue_off = 0;      // offset into queue_tasks (also the base of the tie queue)
+    size_t queue_cap = 0;      // capacity of this bucket's queue region
+    int64_t cells_pair = 0;    // executed cells per run, pk16
+    int64_t cells_queue = 0;   // executed cells per run, prebuilt payload queue
+};
+
+NraScoreParams to_params(const nra_scoring_t& sc)
+{
+    NraScoreParams p;
+    p.match = sc.match; p.mismatch = sc.mismatch;
+    p.open1 = sc.gap_open1 + sc.gap_ext1; p.ext1 = sc.gap_ext1;
+    p.open2 = sc.gap_open2 + sc.gap_ext2; p.ext2 = sc.gap_ext2;
+    p.ambi = sc.sc_ambi; p.min_score = sc.min_dp_score;
+    return p;
+}
+
+bool scoring_ok(const nra_scoring_t* sc)
+{
+    if (!sc) return false;
+    if (sc->match <= 0 || sc->match > 64 || sc->mismatch < 0 || sc->mismatch > 64) return false;
+    if (sc->gap_ext1 <= 0 || sc->gap_ext2 <= 0 || sc->gap_open1 < 0 || sc->gap_open2 < 0) return false;
+    if (sc->gap_open1 + sc->gap_ext1 > 1024 || sc->gap_open2 + sc->gap_ext2 > 1024) return false;
+    if (sc->sc_ambi < 0 || sc->sc_ambi > 64) return false;
+    return true;
+}
+
+// executed cells of one wave sweep: 64*R rows x (ceil((tlen+63)/64)*64) columns
+int64_t sweep_cells(int R, int tlen) { return (int64_t)64 * R * (((int64_t)tlen + 126) / 64 * 64); }
+
+}  // namespace
+
+struct nra_batch {
+    int kind = 0;              // 1 = 1D, 2 = 2D
+    int device = 0;
+    int flags = 0;
+    int has_n = 0;
+    hipStream_t stream = nullptr;
+    NraScoreParams sp{};
+    int n_reads = 0, n_regions = 0;
+    int64_t n_cands = 0;       // 1D candidates or 2D cells
+    std::vector<Bucket> buckets;
+
+    DevBuf<uint8_t> pool;
+    DevBuf<uint32_t> q2bit, qnmask;
+    DevBuf<NraDevRegion> regions;
+    DevBuf<NraDevRead> reads, reads_init;
+    DevBuf<NraPairTask> pair_tasks;
+    DevBuf<NraTask> queue_tasks;
+    DevBuf<int32_t> queue_count;   // per bucket: prebuilt queue length (constant)
+    DevBuf<int32_t> tie_count;     // per bucket: tie queue length (device-written)
+    DevBuf<uint32_t> bucket_task_base;
+    // 1D
+    DevBuf<int32_t> kmin, kmax, read_bucket;
+    DevBuf<uint32_t> coff;
+    DevBuf<int32_t> cand_score, cand_tstart, cand_tend, best_score, n_ties;
+    DevBuf<int64_t> sum_k, sum_k2;
+    DevBuf<uint8_t> status;
+    // 2D
+    DevBuf<int32_t> probe_score, cell_k1, cell_k2;
+    DevBuf<uint32_t> cell_first, cell_cnt;
+    DevBuf<int8_t> strand_in, strand_out;
+    bool have_strand_in = false;
+
+    std::vector<hipEvent_t> ev;    // [0]=run start, [1]=run end, then pairs per dominant launch
+    int n_score_ev = 0, n_ext_ev = 0;
+    bool ran = false;
+    nra_stats_t stats{};
+
+    ~nra_batch()
+    {
+        for (hipEvent_t e : ev) (void)hipEventDestroy(e);
+        if (stream) (void)hipStreamDestroy(stream);
+    }
+};
+
+namespace {
+
+// ---- sequence packing ---------------------------------------------------------------
+struct PackedReads {
+    std::vector<uint32_t> q2bit, nmask;
+    std::vector<NraDevRead> reads;
+    bool has_n = false;
+};
+
+int pack_reads(int32_t n_reads, const char* seqs, const int64_t* seq_off, const int32_t* read_region,
+               int32_t n_regions, PackedReads& out)
+{
+    out.reads.resize((size_t)n_reads);
+    uint64_t base = 0;
+    for (int32_t r = 0; r < n_reads; ++r) {
+        int64_t len = seq_off[r + 1] - seq_off[r];
+        if (len < 0) return fail(NRA_E_ARG, "seq_off must be non-decreasing");
+        if (len > NRA_MAX_QLEN)
+            return fail(NRA_E_RANGE, "read " + std::to_string(r) + " has " + std::to_string(len) +
+                                         " bases; the kernels hold at most " + std::to_string(NRA_MAX_QLEN));
+        int32_t g = read_region ? read_region[r] : 0;
+        if (g < 0 || g >= n_regions) return fail(NRA_E_ARG, "read_region out of range");
+        out.reads[r].qoff = (uint32_t)base;
+        out.reads[r].qlen = (int32_t)len;
+        out.reads[r].region = g;
+        out.reads[r].rc = 0;
+        base += ((uint64_t)len + 31) / 32 * 32;
+        if (base > 0xfff00000ull) return fail(NRA_E_RANGE, "read pool exceeds 4G bases");
+    }
+    out.q2bit.assign((size_t)(base / 16) + 1, 0);
+    out.nmask.assign((size_t)(base / 32) + 1, 0);
+    for (int32_t r = 0; r < n_reads; ++r) {
+        const char* s = seqs + seq_off[r];
+        const uint32_t q0 = out.reads[r].qoff;
+        for (int32_t i = 0; i < out.reads[r].qlen; ++i) {
+            uint8_t c = encode_base(s[i]);
+            uint32_t b = q0 + (uint32_t)i;
+            if (c >= 4) { out.nmask[b >> 5] |= 1u << (b & 31); out.has_n = true; c = 0; }
+            out.q2bit[b >> 4] |= (uint32_t)c << ((b & 15) * 2);
+        }
+    }
+    return NRA_OK;
+}
+
+uint32_t pool_append(std::vector<uint8_t>& pool, const char* s, int32_t len, const char* unit,
+                     int32_t ulen, int32_t reps, bool& has_n)
+{
+    uint32_t off = (uint32_t)pool.size();
+    for (int32_t i = 0; i < len; ++i) { uint8_t c = encode_base(s[i]); has_n |= c >= 4; pool.push_back(c); }
+    for (int32_t k = 0; k < reps; ++k)
+        for (int32_t i = 0; i < ulen; ++i) { uint8_t c = encode_base(unit[i]); has_n |= c >= 4; pool.push_back(c); }
+    return off;
+}
+
+int common_init(nra_batch* b, int device, const nra_scoring_t* sc, int flags)
+{
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
+        return fail(NRA_E_DEVICE, "no HIP device: nanorepeat_amd has no CPU path");
+    if (device < 0 || device >= ndev) return fail(NRA_E_ARG, "device index out of range");
+    HIP_TRY(hipSetDevice(device));
+    b->device = device;
+    b->flags = flags;
+    b->sp = to_params(*sc);
+    HIP_TRY(hipStreamCreateWithFlags(&b->stream, hipStreamNonBlocking));
+    return NRA_OK;
+}
+
+int make_events(nra_batch* b, int n)
+{
+    b->ev.resize((size_t)n);
+    for (int i = 0; i < n; ++i) HIP_TRY(hipEventCreate(&b->ev[i]));
+    return NRA_OK;
+}
+
+}  // namespace
+
+// =====================================================================================
+extern "C" {
+
+int nra_abi_version(void) { return NRA_ABI_VERSION; }
+const char* nra_version(void) { return NRA_VERSION_STR; }
+const char* nra_last_error(void) { return g_err.c_str(); }
+
+int nra_device_count(void)
+{
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess) { g_err = hipGetErrorString(e); return NRA_E_DEVICE; }
+    return n;
+}
+
+void nra_default_scoring(nra_scoring_t* sc)
+{
+    if (!sc) return;
+    sc->match = 2; sc->mismatch = 4;
+    sc->gap_open1 = 4; sc->gap_ext1 = 2;
+    sc->gap_open2 = 24; sc->gap_ext2 = 1;
+    sc->sc_ambi = 1; sc->min_dp_score = 80;
+}
+
+// ---- 1D -----------------------------------------------------------------------------
+int nra_batch1d_create(int device, const nra_region_t* regions, int32_t n_regions,
+                       int32_t n_reads, const char* seqs, const int64_t* seq_off,
+                       const int32_t* read_region, const int32_t* kmin, const int32_t* kmax,
+                       const nra_scoring_t* sc, int32_t flags, nra_batch_t** out)
+{
+    if (!out) return fail(NRA_E_ARG, "out is NULL");
+    *out = nullptr;
+    if (!regions || n_regions <= 0 || n_reads < 0) return fail(NRA_E_ARG, "bad region / read count");
+    if (n_reads > 0 && (!seqs || !seq_off || !kmin || !kmax)) return fail(NRA_E_ARG, "NULL input array");
+    if (n_regions > 1 && n_reads > 0 && !read_region) return fail(NRA_E_ARG, "read_region required when n_regions > 1");
+    if (!scoring_ok(sc)) return fail(NRA_E_ARG, "scoring parameters out of range");
+    for (int32_t g = 0; g < n_regions; ++g) {
+        const nra_region_t& rg = regions[g];
+        if (rg.left_len < 0 || rg.right_len < 0 || rg.unit_len <= 0 || !rg.unit ||
+            (rg.left_len > 0 && !rg.left) || (rg.right_len > 0 && !rg.right))
+            return fail(NRA_E_ARG, "bad region " + std::to_string(g));
+    }
+
+    nra_batch* b = new nra_batch();
+    std::unique_ptr<nra_batch> guard(b);
+    b->kind = 1; b->n_reads = n_reads; b->n_regions = n_regions;
+    int rc = common_init(b, device, sc, flags);
+    if (rc) return rc;
+
+    PackedReads pr;
+    rc = pack_reads(n_reads, seqs, seq_off, read_region, n_regions, pr);
+    if (rc) return rc;
+
+    // per-region largest k, candidate offsets
+    std::vector<int32_t> region_kmax((size_t)n_regions, 0);
+    std::vector<uint32_t> coff((size_t)n_reads + 1, 0);
+    std::vector<int32_t> read_bucket((size_t)n_reads, -1);
+    int64_t total = 0;
+    for (int32_t r = 0; r < n_reads; ++r) {
+        coff[r] = (uint32_t)total;
+        if (kmin[r] > kmax[r]) continue;
+        if (kmin[r] < 0) return fail(NRA_E_ARG, "kmin < 0");
+        const int g = pr.reads[r].region;
+        const int64_t tl = (int64_t)regions[g].left_len + (int64_t)regions[g].unit_len * kmax[r] + regions[g].right_len;
+        if (tl > NRA_MAX_TLEN) return fail(NRA_E_RANGE, "template longer than " + std::to_string(NRA_MAX_TLEN));
+        region_kmax[g] = std::max(region_kmax[g], kmax[r]);
+        total += (int64_t)kmax[r] - kmin[r] + 1;
+        if (total > 0x7ff00000ll) return fail(NRA_E_RANGE, "more than 2^31 candidates in one batch");
+    }
+    coff[n_reads] = (uint32_t)total;
+    b->n_cands = total;
+
+    // code pool + region table
+    std::vector<uint8_t> pool;
+    std::vector<NraDevRegion> dregs((size_t)n_regions);
+    bool has_n = pr.has_n;
+    for (int32_t g = 0; g < n_regions; ++g) {
+        const nra_region_t& rg = regions[g];
+        NraDevRegion d{};
+        d.p1_off = pool_append(pool, rg.left, rg.left_len, rg.unit, rg.unit_len, region_kmax[g], has_n);
+        d.p2_off = (uint32_t)pool.size();
+        d.p3_off = pool_append(pool, rg.right, rg.right_len, nullptr, 0, 0, has_n);
+        d.l1 = rg.left_len; d.m1 = rg.unit_len; d.l2 = 0; d.m2 = 0; d.l3 = rg.right_len;
+        dregs[g] = d;
+        if (pool.size() > 0xfff00000ull) return fail(NRA_E_RANGE, "template pool exceeds 4 GB");
+    }
+    pool.push_back(0);
+    b->has_n = has_n ? 1 : 0;
+
+    // buckets by rows-per-lane; tasks
+    const bool all_ext = (flags & NRA_F_ALL_EXTENTS) != 0;
+    std::vector<std::vector<int32_t>> by_bucket((size_t)kNumR);
+    for (int32_t r = 0; r < n_reads; ++r) {
+        if (kmin[r] > kmax[r] || pr.reads[r].qlen == 0) continue;
+        int bi = rows_for_qlen(pr.reads[r].qlen);
+        read_bucket[r] = bi;
+        by_bucket[bi].push_back(r);
+    }
+    std::vector<NraPairTask> pair_tasks;
+    std::vector<NraTask> queue_tasks;       // ALL_EXTENTS only; otherwise just capacity
+    std::vector<int32_t> queue_count;
+    std::vector<uint32_t> task_base;
+    size_t queue_total = 0;
+    int64_t alg_cells = 0;
+    for (int bi = kNumR - 1; bi >= 0; --bi) {       // longest reads first
+        if (by_bucket[bi].empty()) continue;
+        Bucket bk; bk.R = kRList[bi];
+        bk.pair_off = pair_tasks.size();
+        bk.queue_off = queue_total;
+        for (int32_t r : by_bucket[bi]) {
+            read_bucket[r] = (int32_t)b->buckets.size();
+            const NraDevRegion& d = dregs[pr.reads[r].region];
+            for (int32_t k = kmin[r]; k <= kmax[r]; ++k) {
+                const int tl = d.l1 + d.m1 * k + d.l3;
+                alg_cells += (int64_t)pr.reads[r].qlen * tl;
+                if (all_ext) {
+                    queue_tasks.push_back(NraTask{r, k, 0, (int32_t)(coff[r] + (uint32_t)(k - kmin[r]))});
+                    bk.cells_queue += sweep_cells(bk.R, tl);
+                }
+            }
+            if (!all_ext) {
+                for (int32_t k = kmin[r]; k <= kmax[r]; k += 2) {
+                    NraPairTask t{};
+                    t.read = r; t.k1a = k; t.k2a = 0; t.out_a = (int32_t)(coff[r] + (uint32_t)(k - kmin[r]));
+                    if (k + 1 <= kmax[r]) { t.k1b = k + 1; t.k2b = 0; t.out_b = t.out_a + 1; }
+                    else { t.k1b = k; t.k2b = 0; t.out_b = -1; }
+                    t.flags = 0;
+                    pair_tasks.push_back(t);
+                    const int tl = d.l1 + d.m1 * (t.out_b >= 0 ? k + 1 : k) + d.l3;
+                    bk.cells_pair += 2 * sweep_cells(bk.R, tl);
+                }
+            }
+            bk.queue_cap += (size_t)(kmax[r] - kmin[r] + 1);
+        }
+        bk.n_pair = (int)(pair_tasks.size() - bk.pair_off);
+        bk.n_queue = all_ext ? (int)bk.queue_cap : 0;
+        queue_total += bk.queue_cap;
+        queue_count.push_back(bk.n_queue);
+        task_base.push_back((uint32_t)bk.queue_off);
+        b->buckets.push_back(bk);
+    }
+    const size_t nb = b->buckets.size();
+
+    HIP_TRY(b->pool.upload(pool));
+    HIP_TRY(b->q2bit.upload(pr.q2bit));
+    HIP_TRY(b->qnmask.upload(pr.nmask));
+    HIP_TRY(b->regions.upload(dregs));
+    HIP_TRY(b->reads.upload(pr.reads));
+    HIP_TRY(b->pair_tasks.upload(pair_tasks));
+    if (all_ext) HIP_TRY(b->queue_tasks.upload(queue_tasks));
+    else HIP_TRY(b->queue_tasks.alloc(queue_total));
+    HIP_TRY(b->queue_count.upload(queue_count));
+    HIP_TRY(b->tie_count.alloc(nb));
+    HIP_TRY(b->bucket_task_base.upload(task_base));
+    {
+        std::vector<int32_t> v(kmin, kmin + n_reads); HIP_TRY(b->kmin.upload(v));
+        std::vector<int32_t> w(kmax, kmax + n_reads); HIP_TRY(b->kmax.upload(w));
+    }
+    HIP_TRY(b->read_bucket.upload(read_bucket));
+    HIP_TRY(b->coff.upload(coff));
+    HIP_TRY(b->cand_score.alloc((size_t)total));
+    HIP_TRY(b->cand_tstart.alloc((size_t)total));
+    HIP_TRY(b->cand_tend.alloc((size_t)total));
+    HIP_TRY(b->best_score.alloc((size_t)n_reads));
+    HIP_TRY(b->n_ties.alloc((size_t)n_reads));
+    HIP_TRY(b->sum_k.alloc((size_t)n_reads));
+    HIP_TRY(b->status.alloc((size_t)n_reads));
+    rc = make_events(b, 2 + 4 * (int)nb + 2);
+    if (rc) return rc;
+
+    b->stats.n_alignments = total;
+    b->stats.algorithmic_cells = alg_cells;
+    int64_t ex = 0;
+    for (const Bucket& bk : b->buckets) ex += bk.cells_pair + bk.cells_queue;
+    b->stats.executed_cells = ex;
+    b->stats.algorithmic_bytes = (int64_t)pr.q2bit.size() * 4 + (int64_t)pool.size() + total * 4 + (int64_t)n_reads * 17;
+    *out = guard.release();
+    return NRA_OK;
+}
+
+static int run_1d(nra_batch* b)
+{
+    hipStream_t st = b->stream;
+    const size_t nb = b->buckets.size();
+    const bool all_ext = (b->flags & NRA_F_ALL_EXTENTS) != 0;
+    const size_t nc = (size_t)b->n_cands;
+    HIP_TRY(hipEventRecord(b->ev[0], st));
+    HIP_TRY(hipMemsetAsync(b->cand_score.p, 0xff, std::max<size_t>(nc, 1) * 4, st));
+    HIP_TRY(hipMemsetAsync(b->cand_tstart.p, 0xff, std::max<size_t>(nc, 1) * 4, st));
+    HIP_TRY(hipMemsetAsync(b->cand_tend.p, 0xff, std::max<size_t>(nc, 1) * 4, st));
+    HIP_TRY(hipMemsetAsync(b->tie_count.p, 0, std::max<size_t>(nb, 1) * 4, st));
+    int ev = 2;
+    b->n_score_ev = 0; b->n_ext_ev = 0;
+    const int max_waves = 256 * 16;
+    for (size_t i = 0; i < nb; ++i) {
+        const Bucket& bk = b->buckets[i];
+        HIP_TRY(hipEventRecord(b->ev[ev++], st));
+        if (!all_ext) {
+            LAUNCH_TRY(nra_launch_score_pk16(bk.R, b->has_n, st, bk.n_pair, b->pair_tasks.p + bk.pair_off,
+                                             b->reads.p, b->regions.p, b->pool.p, b->q2bit.p, b->qnmask.p,
+                                             b->sp, b->cand_score.p));
+        } else {
+            LAUNCH_TRY(nra_launch_payload_origin(bk.R, b->has_n, st, std::min(bk.n_queue, max_waves),
+                                              b->queue_tasks.p + bk.queue_off, b->queue_count.p + i,
+                                              b->reads.p, b->regions.p, b->pool.p,
+                                              b->q2bit.p, b->qnmask.p, b->sp, b->cand_score.p,
+                                              b->cand_tstart.p, b->cand_tend.p));
+        }
+        HIP_TRY(hipEventRecord(b->ev[ev++], st));
+        b->n_score_ev++;
+    }
+    LAUNCH_TRY(nra_launch_select_best_1d(st, b->n_reads, b->kmin.p, b->kmax.p, b->coff.p, b->cand_score.p,
+                                         b->read_bucket.p, b->bucket_task_base.p, all_ext ? 0 : 1,
+                                         b->queue_tasks.p, b->tie_count.p, b->best_score.p));
+    if (!all_ext) {
+        for (size_t i = 0; i < nb; ++i) {
+            const Bucket& bk = b->buckets[i];
+            HIP_TRY(hipEventRecord(b->ev[ev++], st));
+            LAUNCH_TRY(nra_launch_payload_origin(bk.R, b->has_n, st, (int)std::min<size_t>(bk.queue_cap, max_waves),
+                                              b->queue_tasks.p + bk.queue_off, b->tie_count.p + i,
+                                              b->reads.p, b->regions.p, b->pool.p,
+                                              b->q2bit.p, b->qnmask.p, b->sp, b->cand_score.p,
+                                              b->cand_tstart.p, b->cand_tend.p));
+            HIP_TRY(hipEventRecord(b->ev[ev++], st));
+            b->n_ext_ev++;
+        }
+    }
+    LAUNCH_TRY(nra_launch_select_final_1d(st, b->n_reads, b->kmin.p, b->kmax.p, b->coff.p, b->reads.p,
+                                          b->regions.p, b->cand_score.p, b->cand_tstart.p, b->cand_tend.p,
+                                          b->best_score.p, b->sum_k.p, b->n_ties.p, b->status.p));
+    HIP_TRY(hipEventRecord(b->ev[1], st));
+    return NRA_OK;
+}
+
+int nra_batch1d_fetch(nra_batch_t* b, int32_t* best_score, int64_t* sum_k, int32_t* n_ties,
+                      uint8_t* status, int32_t* cand_score, int32_t* cand_tstart, int32_t* cand_tend)
+{
+    if (!b || b->kind != 1) return fail(NRA_E_ARG, "not a 1D batch");
+    HIP_TRY(hipSetDevice(b->device));
+    HIP_TRY(hipStreamSynchronize(b->stream));
+    const size_t n = (size_t)b->n_reads, nc = (size_t)b->n_cands;
+    if (n) {
+        if (best_score) HIP_TRY(hipMemcpy(best_score, b->best_score.p, n * 4, hipMemcpyDeviceToHost));
+        if (sum_k) HIP_TRY(hipMemcpy(sum_k, b->sum_k.p, n * 8, hipMemcpyDeviceToHost));
+        if (n_ties) HIP_TRY(hipMemcpy(n_ties, b->n_ties.p, n * 4, hipMemcpyDeviceToHost));
+        if (status) HIP_TRY(hipMemcpy(status, b->status.p, n, hipMemcpyDeviceToHost));
+        if (best_score)
+            for (size_t i = 0; i < n; ++i) if (best_score[i] < 0) best_score[i] = 0;
+    }
+    if (nc) {
+        if (cand_score) HIP_TRY(hipMemcpy(cand_score, b->cand_score.p, nc * 4, hipMemcpyDeviceToHost));
+        if (cand_tstart) HIP_TRY(hipMemcpy(cand_tstart, b->cand_tstart.p, nc * 4, hipMemcpyDeviceToHost));
+        if (cand_tend) HIP_TRY(hipMemcpy(cand_tend, b->cand_tend.p, nc * 4, hipMemcpyDeviceToHost));
+    }
+    return NRA_OK;
+}
+
+int nra_round3_1d(int device, const nra_region_t* regions, int32_t n_regions, int32_t n_reads,
+                  const char* seqs, const int64_t* seq_off, const int32_t* read_region,
+                  const int32_t* kmin, const int32_t* kmax, const nra_scoring_t* sc, int32_t flags,
+                  int32_t* best_score, int64_t* sum_k, int32_t* n_ties, uint8_t* status,
+                  int32_t* cand_score, int32_t* cand_tstart, int32_t* cand_tend)
+{
+    if (n_reads > 0 && (!best_score || !sum_k || !n_ties || !status)) return fail(NRA_E_ARG, "NULL output array");
+    nra_batch_t* b = nullptr;
+    int rc = nra_batch1d_create(device, regions, n_regions, n_reads, seqs, seq_off, read_region, kmin,
+                                kmax, sc, flags, &b);
+    if (rc) return rc;
+    rc = nra_batch_run(b);
+    if (!rc) rc = nra_batch_sync(b);
+    if (!rc) rc = nra_batch1d_fetch(b, best_score, sum_k, n_ties, status, cand_score, cand_tstart, cand_tend);
+    nra_batch_destroy(b);
+    return rc;
+}
+
+// ---- 2D -----------------------------------------------------------------------------
+int nra_batch2d_create(int device, const nra_joint_region_t* reg, int32_t n_reads, const char* seqs,
+                       const int64_t* seq_off, const int8_t* read_strand, int64_t n_cells,
+                       const int32_t* cell_read, const int32_t* cell_k1, const int32_t* cell_k2,
+                       const nra_scoring_t* sc, int32_t flags, nra_batch_t** out)
+{
+    if (!out) return fail(NRA_E_ARG, "out is NULL");
+    *out = nullptr;
+    if (!reg || n_reads < 0 || n_cells < 0) return fail(NRA_E_ARG, "bad region / counts");
+    if (n_reads > 0 && (!seqs || !seq_off)) return fail(NRA_E_ARG, "NULL input array");
+    if (n_cells > 0 && (!cell_read || !cell_k1 || !cell_k2)) return fail(NRA_E_ARG, "NULL cell array");
+    if (n_cells > 0x7ff00000ll) return fail(NRA_E_RANGE, "too many cells");
+    if (!scoring_ok(sc)) return fail(NRA_E_ARG, "scoring parameters out of range");
+    if (reg->left_len < 0 || reg->right_len < 0 || reg->mid_len < 0 || reg->unit1_len <= 0 ||
+        reg->unit2_len <= 0 || !reg->unit1 || !reg->unit2)
+        return fail(NRA_E_ARG, "bad joint region");
+
+    nra_batch* b = new nra_batch();
+    std::unique_ptr<nra_batch> guard(b);
+    b->kind = 2; b->n_reads = n_reads; b->n_regions = 1; b->n_cands = n_cells;
+    int rc = common_init(b, device, sc, flags);
+    if (rc) return rc;
+
+    PackedReads pr;
+    rc = pack_reads(n_reads, seqs, seq_off, nullptr, 1, pr);
+    if (rc) return rc;
+
+    std::vector<uint32_t> first((size_t)n_reads, 0), cnt((size_t)n_reads, 0);
+    int32_t k1max = 0, k2max = 0;
+    for (int64_t c = 0; c < n_cells; ++c) {
+        const int32_t r = cell_read[c];
+        if (r < 0 || r >= n_reads || (c > 0 && r < cell_read[c - 1]) || cell_k1[c] < 0 || cell_k2[c] < 0)
+            return fail(NRA_E_ARG, "cells must be grouped by read, k >= 0");
+        if (cnt[r] == 0) first[r] = (uint32_t)c;
+        cnt[r]++;
+        k1max = std::max(k1max, cell_k1[c]);
+        k2max = std::max(k2max, cell_k2[c]);
+    }
+    const int64_t win = (int64_t)reg->unit1_len * k1max + reg->mid_len + (int64_t)reg->unit2_len * k2max + 20;
+    if (6 * win >= 32768) return fail(NRA_E_RANGE, "repeat window too long for the 16-bit window score");
+    const int64_t tlmax = (int64_t)reg->left_len + win - 20 + reg->right_len;
+    if (tlmax > NRA_MAX_TLEN) return fail(NRA_E_RANGE, "template too long");
+
+    std::vector<uint8_t> pool;
+    bool has_n = pr.has_n;
+    NraDevRegion d{};
+    d.p1_off = pool_append(pool, reg->left, reg->left_len, reg->unit1, reg->unit1_len, k1max, has_n);
+    d.p2_off = pool_append(pool, reg->mid, reg->mid_len, reg->unit2, reg->unit2_len, k2max, has_n);
+    d.p3_off = pool_append(pool, reg->right, reg->right_len, nullptr, 0, 0, has_n);
+    d.l1 = reg->left_len; d.m1 = reg->unit1_len; d.l2 = reg->mid_len; d.m2 = reg->unit2_len; d.l3 = reg->right_len;
+    pool.push_back(0);
+    b->has_n = has_n ? 1 : 0;
+    std::vector<NraDevRegion> dregs(1, d);
+
+    std::vector<std::vector<int32_t>> by_bucket((size_t)kNumR);
+    for (int32_t r = 0; r < n_reads; ++r) {
+        if (cnt[r] == 0 || pr.reads[r].qlen == 0) continue;
+        by_bucket[rows_for_qlen(pr.reads[r].qlen)].push_back(r);
+    }
+    std::vector<NraPairTask> pair_tasks;
+    std::vector<NraTask> queue_tasks;
+    std::vector<int32_t> queue_count;
+    int64_t alg_cells = 0;
+    for (int bi = kNumR - 1; bi >= 0; --bi) {
+        if (by_bucket[bi].empty()) continue;
+        Bucket bk; bk.R = kRList[bi];
+        bk.pair_off = pair_tasks.size();
+        bk.queue_off = queue_tasks.size();
+        for (int32_t r : by_bucket[bi]) {
+            // strand probe against the read's first listed cell: half A = template, half B = its revcomp
+            NraPairTask t{};
+            t.read = r; t.k1a = t.k1b = cell_k1[first[r]]; t.k2a = t.k2b = cell_k2[first[r]];
+            t.out_a = 2 * r; t.out_b = 2 * r + 1; t.flags = 1;
+            pair_tasks.push_back(t);
+            bk.cells_pair += 2 * sweep_cells(bk.R, d.l1 + d.m1 * t.k1a + d.l2 + d.m2 * t.k2a + d.l3);
+            for (uint32_t c = first[r]; c < first[r] + cnt[r]; ++c) {
+                queue_tasks.push_back(NraTask{r, cell_k1[c], cell_k2[c], (int32_t)c});
+                const int tl = d.l1 + d.m1 * cell_k1[c] + d.l2 + d.m2 * cell_k2[c] + d.l3;
+                alg_cells += (int64_t)pr.reads[r].qlen * tl;
+                bk.cells_queue += sweep_cells(bk.R, tl);
+            }
+        }
+        bk.n_pair = (int)(pair_tasks.size() - bk.pair_off);
+        bk.n_queue = (int)(queue_tasks.size() - bk.queue_off);
+        bk.queue_cap = (size_t)bk.n_queue;
+        queue_count.push_back(bk.n_queue);
+        b->buckets.push_back(bk);
+    }
+    const size_t nb = b->buckets.size();
+
+    HIP_TRY(b->pool.upload(pool));
+    HIP_TRY(b->q2bit.upload(pr.q2bit));
+    HIP_TRY(b->qnmask.upload(pr.nmask));
+    HIP_TRY(b->regions.upload(dregs));
+    HIP_TRY(b->reads.upload(pr.reads));
+    HIP_TRY(b->reads_init.upload(pr.reads));
+    HIP_TRY(b->pair_tasks.upload(pair_tasks));
+    HIP_TRY(b->queue_tasks.upload(queue_tasks));
+    HIP_TRY(b->queue_count.upload(queue_count));
+    HIP_TRY(b->probe_score.alloc(2 * (size_t)n_reads));
+    {
+        std::vector<int32_t> v(cell_k1, cell_k1 + n_cells); HIP_TRY(b->cell_k1.upload(v));
+        std::vector<int32_t> w(cell_k2, cell_k2 + n_cells); HIP_TRY(b->cell_k2.upload(w));
+    }
+    HIP_TRY(b->cell_first.upload(first));
+    HIP_TRY(b->cell_cnt.upload(cnt));
+    if (read_strand) {
+        std::vector<int8_t> v(read_strand, read_strand + n_reads);
+        HIP_TRY(b->strand_in.upload(v));
+        b->have_strand_in = true;
+    }
+    HIP_TRY(b->strand_out.alloc((size_t)n_reads));
+    HIP_TRY(b->cand_score.alloc((size_t)n_cells));     // cell_score
+    HIP_TRY(b->cand_tstart.alloc((size_t)n_cells));    // cell_wscore
+    HIP_TRY(b->best_score.alloc((size_t)n_reads));     // best_wscore
+    HIP_TRY(b->n_ties.alloc((size_t)n_reads));
+    HIP_TRY(b->sum_k.alloc((size_t)n_reads));
+    HIP_TRY(b->sum_k2.alloc((size_t)n_reads));
+    HIP_TRY(b->status.alloc((size_t)n_reads));
+    rc = make_events(b, 2 + 4 * (int)nb + 2);
+    if (rc) return rc;
+
+    b->stats.n_alignments = n_cells;
+    b->stats.algorithmic_cells = alg_cells;
+    int64_t ex = 0;
+    for (const Bucket& bk : b->buckets) ex += bk.cells_pair + bk.cells_queue;
+    b->stats.executed_cells = ex;
+    b->stats.algorithmic_bytes = (int64_t)pr.q2bit.size() * 4 + (int64_t)pool.size() + n_cells * 8 + (int64_t)n_reads * 25;
+    *out = guard.release();
+    return NRA_OK;
+}
+
+static int run_2d(nra_batch* b)
+{
+    hipStream_t st = b->stream;
+    const size_t nb = b->buckets.size();
+    const size_t nc = std::max<size_t>((size_t)b->n_cands, 1), nr = std::max<size_t>((size_t)b->n_reads, 1);
+    HIP_TRY(hipEventRecord(b->ev[0], st));
+    HIP_TRY(hipMemcpyAsync(b->reads.p, b->reads_init.p, nr * sizeof(NraDevRead), hipMemcpyDeviceToDevice, st));
+    HIP_TRY(hipMemsetAsync(b->cand_score.p, 0xff, nc * 4, st));
+    HIP_TRY(hipMemsetAsync(b->cand_tstart.p, 0, nc * 4, st));
+    HIP_TRY(hipMemsetAsync(b->probe_score.p, 0xff, 2 * nr * 4, st));
+    int ev = 2;
+    b->n_score_ev = 0; b->n_ext_ev = 0;
+    const int max_waves = 256 * 16;
+    for (size_t i = 0; i < nb; ++i) {
+        const Bucket& bk = b->buckets[i];
+        HIP_TRY(hipEventRecord(b->ev[ev++], st));
+        LAUNCH_TRY(nra_launch_score_pk16(bk.R, b->has_n, st, bk.n_pair, b->pair_tasks.p + bk.pair_off,
+                                         b->reads.p, b->regions.p, b->pool.p, b->q2bit.p, b->qnmask.p,
+                                         b->sp, b->probe_score.p));
+        HIP_TRY(hipEventRecord(b->ev[ev++], st));
+        b->n_ext_ev++;
+    }
+    LAUNCH_TRY(nra_launch_pick_strand(st, b->n_reads, b->probe_score.p,
+                                      b->have_strand_in ? b->strand_in.p : nullptr, b->strand_out.p, b->reads.p));
+    for (size_t i = 0; i < nb; ++i) {
+        const Bucket& bk = b->buckets[i];
+        HIP_TRY(hipEventRecord(b->ev[ev++], st));
+        LAUNCH_TRY(nra_launch_payload_window(bk.R, b->has_n, st, std::min(bk.n_queue, max_waves),
+                                          b->queue_tasks.p + bk.queue_off, b->queue_count.p + i,
+                                          b->reads.p, b->regions.p, b->pool.p,
+                                          b->q2bit.p, b->qnmask.p, b->sp, b->cand_score.p,
+                                          b->cand_tstart.p, nullptr));
+        HIP_TRY(hipEventRecord(b->ev[ev++], st));
+        b->n_score_ev++;
+    }
+    LAUNCH_TRY(nra_launch_select_2d(st, b->n_reads, b->cell_first.p, b->cell_cnt.p, b->cell_k1.p, b->cell_k2.p,
+                                    b->cand_score.p, b->cand_tstart.p, b->best_score.p, b->sum_k.p,
+                                    b->sum_k2.p, b->n_ties.p, b->status.p));
+    HIP_TRY(hipEventRecord(b->ev[1], st));
+    return NRA_OK;
+}
+
+int nra_batch2d_fetch(nra_batch_t* b, int8_t* read_strand, int32_t* cell_score, int32_t* cell_wscore,
+                      int32_t* best_wscore, int64_t* sum_k1, int64_t* sum_k2, int32_t* n_ties, uint8_t* status)
+{
+    if (!b || b->kind != 2) return fail(NRA_E_ARG, "not a 2D batch");
+    HIP_TRY(hipSetDevice(b->device));
+    HIP_TRY(hipStreamSynchronize(b->stream));
+    const size_t n = (size_t)b->n_reads, nc = (size_t)b->n_cands;
+    if (n) {
+        if (read_strand) HIP_TRY(hipMemcpy(read_strand, b->strand_out.p, n, hipMemcpyDeviceToHost));
+        if (best_wscore) HIP_TRY(hipMemcpy(best_wscore, b->best_score.p, n * 4, hipMemcpyDeviceToHost));
+        if (sum_k1) HIP_TRY(hipMemcpy(sum_k1, b->sum_k.p, n * 8, hipMemcpyDeviceToHost));
+        if (sum_k2) HIP_TRY(hipMemcpy(sum_k2, b->sum_k2.p, n * 8, hipMemcpyDeviceToHost));
+        if (n_ties) HIP_TRY(hipMemcpy(n_ties, b->n_ties.p, n * 4, hipMemcpyDeviceToHost));
+        if (status) HIP_TRY(hipMemcpy(status, b->status.p, n, hipMemcpyDeviceToHost));
+    }
+    if (nc) {
+        if (cell_score) HIP_TRY(hipMemcpy(cell_score, b->cand_score.p, nc * 4, hipMemcpyDeviceToHost));
+        if (cell_wscore) HIP_TRY(hipMemcpy(cell_wscore, b->cand_tstart.p, nc * 4, hipMemcpyDeviceToHost));
+    }
+    return NRA_OK;
+}
+
+int nra_joint_2d(int device, const nra_joint_region_t* region, int32_t n_reads, const char* seqs,
+                 const int64_t* seq_off, int8_t* read_strand, int64_t n_cells, const int32_t* cell_read,
+                 const int32_t* cell_k1, const int32_t* cell_k2, const nra_scoring_t* sc, int32_t flags,
+                 int32_t* cell_score, int32_t* cell_wscore, int32_t* best_wscore, int64_t* sum_k1,
+                 int64_t* sum_k2, int32_t* n_ties, uint8_t* status)
+{
+    if (n_reads > 0 && (!best_wscore || !sum_k1 || !sum_k2 || !n_ties || !status)) return fail(NRA_E_ARG, "NULL output array");
+    nra_batch_t* b = nullptr;
+    int rc = nra_batch2d_create(device, region, n_reads, seqs, seq_off, read_strand, n_cells, cell_read,
+                                cell_k1, cell_k2, sc, flags, &b);
+    if (rc) return rc;
+    rc = nra_batch_run(b);
+    if (!rc) rc = nra_batch_sync(b);
+    if (!rc) rc = nra_batch2d_fetch(b, read_strand, cell_score, cell_wscore, best_wscore, sum_k1, sum_k2, n_ties, status);
+    nra_batch_destroy(b);
+    return rc;
+}
+
+// ---- common -------------------------------------------------------------------------
+int nra_batch_run(nra_batch_t* b)
+{
+    if (!b) return fail(NRA_E_ARG, "batch is NULL");
+    HIP_TRY(hipSetDevice(b->device));
+    int rc = b->kind == 1 ? run_1d(b) : run_2d(b);
+    if (!rc) b->ran = true;
+    return rc;
+}
+
+int nra_batch_sync(nra_batch_t* b)
+{
+    if (!b) return fail(NRA_E_ARG, "batch is NULL");
+    HIP_TRY(hipSetDevice(b->device));
+    HIP_TRY(hipStreamSynchronize(b->stream));
+    return NRA_OK;
+}
+
+int nra_batch_stats(nra_batch_t* b, nra_stats_t* st)
+{
+    if (!b || !st) return fail(NRA_E_ARG, "NULL argument");
+    HIP_TRY(hipSetDevice(b->device));
+    if (b->ran) {
+        HIP_TRY(hipStreamSynchronize(b->stream));
+        float ms = 0.f;
+        HIP_TRY(hipEventElapsedTime(&ms, b->ev[0], b->ev[1]));
+        b->stats.total_ms = ms;
+        // event pairs were recorded in launch order: 1D: score..., extents...; 2D: probe..., window...
+        double first = 0, second = 0;
+        const int n_first = b->kind == 1 ? b->n_score_ev : b->n_ext_ev;
+        const int n_second = b->kind == 1 ? b->n_ext_ev : b->n_score_ev;
+        int ev = 2;
+        for (int i = 0; i < n_first; ++i, ev += 2) { HIP_TRY(hipEventElapsedTime(&ms, b->ev[ev], b->ev[ev + 1])); first += ms; }
+        for (int i = 0; i < n_second; ++i, ev += 2) { HIP_TRY(hipEventElapsedTime(&ms, b->ev[ev], b->ev[ev + 1])); second += ms; }
+        b->stats.score_kernel_ms = b->kind == 1 ? first : second;
+        b->stats.extent_kernel_ms = b->kind == 1 ? second : first;
+        b->stats.n_score_launches = b->n_score_ev;
+        if (b->kind == 1 && !(b->flags & NRA_F_ALL_EXTENTS) && !b->buckets.empty()) {
+            std::vector<int32_t> tc(b->buckets.size());
+            HIP_TRY(hipMemcpy(tc.data(), b->tie_count.p, tc.size() * 4, hipMemcpyDeviceToHost));
+            int64_t n = 0;
+            for (int32_t v : tc) n += v;
+            b->stats.n_extent_tasks = n;
+        }
+    }
+    *st = b->stats;
+    return NRA_OK;
+}
+
+void nra_batch_destroy(nra_batch_t* b)
+{
+    if (!b) return;
+    (void)hipSetDevice(b->device);
+    if (b->stream) (void)hipStreamSynchronize(b->stream);
+    delete b;
+}
+
+}  // extern "C"

@@ -1,0 +1,115 @@
+// nra_internal.h -- structures shared by the host side (nra_host.cpp) and the gfx950
+// kernels (nra_kernels.hip).  Not part of the public ABI (include/nanorepeat_amd.h).
+#ifndef NRA_INTERNAL_H
+#define NRA_INTERNAL_H
+
+#include <stdint.h>
+#include <hip/hip_runtime.h>
+
+// Base codes.  Real bases 0..3, N = 4.  The two pad codes never compare equal to
+// anything (including each other), so padded rows / columns only ever mismatch.
+#define NRA_CODE_N    4
+#define NRA_PAD_T     0x20   // target column outside [0, tlen)
+#define NRA_PAD_Q     0x40   // query row >= qlen
+
+// A candidate template is three consecutive pieces (1D: L+unit*k | - | R;
+// 2D: L+unit1*k1 | mid+unit2*k2 | R).  Pieces 1 and 2 are stored pre-expanded to their
+// largest k in the code pool, so a template is fully described by three lengths.
+struct NraDevRegion {
+    uint32_t p1_off;   // L + unit1 * k1max   (byte codes in the pool)
+    uint32_t p2_off;   // mid + unit2 * k2max
+    uint32_t p3_off;   // R
+    int32_t  l1, m1;   // left_len, unit1_len
+    int32_t  l2, m2;   // mid_len,  unit2_len (both 0 for 1D regions)
+    int32_t  l3;       // right_len
+};
+
+struct NraDevRead {
+    uint32_t qoff;     // first base of the read in the 2-bit pool (multiple of 16 bases)
+    int32_t  qlen;
+    int32_t  region;
+    int32_t  rc;       // 1: the kernels read the reverse complement (2D '-' strand reads)
+};
+
+// Two candidates of one read scored by one wave (int16 halves A / B).
+struct NraPairTask {
+    int32_t read;
+    int32_t k1a, k2a, k1b, k2b;
+    int32_t out_a, out_b;  // index into the per-candidate score array; out_b < 0: no B half
+    int32_t flags;         // bit 0: half B is the reverse complement of the template (strand probe)
+};
+
+// One candidate scored with a payload (extents / window kernels).
+struct NraTask {
+    int32_t read;
+    int32_t k1, k2;
+    int32_t out;
+};
+
+struct NraScoreParams {
+    int32_t match, mismatch;       // +a, b (penalty)
+    int32_t open1, ext1;           // q+e, e   (cost of a gap's first base / each further base)
+    int32_t open2, ext2;           // q2+e2, e2
+    int32_t ambi;                  // N penalty
+    int32_t min_score;
+};
+
+// rows-per-lane instantiations (a read of qlen rows uses the smallest R with 64*R >= qlen)
+#ifndef NRA_R_LIST
+#define NRA_R_LIST(X) X(1) X(2) X(3) X(4) X(5) X(6) X(7) X(8) X(9) X(10) X(11) X(12) X(13) X(14) \
+                      X(15) X(16) X(18) X(20) X(22) X(24) X(28) X(32) X(40) X(48)
+#endif
+#define NRA_MAX_R 48
+#define NRA_MAX_QLEN (64 * NRA_MAX_R)
+#define NRA_MAX_TLEN 65000     // payload (tstart) is 16 bits; + 64 pipeline columns
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+// launchers (nra_kernels.hip).  All asynchronous on `st`; return hipError_t as int.
+int nra_launch_score_pk16(int R, int has_n, hipStream_t st, int n_tasks,
+                          const NraPairTask* tasks, const NraDevRead* reads,
+                          const NraDevRegion* regions, const uint8_t* pool,
+                          const uint32_t* q2bit, const uint32_t* qnmask,
+                          NraScoreParams sp, int32_t* out_score);
+
+// payload kernels walk a device-side queue of *count tasks with a grid stride.  ORIGIN outputs (score, tstart, tend); WINDOW outputs (score, wscore).
+int nra_launch_payload_origin(int R, int has_n, hipStream_t st, int n_waves,
+                              const NraTask* tasks, const int32_t* count,
+                              const NraDevRead* reads, const NraDevRegion* regions,
+                              const uint8_t* pool, const uint32_t* q2bit, const uint32_t* qnmask,
+                              NraScoreParams sp,
+                              int32_t* out_score, int32_t* out_p, int32_t* out_tend);
+int nra_launch_payload_window(int R, int has_n, hipStream_t st, int n_waves,
+                              const NraTask* tasks, const int32_t* count,
+                              const NraDevRead* reads, const NraDevRegion* regions,
+                              const uint8_t* pool, const uint32_t* q2bit, const uint32_t* qnmask,
+                              NraScoreParams sp,
+                              int32_t* out_score, int32_t* out_p, int32_t* out_tend);
+
+// 1D selectors (one wave per read)
+int nra_launch_select_best_1d(hipStream_t st, int n_reads, const int32_t* kmin, const int32_t* kmax,
+                              const uint32_t* coff, const int32_t* cand_score,
+                              const int32_t* read_bucket, const uint32_t* bucket_task_base,
+                              int append_ties, NraTask* ext_tasks, int32_t* ext_count,
+                              int32_t* best_score);
+int nra_launch_select_final_1d(hipStream_t st, int n_reads, const int32_t* kmin, const int32_t* kmax,
+                               const uint32_t* coff, const NraDevRead* reads,
+                               const NraDevRegion* regions,
+                               const int32_t* cand_score, const int32_t* cand_tstart,
+                               const int32_t* cand_tend, const int32_t* best_score,
+                               int64_t* sum_k, int32_t* n_ties, uint8_t* status);
+// 2D: strand choice from the probe scores, then the per-read selector over its cells
+int nra_launch_pick_strand(hipStream_t st, int n_reads, const int32_t* probe_score,
+                           const int8_t* strand_in, int8_t* strand_out, NraDevRead* reads);
+int nra_launch_select_2d(hipStream_t st, int n_reads, const uint32_t* cell_first,
+                         const uint32_t* cell_cnt, const int32_t* cell_k1, const int32_t* cell_k2,
+                         const int32_t* cell_score, const int32_t* cell_wscore,
+                         int32_t* best_w, int64_t* sum_k1, int64_t* sum_k2, int32_t* n_ties,
+                         uint8_t* status);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,607 @@
+// nra_kernels.hip -- gfx950 (MI355X / CDNA4) kernels of the repeat-size scoring path.
+//
+// One wavefront (64 lanes) computes one optimal local alignment (two-piece affine gap)
+// of a read against an implicit candidate template as a systolic array:
+//
+//   * lane l owns query rows [l*R, l*R+R) -- their bases, H, E and E2 live in VGPRs
+//     (R is a template parameter, the row loop is fully unrolled, nothing spills);
+//   * the wave sweeps the template left to right, lane l working on column t-l at step t,
+//     so the cells of one step form an anti-diagonal band and are independent;
+//   * the only cross-lane traffic per step is three values handed from lane l-1 to lane l
+//     (H of its last row, and the two vertical gap states) plus the template base, all
+//     moved with DPP wave_shr:1 -- no LDS round trip, no barrier;
+//   * template bases are never materialised per candidate: a lane fetches 1 base per 64
+//     steps from the pre-expanded pieces (L+unit^kmax | mid+unit2^k2max | R) in the L2-
+//     resident pool and the bases circulate through the wave by DPP rotate.
+//
+// Integer VALU only (no MFMA: DP recurrences are max-plus, not a contraction).
+//
+//   k_score_pk16   scores TWO candidates of one read per wave in packed int16 halves
+//                  (v_pk_add/max/min_i16, v_pk_mad): the dominant kernel.
+//   k_payload_i32  scores one candidate in int32 with a 16-bit payload packed under the
+//                  score: tstart (ORIGIN, 1D flank test) or the CIGAR-window score
+//                  (WINDOW, 2D selector).  max() on the packed word is the
+//                  lexicographic (score, payload) max the oracle defines.
+//   select kernels implement the reference's selectors.
+//
+// Semantics: oracle/nr_oracle.c (header comment) is the contract; results are bit-identical.
+#include "nra_internal.h"
+
+// NRA_PART splits this file into translation units that build in parallel:
+// 0/undefined = everything, 1 = k_score_pk16, 2 = k_payload_i32 ORIGIN, 3 = k_payload_i32 WINDOW,
+// 4 = selectors.
+#ifndef NRA_PART
+#define NRA_PART 0
+#endif
+#define NRA_HAS_PART(n) (NRA_PART == 0 || NRA_PART == (n))
+
+#define WAVE 64
+
+typedef short s16x2 __attribute__((ext_vector_type(2)));
+typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
+
+// ------------------------------------------------------------------------------------
+// cross-lane moves (DPP, full-wave shifts exist on gfx9-family CDNA)
+// ------------------------------------------------------------------------------------
+__device__ __forceinline__ int dpp_shr1(int old, int src)   // lane l <- lane l-1 ; lane 0 keeps old
+{
+    return __builtin_amdgcn_update_dpp(old, src, 0x138 /*wave_shr:1*/, 0xf, 0xf, false);
+}
+__device__ __forceinline__ int dpp_rol1(int src)            // lane l <- lane l+1 ; lane 63 <- lane 0
+{
+    return __builtin_amdgcn_update_dpp(src, src, 0x134 /*wave_rol:1*/, 0xf, 0xf, false);
+}
+__device__ __forceinline__ s16x2 as_s(int v) { return __builtin_bit_cast(s16x2, v); }
+__device__ __forceinline__ int as_i(s16x2 v) { return __builtin_bit_cast(int, v); }
+__device__ __forceinline__ s16x2 pmax(s16x2 a, s16x2 b) { return __builtin_elementwise_max(a, b); }
+__device__ __forceinline__ s16x2 splat(int v) { s16x2 r; r.x = (short)v; r.y = (short)v; return r; }
+__device__ __forceinline__ int imax(int a, int b) { return a > b ? a : b; }
+__device__ __forceinline__ int imin(int a, int b) { return a < b ? a : b; }
+
+// ------------------------------------------------------------------------------------
+// implicit template: piece1[0:len1) + piece2[0:len2) + piece3[0:len3), optional revcomp
+// ------------------------------------------------------------------------------------
+struct Tmpl {
+    const uint8_t* p1; const uint8_t* p2; const uint8_t* p3;
+    int len1, len2, tlen, rc;
+};
+
+__device__ __forceinline__ Tmpl make_tmpl(const NraDevRegion& rg, const uint8_t* pool, int k1, int k2, int rc)
+{
+    Tmpl t;
+    t.p1 = pool + rg.p1_off; t.p2 = pool + rg.p2_off; t.p3 = pool + rg.p3_off;
+    t.len1 = rg.l1 + rg.m1 * k1;
+    t.len2 = rg.l2 + rg.m2 * k2;
+    t.tlen = t.len1 + t.len2 + rg.l3;
+    t.rc = rc;
+    return t;
+}
+
+__device__ __forceinline__ int tmpl_code(const Tmpl& t, int col)
+{
+    if (col < 0 || col >= t.tlen) return NRA_PAD_T;
+    int j = t.rc ? (t.tlen - 1 - col) : col;
+    int c;
+    if (j < t.len1) c = t.p1[j];
+    else {
+        j -= t.len1;
+        c = (j < t.len2) ? t.p2[j] : t.p3[j - t.len2];
+    }
+    if (t.rc && c < 4) c = 3 - c;
+    return c;
+}
+
+// query base of global row gi (PAD_Q beyond the read); 2-bit pool + optional N bitmap
+template <bool HAS_N>
+__device__ __forceinline__ int query_code(const NraDevRead& rd, const uint32_t* q2bit,
+                                          const uint32_t* qnmask, int gi)
+{
+    if (gi >= rd.qlen) return NRA_PAD_Q;
+    uint32_t b = rd.qoff + (uint32_t)(rd.rc ? (rd.qlen - 1 - gi) : gi);
+    int c = (q2bit[b >> 4] >> ((b & 15u) * 2u)) & 3u;
+    if (rd.rc) c = 3 - c;
+    if (HAS_N) {
+        if ((qnmask[b >> 5] >> (b & 31u)) & 1u) c = NRA_CODE_N;
+    }
+    return c;
+}
+
+#if NRA_HAS_PART(1)
+// ------------------------------------------------------------------------------------
+// k_score_pk16: two candidates per wave, packed int16
+// ------------------------------------------------------------------------------------
+template <int R, bool HAS_N>
+__global__ __launch_bounds__(WAVE) void k_score_pk16(int n_tasks, const NraPairTask* __restrict__ tasks,
+                                                     const NraDevRead* __restrict__ reads,
+                                                     const NraDevRegion* __restrict__ regions,
+                                                     const uint8_t* __restrict__ pool,
+                                                     const uint32_t* __restrict__ q2bit,
+                                                     const uint32_t* __restrict__ qnmask,
+                                                     NraScoreParams sp, int32_t* __restrict__ out_score)
+{
+    const int task = blockIdx.x;
+    if (task >= n_tasks) return;
+    const int lane = threadIdx.x;
+    const NraPairTask tk = tasks[task];
+    const NraDevRead rd = reads[tk.read];
+    const NraDevRegion rg = regions[rd.region];
+    const bool has_b = tk.out_b >= 0;
+    const Tmpl ta = make_tmpl(rg, pool, tk.k1a, tk.k2a, 0);
+    const Tmpl tb = has_b ? make_tmpl(rg, pool, tk.k1b, tk.k2b, tk.flags & 1) : ta;
+    const int ncols = imax(ta.tlen, tb.tlen);
+
+    // query rows of this lane, the base replicated into both halves
+    int qc[R];
+#pragma unroll
+    for (int i = 0; i < R; ++i) {
+        int c = query_code<HAS_N>(rd, q2bit, qnmask, lane * R + i);
+        qc[i] = c | (c << 16);
+    }
+
+    const s16x2 NEGP = splat(-16384);
+    const s16x2 ZERO = splat(0);
+    const s16x2 v_match = splat(sp.match);
+    const s16x2 v_negab = splat(-(sp.match + sp.mismatch));
+    const s16x2 v_open1 = splat(sp.open1), v_ext1 = splat(sp.ext1);
+    const s16x2 v_open2 = splat(sp.open2), v_ext2 = splat(sp.ext2);
+    const s16x2 v_negambi = splat(-sp.ambi);
+    const s16x2 v_negb = splat(-sp.mismatch);
+
+    s16x2 Hprev[R], E[R], E2[R];
+#pragma unroll
+    for (int i = 0; i < R; ++i) { Hprev[i] = ZERO; E[i] = NEGP; E2[i] = NEGP; }
+    s16x2 Hbot = ZERO, Fout = NEGP, F2out = NEGP, Hup_prev = ZERO, M = ZERO;
+    int tt = NRA_PAD_T | (NRA_PAD_T << 16);
+
+    const int nchunks = (ncols + 63 + 63) >> 6;
+    for (int c = 0; c < nchunks; ++c) {
+        const int col = c * 64 + lane;
+        int feed = tmpl_code(ta, col) | (tmpl_code(tb, col) << 16);
+#pragma unroll 2
+        for (int s = 0; s < 64; ++s) {
+            // hand-off from the lane above (rows just before mine), one column behind me
+            s16x2 F = as_s(dpp_shr1(as_i(NEGP), as_i(Fout)));
+            s16x2 F2 = as_s(dpp_shr1(as_i(NEGP), as_i(F2out)));
+            tt = dpp_shr1(feed, tt);          // lane 0 takes the next template column
+            feed = dpp_rol1(feed);
+            // substitution score: +a where the bases agree, -b otherwise.  x = q ^ t is 0 on a
+            // match and 1..0x7f otherwise, so max(a - (a+b)*x, -b) needs no compare.
+#define NRA_SUBST(i, out)                                                                          \
+            {                                                                                      \
+                const s16x2 x_ = as_s(qc[i] ^ tt);                                                 \
+                out = pmax(x_ * v_negab + v_match, v_negb);                                        \
+                if (HAS_N) {                                                                       \
+                    const s16x2 n_ = as_s(((qc[i] | tt) >> 2) & 0x00010001);                       \
+                    out = out + n_ * (v_negambi - out);                                            \
+                }                                                                                  \
+            }
+            s16x2 sc;
+            NRA_SUBST(0, sc);
+            s16x2 d = pmax(Hup_prev, ZERO) + sc;   // diagonal of my first row came in one step ago
+            Hup_prev = as_s(dpp_shr1(0, as_i(Hbot)));
+            s16x2 h = ZERO;
+#pragma unroll
+            for (int i = 0; i < R; ++i) {
+                s16x2 d_next = d;
+                if (i + 1 < R) {                   // read H(i, j-1) before it is overwritten below
+                    NRA_SUBST(i + 1, sc);
+                    d_next = pmax(Hprev[i], ZERO) + sc;
+                }
+                h = pmax(pmax(d, E[i]), pmax(F, pmax(E2[i], F2)));
+                M = pmax(M, h);
+                Hprev[i] = h;
+                const s16x2 hq = h - v_open1;
+                E[i] = pmax(E[i] - v_ext1, hq);
+                F = pmax(F - v_ext1, hq);
+                const s16x2 hq2 = h - v_open2;
+                E2[i] = pmax(E2[i] - v_ext2, hq2);
+                F2 = pmax(F2 - v_ext2, hq2);
+                d = d_next;
+            }
+#undef NRA_SUBST
+            Hbot = h; Fout = F; F2out = F2;
+        }
+    }
+    // wave-wide max of both halves
+    int m = as_i(M);
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) m = as_i(pmax(as_s(m), as_s(__shfl_xor(m, off, WAVE))));
+    if (lane == 0) {
+        const int sa = (short)(m & 0xffff), sb = (short)(m >> 16);
+        const int lo = sp.min_score > 1 ? sp.min_score : 1;
+        out_score[tk.out_a] = sa >= lo ? sa : -1;
+        if (has_b) out_score[tk.out_b] = sb >= lo ? sb : -1;
+    }
+}
+
+#endif  // part 1
+
+#if NRA_HAS_PART(2) || NRA_HAS_PART(3)
+// ------------------------------------------------------------------------------------
+// k_payload_i32: one candidate per wave, int32 cells = (score << 16) | payload
+// ------------------------------------------------------------------------------------
+#define NEG32 (-(1 << 29))
+#define WBIAS 0x8000
+
+template <int R, bool HAS_N, int MODE>
+__global__ __launch_bounds__(WAVE) void k_payload_i32(const NraTask* __restrict__ tasks,
+                                                      const int32_t* __restrict__ count,
+                                                      const NraDevRead* __restrict__ reads,
+                                                      const NraDevRegion* __restrict__ regions,
+                                                      const uint8_t* __restrict__ pool,
+                                                      const uint32_t* __restrict__ q2bit,
+                                                      const uint32_t* __restrict__ qnmask,
+                                                      NraScoreParams sp,
+                                                      int32_t* __restrict__ out_score,
+                                                      int32_t* __restrict__ out_p,
+                                                      int32_t* __restrict__ out_tend)
+{
+    const int lane = threadIdx.x;
+    const int n_tasks = *count;       // written by an earlier kernel on the same stream (or the host)
+    // grid-stride over the queue: the trip count is wave-uniform and bounded by n_tasks, so
+    // every wave drains; tasks of one queue cost about the same (same R, similar template length)
+    for (int task = blockIdx.x; task < n_tasks; task += gridDim.x) {
+        const NraTask tk = tasks[task];
+        const NraDevRead rd = reads[tk.read];
+        const NraDevRegion rg = regions[rd.region];
+        const Tmpl tm = make_tmpl(rg, pool, tk.k1, tk.k2, 0);
+        const int ncols = tm.tlen;
+        // window of nanoRepeat_joint.py:445-448 (WINDOW mode only)
+        const int wa = imax(0, rg.l1 - 10);
+        const int wb = imin(tm.tlen, tm.len1 + tm.len2 + 10);
+
+        int qc[R];
+#pragma unroll
+        for (int i = 0; i < R; ++i) qc[i] = query_code<HAS_N>(rd, q2bit, qnmask, lane * R + i);
+
+        int Hprev[R], E[R], E2[R];
+#pragma unroll
+        for (int i = 0; i < R; ++i) { Hprev[i] = NEG32; E[i] = NEG32; E2[i] = NEG32; }
+        int Hbot = NEG32, Fout = NEG32, F2out = NEG32, Hup_prev = NEG32;
+        int best = 0xffff, bestj = -1;     // (0, max payload): only cells with score >= 1 can beat it
+        int tt = NRA_PAD_T;
+        int j = -lane;
+
+        const int sA = sp.match << 16, sB = -(sp.mismatch << 16), sN = -(sp.ambi << 16);
+        const int o1 = -(sp.open1 << 16), x1 = -(sp.ext1 << 16);
+        const int o2 = -(sp.open2 << 16), x2 = -(sp.ext2 << 16);
+
+        const int nchunks = (ncols + 63 + 63) >> 6;
+        for (int c = 0; c < nchunks; ++c) {
+            int feed = tmpl_code(tm, c * 64 + lane);
+#pragma unroll 2
+            for (int s = 0; s < 64; ++s) {
+                int F = dpp_shr1(NEG32, Fout);
+                int F2 = dpp_shr1(NEG32, F2out);
+                tt = dpp_shr1(feed, tt);
+                feed = dpp_rol1(feed);
+
+                int fresh, s_eq, s_ne, n_eq, n_ne, eo1, ex1, eo2, ex2, fo1, fx1, fo2, fx2;
+                if (MODE == 0) {
+                    fresh = j;                               // (0, origin = this column)
+                    s_eq = sA; s_ne = sB; n_eq = sN; n_ne = sN;
+                    eo1 = fo1 = o1; ex1 = fx1 = x1; eo2 = fo2 = o2; ex2 = fx2 = x2;
+                } else {
+                    fresh = WBIAS;
+                    const bool inw = (j >= wa) && (j < wb);
+                    const int pe = inw ? 2 : 0, pn = inw ? -4 : 0;          // tk.py:464-475
+                    s_eq = sA + pe; s_ne = sB + pn; n_eq = sN + pe; n_ne = sN + pn;
+                    const int jn = j + 1;                                    // E written below is column j+1
+                    const bool inwn = (jn >= wa) && (jn < wb);
+                    const int po = inwn ? -4 : 0;                            // tk.py:480-485
+                    const int px = inwn ? (jn == wa ? -4 : -2) : 0;
+                    eo1 = o1 + po; ex1 = x1 + px; eo2 = o2 + po; ex2 = x2 + px;
+                    const bool fin = (jn > wa) && (jn < wb - 1);             // tk.py:476-479, ref_pos = j+1
+                    const int qo = fin ? -4 : 0, qx = fin ? -2 : 0;
+                    fo1 = o1 + qo; fx1 = x1 + qx; fo2 = o2 + qo; fx2 = x2 + qx;
+                }
+#define NRA_SUBST(i, out)                                                                          \
+                {                                                                                  \
+                    const bool eq_ = qc[i] == tt;                                                  \
+                    out = eq_ ? s_eq : s_ne;                                                       \
+                    if (HAS_N) {                                                                   \
+                        if ((qc[i] | tt) & 4) out = eq_ ? n_eq : n_ne;                             \
+                    }                                                                              \
+                }
+                int sc;
+                NRA_SUBST(0, sc);
+                int d = imax(Hup_prev, fresh) + sc;   // diagonal of my first row came in one step ago
+                Hup_prev = dpp_shr1(NEG32, Hbot);
+                int colmax = NEG32, h = NEG32;
+#pragma unroll
+                for (int i = 0; i < R; ++i) {
+                    int d_next = d;
+                    if (i + 1 < R) {                  // read H(i, j-1) before it is overwritten below
+                        NRA_SUBST(i + 1, sc);
+                        d_next = imax(Hprev[i], fresh) + sc;
+                    }
+                    h = imax(imax(d, E[i]), F);
+                    h = imax(imax(h, E2[i]), F2);
+                    colmax = imax(colmax, h);
+                    Hprev[i] = h;
+                    E[i] = imax(E[i] + ex1, h + eo1);
+                    F = imax(F + fx1, h + fo1);
+                    E2[i] = imax(E2[i] + ex2, h + eo2);
+                    F2 = imax(F2 + fx2, h + fo2);
+                    d = d_next;
+                }
+#undef NRA_SUBST
+                if (colmax > best) { best = colmax; bestj = j; }
+                Hbot = h; Fout = F; F2out = F2;
+                ++j;
+            }
+        }
+        // wave reduce: max packed value, then the smallest column holding it
+        int vmax = best;
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) vmax = imax(vmax, __shfl_xor(vmax, off, WAVE));
+        int jm = (best == vmax) ? bestj : 0x7fffffff;
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) jm = imin(jm, __shfl_xor(jm, off, WAVE));
+        if (lane == 0) {
+            const int sc = vmax >> 16;
+            const int lo = sp.min_score > 1 ? sp.min_score : 1;
+            if (sc >= lo && jm >= 0 && jm != 0x7fffffff) {
+                out_score[tk.out] = sc;
+                out_p[tk.out] = (MODE == 0) ? (vmax & 0xffff) : ((vmax & 0xffff) - WBIAS);
+                if (out_tend) out_tend[tk.out] = jm + 1;
+            } else {
+                out_score[tk.out] = -1;
+                out_p[tk.out] = (MODE == 0) ? -1 : 0;
+                if (out_tend) out_tend[tk.out] = -1;
+            }
+        }
+    }
+}
+
+#endif  // parts 2, 3
+
+#if NRA_HAS_PART(4)
+// ------------------------------------------------------------------------------------
+// selectors
+// ------------------------------------------------------------------------------------
+__device__ __forceinline__ int wave_max(int v)
+{
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v = imax(v, __shfl_xor(v, off, WAVE));
+    return v;
+}
+__device__ __forceinline__ long long wave_sum64(long long v)
+{
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, WAVE);
+    return v;
+}
+
+// max AS per read; the records tied at it become tasks of the extents kernel
+// (nanoRepeat_bam.py:423-425: only records with AS == top AS are ever examined)
+__global__ __launch_bounds__(WAVE) void k_select_best_1d(int n_reads, const int32_t* __restrict__ kmin,
+                                                        const int32_t* __restrict__ kmax,
+                                                        const uint32_t* __restrict__ coff,
+                                                        const int32_t* __restrict__ cand_score,
+                                                        const int32_t* __restrict__ read_bucket,
+                                                        const uint32_t* __restrict__ bucket_task_base,
+                                                        int append_ties, NraTask* __restrict__ ext_tasks,
+                                                        int32_t* __restrict__ ext_count,
+                                                        int32_t* __restrict__ best_score)
+{
+    const int r = blockIdx.x, lane = threadIdx.x;
+    if (r >= n_reads) return;
+    const int k0 = kmin[r], K = kmax[r] - k0 + 1;
+    if (K <= 0) { if (lane == 0) best_score[r] = -1; return; }
+    const uint32_t base = coff[r];
+    int best = -1;
+    for (int c = lane; c < K; c += WAVE) best = imax(best, cand_score[base + c]);
+    best = wave_max(best);
+    if (lane == 0) best_score[r] = best;
+    if (!append_ties || best < 0) return;
+    const int b = read_bucket[r];
+    for (int c = lane; c < K; c += WAVE) {
+        if (cand_score[base + c] == best) {
+            const int slot = atomicAdd(&ext_count[b], 1);
+            NraTask t; t.read = r; t.k1 = k0 + c; t.k2 = 0; t.out = (int)(base + c);
+            ext_tasks[bucket_task_base[b] + slot] = t;
+        }
+    }
+}
+
+// flank test + tie sum (nanoRepeat_bam.py:426-433)
+__global__ __launch_bounds__(WAVE) void k_select_final_1d(int n_reads, const int32_t* __restrict__ kmin,
+                                                         const int32_t* __restrict__ kmax,
+                                                         const uint32_t* __restrict__ coff,
+                                                         const NraDevRead* __restrict__ reads,
+                                                         const NraDevRegion* __restrict__ regions,
+                                                         const int32_t* __restrict__ cand_score,
+                                                         const int32_t* __restrict__ cand_tstart,
+                                                         const int32_t* __restrict__ cand_tend,
+                                                         const int32_t* __restrict__ best_score,
+                                                         int64_t* __restrict__ sum_k,
+                                                         int32_t* __restrict__ n_ties,
+                                                         uint8_t* __restrict__ status)
+{
+    const int r = blockIdx.x, lane = threadIdx.x;
+    if (r >= n_reads) return;
+    const int k0 = kmin[r], K = kmax[r] - k0 + 1;
+    if (K <= 0) { if (lane == 0) { sum_k[r] = 0; n_ties[r] = 0; status[r] = 3; } return; }
+    const int best = best_score[r];
+    if (best < 0) { if (lane == 0) { sum_k[r] = 0; n_ties[r] = 0; status[r] = 2; } return; }
+    const NraDevRegion rg = regions[reads[r].region];
+    const uint32_t base = coff[r];
+    long long sk = 0; int nt = 0;
+    for (int c = lane; c < K; c += WAVE) {
+        if (cand_score[base + c] == best) {
+            const int k = k0 + c;
+            const int tlen = rg.l1 + rg.m1 * k + rg.l3;
+            const int ts = cand_tstart[base + c], te = cand_tend[base + c];
+            if (ts >= 0 && ts < rg.l1 && tlen - te < rg.l3) { sk += k; ++nt; }
+        }
+    }
+    sk = wave_sum64(sk);
+    nt = (int)wave_sum64(nt);
+    if (lane == 0) { sum_k[r] = sk; n_ties[r] = nt; status[r] = nt > 0 ? 0 : 1; }
+}
+
+// strand = the orientation with the higher DP score against the read's first cell
+__global__ void k_pick_strand(int n_reads, const int32_t* __restrict__ probe_score,
+                              const int8_t* __restrict__ strand_in, int8_t* __restrict__ strand_out,
+                              NraDevRead* __restrict__ reads)
+{
+    const int r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= n_reads) return;
+    int s = strand_in ? strand_in[r] : 0;
+    if (s == 0) s = (probe_score[2 * r + 1] > probe_score[2 * r]) ? -1 : 1;
+    strand_out[r] = (int8_t)s;
+    reads[r].rc = s < 0 ? 1 : 0;
+}
+
+// max window score per read, ties -> sums of k1 / k2 (nanoRepeat_joint.py:458-476)
+__global__ __launch_bounds__(WAVE) void k_select_2d(int n_reads, const uint32_t* __restrict__ cell_first,
+                                                   const uint32_t* __restrict__ cell_cnt,
+                                                   const int32_t* __restrict__ cell_k1,
+                                                   const int32_t* __restrict__ cell_k2,
+                                                   const int32_t* __restrict__ cell_score,
+                                                   const int32_t* __restrict__ cell_wscore,
+                                                   int32_t* __restrict__ best_w, int64_t* __restrict__ sum_k1,
+                                                   int64_t* __restrict__ sum_k2, int32_t* __restrict__ n_ties,
+                                                   uint8_t* __restrict__ status)
+{
+    const int r = blockIdx.x, lane = threadIdx.x;
+    if (r >= n_reads) return;
+    const uint32_t f = cell_first[r], n = cell_cnt[r];
+    const int NONE = -0x7fffffff;
+    int w = NONE;
+    for (uint32_t c = lane; c < n; c += WAVE)
+        if (cell_score[f + c] >= 0) w = imax(w, cell_wscore[f + c]);
+    w = wave_max(w);
+    if (w == NONE) {
+        if (lane == 0) { best_w[r] = 0; sum_k1[r] = 0; sum_k2[r] = 0; n_ties[r] = 0; status[r] = 2; }
+        return;
+    }
+    long long s1 = 0, s2 = 0; int nt = 0;
+    for (uint32_t c = lane; c < n; c += WAVE)
+        if (cell_score[f + c] >= 0 && cell_wscore[f + c] == w) { s1 += cell_k1[f + c]; s2 += cell_k2[f + c]; ++nt; }
+    s1 = wave_sum64(s1); s2 = wave_sum64(s2); nt = (int)wave_sum64(nt);
+    if (lane == 0) { best_w[r] = w; sum_k1[r] = s1; sum_k2[r] = s2; n_ties[r] = nt; status[r] = 0; }
+}
+
+#endif  // part 4
+
+// ------------------------------------------------------------------------------------
+// launchers
+// ------------------------------------------------------------------------------------
+#if NRA_HAS_PART(1)
+extern "C" int nra_launch_score_pk16(int R, int has_n, hipStream_t st, int n_tasks,
+                                     const NraPairTask* tasks, const NraDevRead* reads,
+                                     const NraDevRegion* regions, const uint8_t* pool,
+                                     const uint32_t* q2bit, const uint32_t* qnmask,
+                                     NraScoreParams sp, int32_t* out_score)
+{
+    if (n_tasks <= 0) return 0;
+#define CASE(r)                                                                                     \
+    case r:                                                                                         \
+        if (has_n) k_score_pk16<r, true><<<n_tasks, WAVE, 0, st>>>(n_tasks, tasks, reads, regions, pool, q2bit, qnmask, sp, out_score); \
+        else k_score_pk16<r, false><<<n_tasks, WAVE, 0, st>>>(n_tasks, tasks, reads, regions, pool, q2bit, qnmask, sp, out_score);       \
+        break;
+    switch (R) {
+        NRA_R_LIST(CASE)
+    default: return (int)hipErrorInvalidValue;
+    }
+#undef CASE
+    return (int)hipGetLastError();
+}
+
+#endif  // part 1
+
+#if NRA_HAS_PART(2) || NRA_HAS_PART(3)
+template <int MODE>
+static int launch_payload(int R, int has_n, hipStream_t st, int n_waves, const NraTask* tasks,
+                          const int32_t* count, const NraDevRead* reads,
+                          const NraDevRegion* regions, const uint8_t* pool, const uint32_t* q2bit,
+                          const uint32_t* qnmask, NraScoreParams sp, int32_t* out_score,
+                          int32_t* out_p, int32_t* out_tend)
+{
+#define CASE(r)                                                                                     \
+    case r:                                                                                         \
+        if (has_n) k_payload_i32<r, true, MODE><<<n_waves, WAVE, 0, st>>>(tasks, count, reads, regions, pool, q2bit, qnmask, sp, out_score, out_p, out_tend); \
+        else k_payload_i32<r, false, MODE><<<n_waves, WAVE, 0, st>>>(tasks, count, reads, regions, pool, q2bit, qnmask, sp, out_score, out_p, out_tend);       \
+        break;
+    switch (R) {
+        NRA_R_LIST(CASE)
+    default: return (int)hipErrorInvalidValue;
+    }
+#undef CASE
+    return (int)hipGetLastError();
+}
+
+#if NRA_HAS_PART(2)
+extern "C" int nra_launch_payload_origin(int R, int has_n, hipStream_t st, int n_waves,
+                                         const NraTask* tasks, const int32_t* count,
+                                         const NraDevRead* reads, const NraDevRegion* regions,
+                                         const uint8_t* pool, const uint32_t* q2bit, const uint32_t* qnmask,
+                                         NraScoreParams sp, int32_t* out_score, int32_t* out_p,
+                                         int32_t* out_tend)
+{
+    if (n_waves <= 0) return 0;
+    return launch_payload<0>(R, has_n, st, n_waves, tasks, count, reads, regions, pool, q2bit, qnmask, sp, out_score, out_p, out_tend);
+}
+#endif
+#if NRA_HAS_PART(3)
+extern "C" int nra_launch_payload_window(int R, int has_n, hipStream_t st, int n_waves,
+                                         const NraTask* tasks, const int32_t* count,
+                                         const NraDevRead* reads, const NraDevRegion* regions,
+                                         const uint8_t* pool, const uint32_t* q2bit, const uint32_t* qnmask,
+                                         NraScoreParams sp, int32_t* out_score, int32_t* out_p,
+                                         int32_t* out_tend)
+{
+    if (n_waves <= 0) return 0;
+    return launch_payload<1>(R, has_n, st, n_waves, tasks, count, reads, regions, pool, q2bit, qnmask, sp, out_score, out_p, out_tend);
+}
+#endif
+#endif  // parts 2, 3
+
+#if NRA_HAS_PART(4)
+extern "C" int nra_launch_select_best_1d(hipStream_t st, int n_reads, const int32_t* kmin, const int32_t* kmax,
+                                         const uint32_t* coff, const int32_t* cand_score,
+                                         const int32_t* read_bucket, const uint32_t* bucket_task_base,
+                                         int append_ties, NraTask* ext_tasks, int32_t* ext_count,
+                                         int32_t* best_score)
+{
+    if (n_reads <= 0) return 0;
+    k_select_best_1d<<<n_reads, WAVE, 0, st>>>(n_reads, kmin, kmax, coff, cand_score, read_bucket,
+                                               bucket_task_base, append_ties, ext_tasks, ext_count, best_score);
+    return (int)hipGetLastError();
+}
+
+extern "C" int nra_launch_select_final_1d(hipStream_t st, int n_reads, const int32_t* kmin, const int32_t* kmax,
+                                          const uint32_t* coff, const NraDevRead* reads,
+                                          const NraDevRegion* regions, const int32_t* cand_score,
+                                          const int32_t* cand_tstart, const int32_t* cand_tend,
+                                          const int32_t* best_score, int64_t* sum_k, int32_t* n_ties,
+                                          uint8_t* status)
+{
+    if (n_reads <= 0) return 0;
+    k_select_final_1d<<<n_reads, WAVE, 0, st>>>(n_reads, kmin, kmax, coff, reads, regions, cand_score,
+                                                cand_tstart, cand_tend, best_score, sum_k, n_ties, status);
+    return (int)hipGetLastError();
+}
+
+extern "C" int nra_launch_pick_strand(hipStream_t st, int n_reads, const int32_t* probe_score,
+                                      const int8_t* strand_in, int8_t* strand_out, NraDevRead* reads)
+{
+    if (n_reads <= 0) return 0;
+    k_pick_strand<<<(n_reads + 255) / 256, 256, 0, st>>>(n_reads, probe_score, strand_in, strand_out, reads);
+    return (int)hipGetLastError();
+}
+
+extern "C" int nra_launch_select_2d(hipStream_t st, int n_reads, const uint32_t* cell_first,
+                                    const uint32_t* cell_cnt, const int32_t* cell_k1, const int32_t* cell_k2,
+                                    const int32_t* cell_score, const int32_t* cell_wscore,
+                                    int32_t* best_w, int64_t* sum_k1, int64_t* sum_k2, int32_t* n_ties,
+                                    uint8_t* status)
+{
+    if (n_reads <= 0) return 0;
+    k_select_2d<<<n_reads, WAVE, 0, st>>>(n_reads, cell_first, cell_cnt, cell_k1, cell_k2, cell_score,
+                                          cell_wscore, best_w, sum_k1, sum_k2, n_ties, status);
+    return (int)hipGetLastError();
+}
+#endif  // part 4
