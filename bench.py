@@ -1,0 +1,216 @@
+#!/usr/bin/env python3
+"""bench.py -- headline benchmark of the repeat-size scoring path on MI355X.
+
+Metric (BASELINE.json): read-alignments/sec = (reads x candidate-k) scored per second.
+Workload (BASELINE.json configs[1]): 10 000 synthetic ONT-error core reads over one 5 bp
+motif (TATTG), every read scored against k in [5,200] (196 candidates), alleles k=40/150.
+
+A "step" is one pass of the whole hot path (packed-int16 scoring of every candidate,
+per-read best score, extents of the top-score ties, flank test + tie mean) over one batch
+whose inputs are already resident in HBM (nra_batch1d_create has run).  N > 1: one process
+per GPU, every rank owns its own 10 000 reads (weak scaling, no data-path collective), then
+one small all_gather of the per-read results over RCCL.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+# Integer-VALU roofline of the dominant kernel (DESIGN.md "Roofline"):
+#   peak lane-ops/s = 256 CU x 4 SIMD x 32 lanes/clk x 2.4 GHz
+#   a two-piece-affine local-alignment cell needs 20 packed-int16 VALU instructions per
+#   2 cells (3 substitution, 2 diagonal, 4 five-way max, 1 running max, 10 gap states)
+#   = 10 lane-ops per cell; that is the work counted as "achieved".
+VALU_PEAK_TLANEOPS = 256 * 4 * 32 * 2.4e9 / 1e12      # 78.6
+LANEOPS_PER_CELL = 10.0
+HBM_PEAK_GBPS = 8000.0
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--reads", type=int, default=10000, help="reads per GPU (config 2: 10000)")
+    ap.add_argument("--cpu-sample", type=int, default=-1,
+                    help="reads in the CPU-baseline sample (-1: sized for ~15 s, 0: skip)")
+    return ap.parse_args()
+
+
+def host_cores():
+    """Threads for the CPU baseline: the process's CPU share (affinity, cgroup quota), capped at
+    the 16 cores a one-GPU box grants; NRA_CPU_THREADS overrides."""
+    if os.environ.get("NRA_CPU_THREADS"):
+        return max(1, int(os.environ["NRA_CPU_THREADS"]))
+    try:
+        n = len(os.sched_getaffinity(0))
+    except AttributeError:
+        n = os.cpu_count() or 1
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except Exception:
+        pass
+    return min(n, 16)
+
+
+def cpu_baseline(data, n_sample):
+    """Times the CPU oracle (oracle/, the restatement of the reference algorithm: K independent
+    optimal alignments per read) on a bounded sample of the same workload, all host cores."""
+    from oracle import oracle as O
+    cores = host_cores()
+    n_total = len(data["reads"])
+    # calibrate on one read per thread, then size the sample for ~15 s of CPU work
+    n_cal = min(cores, n_total)
+    t0 = time.perf_counter()
+    O.round3_1d(data["regions"], data["reads"][:n_cal], data["kmin"][:n_cal], data["kmax"][:n_cal], threads=cores)
+    t_cal = max(time.perf_counter() - t0, 1e-3)
+    if n_sample < 0:
+        n_sample = int(n_cal * 15.0 / t_cal)
+        n_sample = max(cores, n_sample // cores * cores)
+    n_sample = min(n_sample, n_total)
+    if n_sample == 0:
+        return None
+    reads = data["reads"][:n_sample]
+    kmin, kmax = data["kmin"][:n_sample], data["kmax"][:n_sample]
+    t0 = time.perf_counter()
+    out = O.round3_1d(data["regions"], reads, kmin, kmax, threads=cores)
+    dt = time.perf_counter() - t0
+    n_align = int((kmax.astype("int64") - kmin + 1).sum())
+    return {"value": n_align / dt, "unit": "read-alignments/s", "cores": cores, "kind": "port",
+            "sample": f"first {n_sample} of the workload's reads x 196 candidates = {n_align} "
+                      f"alignments in {dt:.1f} s; CPU restatement (optimal DP, oracle/nr_oracle.c, "
+                      f"OpenMP over reads), not minimap2"}, out
+
+
+def main():
+    args = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+
+    import numpy as np
+    import torch
+    from nanorepeat_amd import _capi as A, synth
+
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: no HIP device visible (there is no CPU path)")
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+
+    # every rank owns its own reads (weak scaling); rank 0's are BASELINE config 2 exactly
+    data = synth.config2(n_reads=args.reads, seed=synth.SEED + rank)
+    n_align = int((data["kmax"].astype(np.int64) - data["kmin"] + 1).sum())
+    batch = A.Batch.create_1d(data["regions"], data["reads"], data["kmin"], data["kmax"],
+                              device=local_rank)
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    def step():
+        batch.run()
+        batch.sync()
+        if dist is not None:
+            out = batch.fetch(per_candidate=False)
+            mine = torch.from_numpy(np.stack([out["sum_k"], out["n_ties"].astype(np.int64),
+                                              out["status"].astype(np.int64)], 1)).cuda()
+            gathered = [torch.empty_like(mine) for _ in range(world)]
+            dist.all_gather(gathered, mine)
+            return gathered
+        return None
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    barrier()
+    dt = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+    st = batch.stats()
+    out = batch.fetch(per_candidate=False)
+    ok = out["status"] == 0
+    est = out["sum_k"][ok] / np.maximum(out["n_ties"][ok], 1)
+    exact = float(np.mean(est == data["k_true"][ok])) if ok.any() else 0.0
+
+    if rank == 0:
+        kernel_s = st["score_kernel_ms"] / 1e3
+        cells_per_s = st["algorithmic_cells"] / kernel_s
+        achieved = cells_per_s * LANEOPS_PER_CELL / 1e12
+        traffic = None
+        prof = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
+        if os.path.exists(prof):
+            try:
+                traffic = json.load(open(prof)).get("hbm_bytes_per_step_score_kernels")
+            except Exception:
+                traffic = None
+        hbm_gbps = st["algorithmic_bytes"] / kernel_s / 1e9
+        line = {
+            "metric": "read-alignments/sec (reads x candidate-k)",
+            "value": world * n_align * args.steps / dt,
+            "unit": "read-alignments/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": dt / args.steps * 1e3,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "int16", "data": "synthetic",
+            "config": {"workload": "config2: 10k synthetic ONT-error core reads (q~400/950), motif "
+                                   "TATTG, k in [5,200] (196 candidates/read), 1000 bp flanks",
+                       "reads_per_gpu": args.reads, "alignments_per_gpu": n_align,
+                       "parallelism": f"reads sharded over {world} GPU(s), no data-path collective"},
+            "roofline": {"bound": "valu", "achieved": achieved, "peak": VALU_PEAK_TLANEOPS,
+                         "unit": "Tlane-op/s", "frac": achieved / VALU_PEAK_TLANEOPS,
+                         "traffic": traffic,
+                         "kernel": "k_score_pk16<R> (all R instantiations of one step)",
+                         "kernel_ms_per_step": st["score_kernel_ms"],
+                         "n_launches_per_step": st["n_score_launches"],
+                         "algorithmic_cells_per_step": st["algorithmic_cells"],
+                         "executed_cells_per_step": st["executed_cells"],
+                         "Tcell_per_s": cells_per_s / 1e12,
+                         "laneops_per_cell": LANEOPS_PER_CELL,
+                         "hbm": {"algorithmic_bytes_per_step": st["algorithmic_bytes"],
+                                 "achieved_GBps": hbm_gbps, "peak_GBps": HBM_PEAK_GBPS,
+                                 "frac": hbm_gbps / HBM_PEAK_GBPS,
+                                 "note": "compute-bound by design: ~4 B per read-alignment"}},
+            "extent_kernel_ms_per_step": st["extent_kernel_ms"],
+            "extent_tasks_per_step": st["n_extent_tasks"],
+            "device_ms_per_step": st["total_ms"],
+            "exact_k_fraction": exact,
+        }
+        if world == 1:
+            cb = cpu_baseline(data, args.cpu_sample) if args.cpu_sample != 0 else None
+            if cb is not None:
+                base, ref = cb
+                n = len(ref["sum_k"])
+                same = all(np.array_equal(out[k][:n], ref[k]) for k in ("sum_k", "n_ties", "status", "best_score"))
+                base["gpu_matches_sample"] = bool(same)
+                line["cpu_baseline"] = base
+                line["gpu_over_cpu"] = line["value"] / base["value"]
+        print(json.dumps(line), flush=True)
+    batch.close()
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,249 @@
+"""2D (joint) host side: mirrors the reference's round-2 / round-3 grid interface
+(nanoRepeat_joint.py:234-507).
+
+The functions keep the reference's names, arguments and results; the aligner loop -- one
+`pymm2.main(...)` call, one template file and one FASTQ per grid cell -- and the Python
+CIGAR walk of `estimate_two_repeats_from_paf` are replaced by ONE call through the C ABI
+(`nra_joint_2d`) per round: the (read, k1, k2) list goes in, per-read tie sums come back.
+"""
+import numpy as np
+
+from . import _capi
+
+
+class Repeat:
+    """nanoRepeat_joint.py:42-69."""
+
+    def __init__(self):
+        self.repeat_id = ""
+        self.chrom = ""
+        self.start = -1
+        self.end = -1
+        self.repeat_unit = ""
+        self.repeat_unit_size = 0
+        self.min_size = 0
+        self.max_size = 1000
+        self.round1_min_size = 0
+        self.round1_max_size = 1000
+
+    def init_from_string(self, string):
+        col_list = string.split(":")
+        if len(col_list) != 5:
+            raise ValueError("--repeat1 and --repeat2 should be in this format: "
+                             "chr:start:end:repeat_unit:max_size")
+        self.chrom, self.start, self.end, self.repeat_unit, self.max_size = col_list
+        self.start = int(self.start)
+        self.end = int(self.end)
+        self.repeat_unit_size = len(self.repeat_unit)
+        self.min_size = 0
+        self.max_size = int(self.max_size)
+        self.repeat_id = "-".join(col_list[0:4])
+        return self
+
+
+class Round1Estimation:
+    """nanoRepeat_joint.py:71-84: per-read [min, max) ranges of both repeat counts."""
+
+    def __init__(self):
+        self.repeat1_count_range_dict = dict()
+        self.repeat2_count_range_dict = dict()
+
+
+class RepeatSize:
+    """nanoRepeat_joint.py:86-91."""
+
+    def __init__(self):
+        self.repeat1_count_dict = dict()
+        self.repeat2_count_dict = dict()
+        self.step_size1 = 1
+        self.step_size2 = 1
+
+
+def choose_best_step_size(repeat, count_range_dict):
+    """nanoRepeat_joint.py:351-374 (first minimum wins: the sort is stable)."""
+    max_len = 50
+    max_step_size = int(max_len / repeat.repeat_unit_size)
+    if max_step_size < 1:
+        max_step_size = 1
+    error_list = [b - a for a, b in count_range_dict.values()]
+    mean_range = np.mean(error_list)
+    best_size, best_count = None, None
+    for size in range(1, max_step_size + 1):
+        count = int(mean_range / size) + 1
+        count += size * 2 + 2
+        if best_count is None or count < best_count:
+            best_size, best_count = size, count
+    return best_size
+
+
+def extract_anchor_seq_for_two_repeats(repeat_chrom_seq, repeat1, repeat2, max_flanking_len):
+    """nanoRepeat_joint.py:480-497."""
+    left_end_pos = repeat1.start
+    left_start_pos = max(0, left_end_pos - max_flanking_len)
+    right_start_pos = repeat2.end
+    right_end_pos = min(len(repeat_chrom_seq), right_start_pos + max_flanking_len)
+    return (repeat_chrom_seq[left_start_pos:left_end_pos],
+            repeat_chrom_seq[repeat1.end:repeat2.start],
+            repeat_chrom_seq[right_start_pos:right_end_pos])
+
+
+def build_template_for_two_repeats(left_anchor_seq, mid_anchor_seq, right_anchor_seq, repeat1,
+                                   repeat2, repeat_count1, repeat_count2):
+    """Name and sequence of one grid-cell template (nanoRepeat_joint.py:499-507)."""
+    return ("%d-%d" % (repeat_count1, repeat_count2),
+            left_anchor_seq + repeat1.repeat_unit * repeat_count1 + mid_anchor_seq +
+            repeat2.repeat_unit * repeat_count2 + right_anchor_seq)
+
+
+def _read_seq(fastq_record):
+    return fastq_record.split("\n")[1].strip()
+
+
+def _score_cells(region, readnames, fastq_dict, cells_by_read, device, scoring, scorer, strands):
+    """One C-ABI call for every (read, k1, k2) cell; returns (RepeatSize, raw outputs)."""
+    scorer = scorer or _capi.joint_2d
+    names = [n for n in readnames if cells_by_read.get(n)]
+    reads = [_read_seq(fastq_dict[n]) for n in names]
+    cell_read, k1, k2 = [], [], []
+    for i, n in enumerate(names):
+        for a, b in cells_by_read[n]:
+            cell_read.append(i); k1.append(a); k2.append(b)
+    est = RepeatSize()
+    if not names:
+        return est, None
+    st_in = None
+    if strands is not None:
+        st_in = np.array([strands.get(n, 0) for n in names], np.int8)
+    out = scorer(region, reads, np.array(cell_read, np.int32), np.array(k1, np.int32),
+                 np.array(k2, np.int32), read_strand=st_in, sc=scoring, device=device)
+    for i, n in enumerate(names):
+        if int(out["status"][i]) == _capi.READ_OK:        # nanoRepeat_joint.py:473-476
+            nt = np.float64(out["n_ties"][i])
+            est.repeat1_count_dict[n] = np.float64(out["sum_k1"][i]) / nt
+            est.repeat2_count_dict[n] = np.float64(out["sum_k2"][i]) / nt
+        if strands is not None:
+            strands[n] = int(out["read_strand"][i])
+    return est, out
+
+
+def round2_estimation_of_repeat_size(initial_estimation, fastq_dict, repeat_chrom_seq, repeat1,
+                                     repeat2, data_type="ont", num_threads=1, out_dir=None,
+                                     device=0, scoring=None, scorer=None, strands=None):
+    """Coarse grid (nanoRepeat_joint.py:376-425).  `strands` (dict, optional) carries each
+    read's orientation between rounds so round 3 does not probe it again."""
+    assert repeat1.chrom == repeat2.chrom
+    assert repeat1.start < repeat2.start
+    max_flanking_len = 1000
+    step_size1 = choose_best_step_size(repeat1, initial_estimation.repeat1_count_range_dict)
+    step_size2 = choose_best_step_size(repeat2, initial_estimation.repeat2_count_range_dict)
+    left, mid, right = extract_anchor_seq_for_two_repeats(repeat_chrom_seq, repeat1, repeat2, max_flanking_len)
+    cells = {}
+    for repeat_count1 in range(repeat1.round1_min_size, repeat1.round1_max_size + 1, step_size1):
+        for repeat_count2 in range(repeat2.round1_min_size, repeat2.round1_max_size + 1, step_size2):
+            for readname in fastq_dict:                                   # :402-409
+                if readname not in initial_estimation.repeat1_count_range_dict: continue
+                if readname not in initial_estimation.repeat2_count_range_dict: continue
+                min1, max1 = initial_estimation.repeat1_count_range_dict[readname]
+                min2, max2 = initial_estimation.repeat2_count_range_dict[readname]
+                if min1 <= repeat_count1 < max1 and min2 <= repeat_count2 < max2:
+                    cells.setdefault(readname, []).append((repeat_count1, repeat_count2))
+    region = (left, repeat1.repeat_unit, mid, repeat2.repeat_unit, right)
+    est, _ = _score_cells(region, list(fastq_dict), fastq_dict, cells, device, scoring, scorer, strands)
+    est.step_size1 = step_size1
+    est.step_size2 = step_size2
+    return est
+
+
+def round3_estimation_of_repeat_size(initial_estimation, round2_estimation, fastq_dict,
+                                     repeat_chrom_seq, repeat1, repeat2, data_type="ont",
+                                     num_threads=1, out_dir=None, device=0, scoring=None,
+                                     scorer=None, strands=None):
+    """Fine grid, step 1 (nanoRepeat_joint.py:275-349)."""
+    if len(round2_estimation.repeat1_count_dict) == 0 or len(round2_estimation.repeat2_count_dict) == 0:
+        return RepeatSize()
+    assert repeat1.chrom == repeat2.chrom
+    assert repeat1.start < repeat2.start
+    max_flanking_len = 1000
+    buffer_size1 = round2_estimation.step_size1
+    buffer_size2 = round2_estimation.step_size2
+    size1_list, size2_list = [], []
+    for readname in round2_estimation.repeat1_count_dict:
+        if readname not in round2_estimation.repeat2_count_dict: continue
+        size1_list.append(round2_estimation.repeat1_count_dict[readname])
+        size2_list.append(round2_estimation.repeat2_count_dict[readname])
+    min_size1 = max(0, int(min(size1_list) - buffer_size1))               # :298-303
+    max_size1 = int(max(size1_list) + buffer_size1 + 2)
+    min_size2 = max(0, int(min(size2_list) - buffer_size2))
+    max_size2 = int(max(size2_list) + buffer_size2 + 2)
+    left, mid, right = extract_anchor_seq_for_two_repeats(repeat_chrom_seq, repeat1, repeat2, max_flanking_len)
+    cells = {}
+    for repeat_count1 in range(min_size1, max_size1):
+        for repeat_count2 in range(min_size2, max_size2):
+            for readname in fastq_dict:                                   # :320-330
+                if readname not in round2_estimation.repeat1_count_dict: continue
+                if readname not in round2_estimation.repeat2_count_dict: continue
+                size1 = round2_estimation.repeat1_count_dict[readname]
+                size2 = round2_estimation.repeat2_count_dict[readname]
+                if repeat_count1 < size1 - buffer_size1 or repeat_count1 >= size1 + buffer_size1: continue
+                if repeat_count2 < size2 - buffer_size2 or repeat_count2 >= size2 + buffer_size2: continue
+                r1min1, r1max1 = initial_estimation.repeat1_count_range_dict[readname]
+                r1min2, r1max2 = initial_estimation.repeat2_count_range_dict[readname]
+                if repeat_count1 < r1min1 or repeat_count1 >= r1max1: continue
+                if repeat_count2 < r1min2 or repeat_count2 >= r1max2: continue
+                cells.setdefault(readname, []).append((repeat_count1, repeat_count2))
+    region = (left, repeat1.repeat_unit, mid, repeat2.repeat_unit, right)
+    est, _ = _score_cells(region, list(fastq_dict), fastq_dict, cells, device, scoring, scorer, strands)
+    est.step_size1 = 1
+    est.step_size2 = 1
+    return est
+
+
+def fine_tune_read_count(initial_estimation, fastq_dict, repeat_chrom_seq, repeat1, repeat2,
+                         data_type="ont", num_threads=1, out_dir=None, device=0, scoring=None,
+                         scorer=None):
+    """nanoRepeat_joint.py:234-273.  Takes the FASTQ as the {readname: 4-line record} dict the
+    reference builds at :264 (file ingestion is outside the hot path)."""
+    assert repeat1.chrom == repeat2.chrom
+    assert repeat1.start < repeat2.start
+    repeat1.round1_max_size = 0
+    repeat2.round1_max_size = 0
+    repeat1.round1_min_size = repeat1.max_size
+    repeat2.round1_min_size = repeat2.max_size
+    for lo, hi in initial_estimation.repeat1_count_range_dict.values():
+        repeat1.round1_max_size = max(repeat1.round1_max_size, hi)
+        repeat1.round1_min_size = min(repeat1.round1_min_size, lo)
+    for lo, hi in initial_estimation.repeat2_count_range_dict.values():
+        repeat2.round1_max_size = max(repeat2.round1_max_size, hi)
+        repeat2.round1_min_size = min(repeat2.round1_min_size, lo)
+    repeat1.round1_max_size = min(repeat1.round1_max_size, repeat1.max_size)
+    repeat2.round1_max_size = min(repeat2.round1_max_size, repeat2.max_size)
+    strands = {}
+    round2_estimation = round2_estimation_of_repeat_size(
+        initial_estimation, fastq_dict, repeat_chrom_seq, repeat1, repeat2, data_type, num_threads,
+        out_dir, device, scoring, scorer, strands)
+    if round2_estimation.step_size1 > 1 and round2_estimation.step_size2 > 1:     # :268
+        return round3_estimation_of_repeat_size(
+            initial_estimation, round2_estimation, fastq_dict, repeat_chrom_seq, repeat1, repeat2,
+            data_type, num_threads, out_dir, device, scoring, scorer, strands)
+    return round2_estimation
+
+
+def output_repeat_size_2d(in_fastq_file, repeat1_id, repeat2_id, out_prefix, repeat1_count_dict,
+                          repeat2_count_dict):
+    """`<out_prefix>.repeat_size.txt` of the joint mode (split_alleles.py:560-600).  Rows are
+    sorted by the first size (stable); reads present on one axis only cannot come out of the
+    selector (both dicts are filled together)."""
+    rows = []
+    seen = set()
+    for readname in list(repeat1_count_dict) + list(repeat2_count_dict):
+        if readname in seen:
+            continue
+        seen.add(readname)
+        rows.append((readname, repeat1_count_dict[readname], repeat2_count_dict[readname]))
+    rows.sort(key=lambda x: x[1])
+    text = f"##Input_FASTQ={in_fastq_file}\n#Read_Name\t{repeat1_id}.Repeat_Size\t{repeat2_id}.Repeat_Size\n"
+    text += "".join(f"{n}\t{a:.1f}\t{b:.1f}\n" for n, a, b in rows)
+    if out_prefix:
+        with open(f"{out_prefix}.repeat_size.txt", "w") as f:
+            f.write(text)
+    return {n: (a, b) for n, a, b in rows}, text

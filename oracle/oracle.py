@@ -92,6 +92,15 @@ def default_scoring(**over):
     return sc
 
 
+def _scoring(sc):
+    """Accepts None, this module's Scoring, or any object with the same eight fields."""
+    if sc is None:
+        return default_scoring()
+    if isinstance(sc, Scoring):
+        return sc
+    return Scoring(*[getattr(sc, n) for n, _ in Scoring._fields_])
+
+
 def _ptr(a, ty):
     return None if a is None else a.ctypes.data_as(C.POINTER(ty))
 
@@ -106,7 +115,7 @@ def encode(s):
 def align(q, t, sc=None, mode=MODE_ORIGIN, wa=0, wb=0):
     """(score, payload, tend) of the optimal local alignment of q vs t (str or code arrays)."""
     lib = load()
-    sc = sc or default_scoring()
+    sc = _scoring(sc)
     qc = encode(q) if not isinstance(q, np.ndarray) else np.ascontiguousarray(q, np.uint8)
     tc = encode(t) if not isinstance(t, np.ndarray) else np.ascontiguousarray(t, np.uint8)
     pay, tend = C.c_int32(0), C.c_int32(0)
@@ -118,7 +127,7 @@ def align(q, t, sc=None, mode=MODE_ORIGIN, wa=0, wb=0):
 def align_cigar(q, t, sc=None, mode=MODE_ORIGIN, wa=0, wb=0):
     """dict(score, cigar, tstart, tend, qstart, qend, payload) with traceback."""
     lib = load()
-    sc = sc or default_scoring()
+    sc = _scoring(sc)
     qc, tc = encode(q), encode(t)
     cap = 16 * (len(qc) + len(tc)) + 64
     buf = C.create_string_buffer(cap)
@@ -156,12 +165,12 @@ def _regions(regions):
     return arr, keep
 
 
-def round3_1d(regions, reads, kmin, kmax, read_region=None, sc=None, flags=0, threads=None):
+def round3_1d(regions, reads, kmin, kmax, read_region=None, sc=None, flags=0, threads=None, **_ignored):
     """Oracle twin of nra_round3_1d.  regions = [(left, unit, right)], reads = [str]."""
     lib = load()
     if threads is not None:
         lib.nro_set_threads(int(threads))
-    sc = sc or default_scoring()
+    sc = _scoring(sc)
     n = len(reads)
     seqs, off = _pack_reads(reads)
     kmin = np.ascontiguousarray(kmin, np.int32)
@@ -185,12 +194,12 @@ def round3_1d(regions, reads, kmin, kmax, read_region=None, sc=None, flags=0, th
 
 
 def joint_2d(region, reads, cell_read, cell_k1, cell_k2, read_strand=None, sc=None, flags=0,
-             threads=None):
+             threads=None, **_ignored):
     """Oracle twin of nra_joint_2d.  region = (left, unit1, mid, unit2, right)."""
     lib = load()
     if threads is not None:
         lib.nro_set_threads(int(threads))
-    sc = sc or default_scoring()
+    sc = _scoring(sc)
     n = len(reads)
     seqs, off = _pack_reads(reads)
     parts = [x.encode() for x in region]

@@ -1,0 +1,274 @@
+"""Parity tests proper: the HIP path, called through the C ABI, against the CPU oracle on
+the same seeded inputs (bit-exact: integer DP), the golden fixtures captured from the
+reference, and size-independent properties at BASELINE config-2 size."""
+import random
+
+import numpy as np
+import pytest
+
+from nanorepeat_amd import synth, round3 as R3, joint as J
+
+pytestmark = pytest.mark.gpu
+
+KEYS_1D = ("best_score", "sum_k", "n_ties", "status", "cand_score", "cand_tstart", "cand_tend")
+KEYS_2D = ("read_strand", "cell_score", "cell_wscore", "best_wscore", "sum_k1", "sum_k2", "n_ties", "status")
+
+
+def same_1d(capi, oracle, regions, reads, kmin, kmax, read_region=None, sc_over=None, flags=0):
+    kw = dict(read_region=read_region, flags=flags)
+    g = capi.round3_1d(regions, reads, kmin, kmax, sc=capi.default_scoring(**(sc_over or {})), **kw)
+    o = oracle.round3_1d(regions, reads, kmin, kmax, sc=oracle.default_scoring(**(sc_over or {})), **kw)
+    for k in KEYS_1D:
+        assert np.array_equal(g[k], o[k]), (k, np.nonzero(g[k] != o[k])[0][:8], g[k][:8], o[k][:8])
+    return g
+
+
+def same_2d(capi, oracle, region, reads, cr, k1, k2, strand=None, sc_over=None):
+    g = capi.joint_2d(region, reads, cr, k1, k2, read_strand=strand, sc=capi.default_scoring(**(sc_over or {})))
+    o = oracle.joint_2d(region, reads, cr, k1, k2, read_strand=strand, sc=oracle.default_scoring(**(sc_over or {})))
+    for k in KEYS_2D:
+        assert np.array_equal(g[k], o[k]), (k, np.nonzero(g[k] != o[k])[0][:8], g[k][:8], o[k][:8])
+    return g
+
+
+# ------------------------------------------------------------------ 1D
+@pytest.mark.parametrize("unit,alleles,model,anchor,flank", [
+    ("TATTG", (8, 30), "ont", 300, 100),
+    ("CAG", (5, 41), "ont_q20", 250, 80),
+    ("AT", (0, 17), "hifi", 120, 60),
+    ("GGCCCC", (3, 12), "ont", 1000, 100),
+    ("A", (10, 25), "ont", 200, 70),
+])
+def test_1d_random_matches_oracle(capi, oracle, unit, alleles, model, anchor, flank):
+    d = synth.make_1d(20, unit, alleles, model, kwin=(0, max(alleles) + 12), anchor=anchor, flank=flank,
+                      seed=hash((unit, anchor)) % 1000)
+    g = same_1d(capi, oracle, d["regions"], d["reads"], d["kmin"], d["kmax"])
+    ok = g["status"] == 0
+    assert ok.mean() > 0.8
+    est = g["sum_k"][ok] / g["n_ties"][ok]
+    assert np.mean(np.abs(est - d["k_true"][ok]) <= 1) > 0.8
+
+
+def test_1d_reference_window_rule_and_all_extents(capi, oracle):
+    d = synth.make_1d(16, "TATTG", (12, 33), "ont", kwin=None, anchor=300, seed=11)
+    same_1d(capi, oracle, d["regions"], d["reads"], d["kmin"], d["kmax"])
+    same_1d(capi, oracle, d["regions"], d["reads"], d["kmin"], d["kmax"], flags=capi.F_ALL_EXTENTS)
+    d2 = synth.make_1d(8, "TATTG", (12, 33), "ont", kwin=None, anchor=300, seed=12, fast_mode=True)
+    same_1d(capi, oracle, d2["regions"], d2["reads"], d2["kmin"], d2["kmax"])
+
+
+def test_1d_edge_cases(capi, oracle):
+    rng = np.random.default_rng(5)
+    L, R, u = synth.rand_seq(rng, 200), synth.rand_seq(rng, 200), "TATTG"
+    core = lambda k, fl=80: L[-fl:] + u * k + R[:fl]
+    reads = [
+        "",                                   # empty read
+        core(7),                              # skipped (kmin > kmax)
+        synth.rand_seq(rng, 120),             # junk: nothing reaches min_dp_score -> NO_RECORD
+        core(0),                              # true k = 0 (template L+R is a legal candidate)
+        core(9),                              # error-free
+        u * 9 + R[:80],                       # no left flank: alignment starts inside the repeat -> flank test fails
+        L[-80:] + u * 9,                      # no right flank
+        core(6).lower(),                      # lower case
+        core(6).replace("T", "U", 3),         # U == T
+        core(8)[:40] + "N" * 3 + core(8)[43:],  # N in the read
+        "ACGT",                               # shorter than anything useful
+        core(5, 200),                         # whole flanks
+    ]
+    kmin = np.array([0, 5, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0], np.int32)
+    kmax = np.array([9, 4, 12, 6, 20, 20, 20, 15, 15, 15, 5, 12], np.int32)
+    g = same_1d(capi, oracle, [(L, u, R)], reads, kmin, kmax)
+    assert g["status"].tolist()[:7] == [2, 3, 2, 0, 0, 1, 1]
+    assert g["sum_k"][3] == 0 and g["n_ties"][3] == 1
+    assert g["sum_k"][4] == 9 * g["n_ties"][4]
+    same_1d(capi, oracle, [(L, u, R)], reads, kmin, kmax, flags=capi.F_ALL_EXTENTS)
+    # N inside the flanks / unit as well
+    Ln = L[:150] + "NN" + L[152:]
+    same_1d(capi, oracle, [(Ln, "TANTG", R)], reads, kmin, kmax)
+
+
+def test_1d_ties_average(capi, oracle):
+    """A read whose repeat tract lost part of one unit ties between neighbouring k."""
+    rng = np.random.default_rng(8)
+    L, R, u = synth.rand_seq(rng, 150), synth.rand_seq(rng, 150), "CAG"
+    reads = []
+    for k in (6, 10, 14):
+        s = L[-70:] + u * k + R[:70]
+        reads += [s, s[:70 + 3 * 3] + s[70 + 3 * 3 + 1:], s[:70 + 6] + "T" + s[70 + 6:]]
+    g = same_1d(capi, oracle, [(L, u, R)], reads, [0] * 9, [22] * 9, sc_over=dict(min_dp_score=40))
+    assert (g["n_ties"] >= 1).all()
+
+
+def test_1d_many_regions_and_buckets(capi, oracle):
+    """Several regions with different motif lengths in one batch; read lengths spanning many
+    rows-per-lane instantiations, up to the 3072-row limit."""
+    rng = np.random.default_rng(21)
+    regions, reads, rr, kmin, kmax = [], [], [], [], []
+    for g, (m, fl) in enumerate([(3, 60), (4, 80), (5, 100), (6, 50), (2, 30)]):
+        unit = synth.rand_unit(rng, m)
+        L, R = synth.rand_seq(rng, 90 + 10 * g), synth.rand_seq(rng, 110 - 10 * g)
+        regions.append((L, unit, R))
+        for k in (1, 7, 20, 45, 90):
+            s = synth.apply_errors(rng, L[-min(fl, len(L)):] + unit * k + R[:min(fl, len(R))], "ont_q20")
+            reads.append(s); rr.append(g); kmin.append(max(0, k - 2)); kmax.append(k + 2)
+    # long reads: q ~ 700, 1300, 2100, 3072 (R = 11, 22, 40, 48)
+    unit = regions[2][1]
+    L, R = regions[2][0], regions[2][2]
+    for q in (700, 1300, 2100, 3072):
+        k = (q - 160) // 5
+        s = (L[-80:] + unit * k + R[:80])
+        s = synth.apply_errors(rng, s, "hifi")[:q]
+        reads.append(s); rr.append(2); kmin.append(k - 1); kmax.append(k + 1)
+    same_1d(capi, oracle, regions, reads, kmin, kmax, read_region=rr)
+
+
+def test_1d_scoring_variants(capi, oracle):
+    d = synth.make_1d(8, "CAG", (7, 19), "ont", kwin=(0, 26), anchor=200, seed=31)
+    for over in (dict(min_dp_score=0), dict(match=1, mismatch=3, gap_open1=5, gap_ext1=2, gap_open2=20, gap_ext2=1),
+                 dict(match=3, mismatch=2, gap_open1=2, gap_ext1=3, gap_open2=9, gap_ext2=2, sc_ambi=2, min_dp_score=30)):
+        same_1d(capi, oracle, d["regions"], d["reads"], d["kmin"], d["kmax"], sc_over=over)
+
+
+def test_1d_errors(capi):
+    L, R = "ACGT" * 20, "TTGCA" * 16
+    with pytest.raises(capi.NraError) as e:
+        capi.round3_1d([(L, "CAG", R)], ["A" * 3073], [0], [1])
+    assert e.value.code == -3
+    with pytest.raises(capi.NraError) as e:
+        capi.round3_1d([(L, "", R)], ["ACGT"], [0], [1])
+    assert e.value.code == -1
+    with pytest.raises(capi.NraError) as e:
+        capi.round3_1d([(L, "CAG", R)], ["ACGT"], [0], [30000])
+    assert e.value.code == -3
+    out = capi.round3_1d([(L, "CAG", R)], [], [], [])
+    assert len(out["status"]) == 0
+
+
+def test_1d_batch_rerun_is_idempotent(capi):
+    d = synth.make_1d(12, "TATTG", (9, 22), "ont", kwin=(0, 30), anchor=300, seed=41)
+    with capi.Batch.create_1d(d["regions"], d["reads"], d["kmin"], d["kmax"]) as b:
+        b.run(); b.sync(); first = b.fetch()
+        b.run(); b.run(); b.sync(); again = b.fetch()
+        st = b.stats()
+    for k in KEYS_1D:
+        assert np.array_equal(first[k], again[k]), k
+    assert st["n_alignments"] == 12 * 31 and st["score_kernel_ms"] > 0
+    assert st["executed_cells"] >= st["algorithmic_cells"] > 0
+
+
+def test_round3_estimation_golden_end_to_end(capi, golden_1d):
+    """Reference round3_estimation results (fixture) reproduced by the product host path + HIP."""
+    for c in golden_1d["e2e"]:
+        rr = R3.RepeatRegion()
+        rr.left_anchor_seq, rr.repeat_unit_seq, rr.right_anchor_seq = c["left"], c["unit"], c["right"]
+        rr.chrom, rr.start_pos, rr.end_pos = "chrT", 1000, 1100
+        for r in c["reads"]:
+            rr.read_dict[r["name"]] = R3.Read(r["name"], r["r2"])
+            rr.read_core_seq_dict[r["name"]] = r["core"]
+        R3.round3_estimation("ont", c["fast_mode"], rr, 4)
+        got = {n: (None if rd.round3_repeat_size is None else float(rd.round3_repeat_size))
+               for n, rd in rr.read_dict.items()}
+        assert got == c["round3"]
+        assert R3.output_repeat_size_1d(rr) == c["repeat_size_txt"]
+
+
+# ------------------------------------------------------------------ 2D
+def _cells(j, step=2):
+    cr, k1, k2 = [], [], []
+    for r in range(len(j["reads"])):
+        for a in range(int(j["range1"][r][0]), int(j["range1"][r][1]), step):
+            for b in range(int(j["range2"][r][0]), int(j["range2"][r][1]), step):
+                cr.append(r); k1.append(a); k2.append(b)
+    return cr, k1, k2
+
+
+def test_2d_random_matches_oracle(capi, oracle):
+    j = synth.make_joint(10, alleles=((6, 4), (11, 3)), read_len=500, read_sd=30, anchor=300, seed=3)
+    cr, k1, k2 = _cells(j)
+    g = same_2d(capi, oracle, j["region"], j["reads"], cr, k1, k2)
+    assert np.array_equal(g["read_strand"], j["strand"])
+    same_2d(capi, oracle, j["region"], j["reads"], cr, k1, k2, strand=j["strand"])
+    same_2d(capi, oracle, j["region"], j["reads"], cr, k1, k2, strand=-j["strand"])     # forced wrong strand
+
+
+def test_2d_htt_like_and_edges(capi, oracle):
+    j = synth.make_joint(6, alleles=((17, 10), (30, 7)), read_len=700, read_sd=40, anchor=1000, seed=7)
+    cr, k1, k2 = _cells(j, step=3)
+    same_2d(capi, oracle, j["region"], j["reads"], cr, k1, k2)
+    # short flanks: the window is clipped at both template ends (left_len < 10, wb > tlen)
+    left, u1, mid, u2, right = j["region"]
+    region = (left[-6:], u1, "", u2, right[:5])
+    reads = [u1 * 9 + u2 * 6, synth.revcomp(u1 * 9 + u2 * 6), "ACGTNNACGT" + u1 * 5 + "N" + u2 * 4, ""]
+    cr2, a2, b2 = [], [], []
+    for r in (0, 1, 2):
+        for a in range(3, 12, 2):
+            for b in range(2, 9, 2):
+                cr2.append(r); a2.append(a); b2.append(b)
+    same_2d(capi, oracle, region, reads, cr2, a2, b2, sc_over=dict(min_dp_score=20))
+    # read without cells, zero cells at all
+    g = capi.joint_2d(j["region"], j["reads"][:2], [], [], [])
+    assert g["status"].tolist() == [2, 2]
+
+
+def test_joint_golden_end_to_end(capi, golden_2d):
+    for c in golden_2d["e2e"]:
+        a = J.Repeat().init_from_string(c["repeat1"]); b = J.Repeat().init_from_string(c["repeat2"])
+        a.max_size += 10; b.max_size += 10
+        init = J.Round1Estimation()
+        fq = {}
+        for r in c["reads"]:
+            init.repeat1_count_range_dict[r["name"]] = tuple(r["range1"])
+            init.repeat2_count_range_dict[r["name"]] = tuple(r["range2"])
+            fq[r["name"]] = f"@{r['name']}\n{r['seq']}\n+\n{'!' * len(r['seq'])}\n"
+        final = J.fine_tune_read_count(init, fq, c["chrom"], a, b)
+        assert [final.step_size1, final.step_size2] == c["final_step"]
+        assert {k: float(v) for k, v in final.repeat1_count_dict.items()} == c["k1"]
+        assert {k: float(v) for k, v in final.repeat2_count_dict.items()} == c["k2"]
+
+
+# ------------------------------------------------------------------ full size: properties
+@pytest.fixture(scope="module")
+def config2_run(capi):
+    d = synth.config2()
+    with capi.Batch.create_1d(d["regions"], d["reads"], d["kmin"], d["kmax"]) as b:
+        b.run(); b.sync()
+        return d, b.fetch(), b.stats()
+
+
+def test_config2_full_size_properties(capi, oracle, config2_run):
+    d, g, st = config2_run
+    n = len(d["reads"])
+    assert st["n_alignments"] == n * 196
+    # every read has a record, the size lies inside its window, scores are bounded by 2*qlen
+    assert (g["status"] <= 1).all() and (g["status"] == 0).mean() > 0.98
+    ok = g["status"] == 0
+    est = g["sum_k"][ok] / g["n_ties"][ok]
+    assert (est >= 5).all() and (est <= 200).all()
+    qlen = np.array([len(r) for r in d["reads"]])
+    assert (g["best_score"] <= 2 * qlen).all() and (g["best_score"] > qlen).all()
+    assert np.mean(np.abs(est - d["k_true"][ok]) <= 1) > 0.95
+    # Score(k) of a read is maximal at the reported ties and the profile is unimodal around them
+    sc = g["cand_score"].reshape(n, 196)
+    assert np.array_equal(sc.max(1), g["best_score"])
+    for r in range(0, n, 997):
+        kbest = int(np.argmax(sc[r]))
+        assert (np.diff(sc[r][:max(kbest - 3, 1)]) >= -2).all()
+    # extents were produced exactly for the top-score ties
+    ties = sc == g["best_score"][:, None]
+    assert np.array_equal(g["cand_tstart"].reshape(n, 196) >= 0, ties)
+    # a seeded sample of reads against the oracle at full problem size
+    pick = np.random.default_rng(1).choice(n, 12, replace=False)
+    o = oracle.round3_1d(d["regions"], [d["reads"][i] for i in pick], d["kmin"][pick], d["kmax"][pick])
+    for k in ("best_score", "sum_k", "n_ties", "status"):
+        assert np.array_equal(g[k][pick], o[k]), k
+    assert np.array_equal(sc[pick].ravel(), o["cand_score"])
+
+
+def test_config2_order_and_batching_invariance(capi, config2_run):
+    d, g, _ = config2_run
+    n = len(d["reads"])
+    perm = np.random.default_rng(2).permutation(n)[:3000]
+    sub = capi.round3_1d(d["regions"], [d["reads"][i] for i in perm], d["kmin"][perm], d["kmax"][perm],
+                         per_candidate=False)
+    for k in ("best_score", "sum_k", "n_ties", "status"):
+        assert np.array_equal(sub[k], g[k][perm]), k
