@@ -47,7 +47,12 @@ extern "C" {
                                  (nanoRepeat_bam.py:460) */
 
 /* flags */
-#define NRA_F_ALL_EXTENTS  1  /* compute tstart/tend for every candidate, not only the top-score ties */
+#define NRA_F_ALL_EXTENTS  1  /* explicit extents DP (tstart/tend) for EVERY candidate; implies brute force */
+#define NRA_F_TIE_EXTENTS  2  /* explicit extents DP for every top-score tie, so cand_tstart/cand_tend are
+                                 filled for them (the one-shot call sets it when those arrays are given);
+                                 without it only ties whose flank verdict is ambiguous are re-run */
+#define NRA_F_BRUTE_FORCE  4  /* score the K candidates of a read as K independent alignments
+                                 (k_score_pk16) instead of the junction decomposition (k_sweep_pk16) */
 
 /* Scoring parameters: minimap2 `-x map-ont` defaults.
  * A gap of length l costs min(gap_open1 + l*gap_ext1, gap_open2 + l*gap_ext2). */
@@ -92,7 +97,8 @@ typedef struct nra_joint_region {
 typedef struct nra_stats {
     int64_t n_alignments;     /* (read, candidate) pairs scored */
     int64_t algorithmic_cells;/* sum of qlen * tlen over those pairs */
-    int64_t executed_cells;   /* DP cells the kernels actually updated (padding included) */
+    int64_t executed_cells;   /* DP cells the scoring kernels actually updated (padding included); far below
+                                 algorithmic_cells when the junction decomposition shares work across k */
     int64_t algorithmic_bytes;/* HBM bytes the algorithm must move (packed reads + flanks + results) */
     int64_t n_extent_tasks;   /* alignments re-run by the extents kernel (top-score ties) */
     double  score_kernel_ms;  /* dominant kernel: sum of its launches, HIP events on the batch stream */
@@ -127,7 +133,8 @@ void        nra_default_scoring(nra_scoring_t* sc);
  *   status      NRA_READ_*
  * Optional per-candidate outputs (NULL to skip), sum_i max(0, kmax-kmin+1) entries in
  * read order then k order: cand_score (AS, or -1 when below min_dp_score), cand_tstart,
- * cand_tend (-1 unless the candidate ties the best score or NRA_F_ALL_EXTENTS is set). */
+ * cand_tend (-1 unless the candidate ties the best score -- NRA_F_TIE_EXTENTS, implied when
+ * these arrays are given -- or NRA_F_ALL_EXTENTS is set). */
 int nra_round3_1d(int device,
                   const nra_region_t* regions, int32_t n_regions,
                   int32_t n_reads, const char* seqs, const int64_t* seq_off,

@@ -13,7 +13,9 @@ LIB_PATH = os.path.join(_HERE, "libnanorepeat_amd.so")
 _LIB = None
 
 READ_OK, READ_FALLBACK, READ_NO_RECORD, READ_SKIPPED = 0, 1, 2, 3
-F_ALL_EXTENTS = 1
+F_ALL_EXTENTS = 1     # explicit extents DP for every candidate (brute force)
+F_TIE_EXTENTS = 2     # explicit extents DP for every top-score tie (fills cand_tstart/cand_tend)
+F_BRUTE_FORCE = 4     # K independent alignments per read instead of the junction decomposition
 
 # every symbol include/nanorepeat_amd.h declares
 EXPORTS = ("nra_abi_version", "nra_version", "nra_last_error", "nra_device_count",

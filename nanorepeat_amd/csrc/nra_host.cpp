@@ -101,8 +101,11 @@ struct Bucket {
     int n_queue = 0;           // payload tasks prebuilt on the host (ALL_EXTENTS / 2D cells)
     size_t queue_off = 0;      // offset into queue_tasks (also the base of the tie queue)
     size_t queue_cap = 0;      // capacity of this bucket's queue region
+    int n_sweep = 0;           // junction-decomposition tasks (pairs of reads)
+    size_t sweep_off = 0;
     int64_t cells_pair = 0;    // executed cells per run, pk16
     int64_t cells_queue = 0;   // executed cells per run, prebuilt payload queue
+    int64_t cells_sweep = 0;   // executed cells per run, both sweeps
 };
 
 NraScoreParams to_params(const nra_scoring_t& sc)
@@ -146,6 +149,11 @@ struct nra_batch {
     DevBuf<NraDevRegion> regions;
     DevBuf<NraDevRead> reads, reads_init;
     DevBuf<NraPairTask> pair_tasks;
+    DevBuf<NraSweepTask> sweep_tasks;
+    DevBuf<int16_t> snap_h, snap_e, snap_e2;   // R side of the junction, one entry per read base
+    DevBuf<int32_t> arr_a;                     // A_k per candidate
+    DevBuf<uint8_t> cand_flag;                 // flank verdict per candidate
+    bool brute = false;                        // K independent alignments instead of the sweeps
     DevBuf<NraTask> queue_tasks;
     DevBuf<int32_t> queue_count;   // per bucket: prebuilt queue length (constant)
     DevBuf<int32_t> tie_count;     // per bucket: tie queue length (device-written)
@@ -333,6 +341,12 @@ int nra_batch1d_create(int device, const nra_region_t* regions, int32_t n_region
         d.p1_off = pool_append(pool, rg.left, rg.left_len, rg.unit, rg.unit_len, region_kmax[g], has_n);
         d.p2_off = (uint32_t)pool.size();
         d.p3_off = pool_append(pool, rg.right, rg.right_len, nullptr, 0, 0, has_n);
+        {   // rev(R) + rev(unit)^kmax for the reverse sweep
+            std::string rr(rg.right, rg.right + rg.right_len), ru(rg.unit, rg.unit + rg.unit_len);
+            std::reverse(rr.begin(), rr.end());
+            std::reverse(ru.begin(), ru.end());
+            d.pr_off = pool_append(pool, rr.data(), rg.right_len, ru.data(), rg.unit_len, region_kmax[g], has_n);
+        }
         d.l1 = rg.left_len; d.m1 = rg.unit_len; d.l2 = 0; d.m2 = 0; d.l3 = rg.right_len;
         dregs[g] = d;
         if (pool.size() > 0xfff00000ull) return fail(NRA_E_RANGE, "template pool exceeds 4 GB");
@@ -342,6 +356,11 @@ int nra_batch1d_create(int device, const nra_region_t* regions, int32_t n_region
 
     // buckets by rows-per-lane; tasks
     const bool all_ext = (flags & NRA_F_ALL_EXTENTS) != 0;
+    bool brute = all_ext || (flags & NRA_F_BRUTE_FORCE) != 0;
+    for (int32_t g = 0; g < n_regions; ++g)       // the junction needs a base on either side
+        if (regions[g].left_len < 1 || regions[g].right_len < 1) brute = true;
+    b->brute = brute;
+    std::vector<NraSweepTask> sweep_tasks;
     std::vector<std::vector<int32_t>> by_bucket((size_t)kNumR);
     for (int32_t r = 0; r < n_reads; ++r) {
         if (kmin[r] > kmax[r] || pr.reads[r].qlen == 0) continue;
@@ -371,7 +390,7 @@ int nra_batch1d_create(int device, const nra_region_t* regions, int32_t n_region
                     bk.cells_queue += sweep_cells(bk.R, tl);
                 }
             }
-            if (!all_ext) {
+            if (!all_ext && brute) {
                 for (int32_t k = kmin[r]; k <= kmax[r]; k += 2) {
                     NraPairTask t{};
                     t.read = r; t.k1a = k; t.k2a = 0; t.out_a = (int32_t)(coff[r] + (uint32_t)(k - kmin[r]));
@@ -384,6 +403,32 @@ int nra_batch1d_create(int device, const nra_region_t* regions, int32_t n_region
                 }
             }
             bk.queue_cap += (size_t)(kmax[r] - kmin[r] + 1);
+        }
+        if (!brute) {
+            // pair reads of one region by length: two reads share a wave (int16 halves)
+            std::vector<int32_t> order(by_bucket[bi]);
+            std::stable_sort(order.begin(), order.end(), [&](int32_t x, int32_t y) {
+                if (pr.reads[x].region != pr.reads[y].region) return pr.reads[x].region < pr.reads[y].region;
+                return pr.reads[x].qlen > pr.reads[y].qlen;
+            });
+            bk.sweep_off = sweep_tasks.size();
+            for (size_t i = 0; i < order.size();) {
+                NraSweepTask t{};
+                t.read_a = order[i]; t.read_b = -1;
+                t.kmin = kmin[t.read_a]; t.kmax = kmax[t.read_a];
+                if (i + 1 < order.size() && pr.reads[order[i + 1]].region == pr.reads[order[i]].region) {
+                    t.read_b = order[i + 1];
+                    t.kmin = std::min(t.kmin, kmin[t.read_b]);
+                    t.kmax = std::max(t.kmax, kmax[t.read_b]);
+                    i += 2;
+                } else {
+                    i += 1;
+                }
+                const NraDevRegion& d = dregs[pr.reads[t.read_a].region];
+                bk.cells_sweep += 2 * (sweep_cells(bk.R, d.l1 + d.m1 * t.kmax) + sweep_cells(bk.R, d.l3 + d.m1 * t.kmax));
+                sweep_tasks.push_back(t);
+            }
+            bk.n_sweep = (int)(sweep_tasks.size() - bk.sweep_off);
         }
         bk.n_pair = (int)(pair_tasks.size() - bk.pair_off);
         bk.n_queue = all_ext ? (int)bk.queue_cap : 0;
@@ -400,6 +445,15 @@ int nra_batch1d_create(int device, const nra_region_t* regions, int32_t n_region
     HIP_TRY(b->regions.upload(dregs));
     HIP_TRY(b->reads.upload(pr.reads));
     HIP_TRY(b->pair_tasks.upload(pair_tasks));
+    HIP_TRY(b->sweep_tasks.upload(sweep_tasks));
+    if (!brute) {
+        const size_t nbases = pr.q2bit.size() * 16;
+        HIP_TRY(b->snap_h.alloc(nbases));
+        HIP_TRY(b->snap_e.alloc(nbases));
+        HIP_TRY(b->snap_e2.alloc(nbases));
+        HIP_TRY(b->arr_a.alloc((size_t)total));
+    }
+    HIP_TRY(b->cand_flag.alloc((size_t)total));
     if (all_ext) HIP_TRY(b->queue_tasks.upload(queue_tasks));
     else HIP_TRY(b->queue_tasks.alloc(queue_total));
     HIP_TRY(b->queue_count.upload(queue_count));
@@ -418,13 +472,13 @@ int nra_batch1d_create(int device, const nra_region_t* regions, int32_t n_region
     HIP_TRY(b->n_ties.alloc((size_t)n_reads));
     HIP_TRY(b->sum_k.alloc((size_t)n_reads));
     HIP_TRY(b->status.alloc((size_t)n_reads));
-    rc = make_events(b, 2 + 4 * (int)nb + 2);
+    rc = make_events(b, 2 + 6 * (int)nb + 2);
     if (rc) return rc;
 
     b->stats.n_alignments = total;
     b->stats.algorithmic_cells = alg_cells;
     int64_t ex = 0;
-    for (const Bucket& bk : b->buckets) ex += bk.cells_pair + bk.cells_queue;
+    for (const Bucket& bk : b->buckets) ex += bk.cells_pair + bk.cells_queue + bk.cells_sweep;
     b->stats.executed_cells = ex;
     b->stats.algorithmic_bytes = (int64_t)pr.q2bit.size() * 4 + (int64_t)pool.size() + total * 4 + (int64_t)n_reads * 17;
     *out = guard.release();
@@ -442,28 +496,55 @@ static int run_1d(nra_batch* b)
     HIP_TRY(hipMemsetAsync(b->cand_tstart.p, 0xff, std::max<size_t>(nc, 1) * 4, st));
     HIP_TRY(hipMemsetAsync(b->cand_tend.p, 0xff, std::max<size_t>(nc, 1) * 4, st));
     HIP_TRY(hipMemsetAsync(b->tie_count.p, 0, std::max<size_t>(nb, 1) * 4, st));
+    HIP_TRY(hipMemsetAsync(b->cand_flag.p, 2, std::max<size_t>(nc, 1), st));   // 2 = "needs the extents DP"
     int ev = 2;
     b->n_score_ev = 0; b->n_ext_ev = 0;
     const int max_waves = 256 * 16;
-    for (size_t i = 0; i < nb; ++i) {
-        const Bucket& bk = b->buckets[i];
-        HIP_TRY(hipEventRecord(b->ev[ev++], st));
-        if (!all_ext) {
-            LAUNCH_TRY(nra_launch_score_pk16(bk.R, b->has_n, st, bk.n_pair, b->pair_tasks.p + bk.pair_off,
-                                             b->reads.p, b->regions.p, b->pool.p, b->q2bit.p, b->qnmask.p,
-                                             b->sp, b->cand_score.p));
-        } else {
-            LAUNCH_TRY(nra_launch_payload_origin(bk.R, b->has_n, st, std::min(bk.n_queue, max_waves),
-                                              b->queue_tasks.p + bk.queue_off, b->queue_count.p + i,
-                                              b->reads.p, b->regions.p, b->pool.p,
-                                              b->q2bit.p, b->qnmask.p, b->sp, b->cand_score.p,
-                                              b->cand_tstart.p, b->cand_tend.p));
+    const bool tie_ext = (b->flags & NRA_F_TIE_EXTENTS) != 0;
+    if (!b->brute) {
+        // junction decomposition: reverse sweeps of every bucket, then forward sweeps
+        for (int dir = 0; dir < 2; ++dir) {
+            for (size_t i = 0; i < nb; ++i) {
+                const Bucket& bk = b->buckets[i];
+                HIP_TRY(hipEventRecord(b->ev[ev++], st));
+                if (dir == 0)
+                    LAUNCH_TRY(nra_launch_sweep_bwd(bk.R, b->has_n, st, bk.n_sweep, b->sweep_tasks.p + bk.sweep_off,
+                                                    b->reads.p, b->regions.p, b->pool.p, b->q2bit.p, b->qnmask.p, b->sp,
+                                                    b->kmin.p, b->kmax.p, b->coff.p, b->snap_h.p, b->snap_e.p,
+                                                    b->snap_e2.p, b->arr_a.p));
+                else
+                    LAUNCH_TRY(nra_launch_sweep_fwd(bk.R, b->has_n, st, bk.n_sweep, b->sweep_tasks.p + bk.sweep_off,
+                                                    b->reads.p, b->regions.p, b->pool.p, b->q2bit.p, b->qnmask.p, b->sp,
+                                                    b->kmin.p, b->kmax.p, b->coff.p, b->snap_h.p, b->snap_e.p,
+                                                    b->snap_e2.p, b->arr_a.p, b->cand_score.p, b->cand_flag.p));
+                HIP_TRY(hipEventRecord(b->ev[ev++], st));
+                b->n_score_ev++;
+            }
         }
-        HIP_TRY(hipEventRecord(b->ev[ev++], st));
-        b->n_score_ev++;
+    } else {
+        for (size_t i = 0; i < nb; ++i) {
+            const Bucket& bk = b->buckets[i];
+            HIP_TRY(hipEventRecord(b->ev[ev++], st));
+            if (!all_ext) {
+                LAUNCH_TRY(nra_launch_score_pk16(bk.R, b->has_n, st, bk.n_pair, b->pair_tasks.p + bk.pair_off,
+                                                 b->reads.p, b->regions.p, b->pool.p, b->q2bit.p, b->qnmask.p,
+                                                 b->sp, b->cand_score.p));
+            } else {
+                LAUNCH_TRY(nra_launch_payload_origin(bk.R, b->has_n, st, std::min(bk.n_queue, max_waves),
+                                                  b->queue_tasks.p + bk.queue_off, b->queue_count.p + i,
+                                                  b->reads.p, b->regions.p, b->pool.p,
+                                                  b->q2bit.p, b->qnmask.p, b->sp, b->cand_score.p,
+                                                  b->cand_tstart.p, b->cand_tend.p));
+            }
+            HIP_TRY(hipEventRecord(b->ev[ev++], st));
+            b->n_score_ev++;
+        }
     }
+    // ties that need the explicit extents DP: all of them (brute force / TIE_EXTENTS), or only those
+    // whose three-score flank verdict is ambiguous
+    const int append_mode = all_ext ? 0 : ((b->brute || tie_ext) ? 2 : 1);
     LAUNCH_TRY(nra_launch_select_best_1d(st, b->n_reads, b->kmin.p, b->kmax.p, b->coff.p, b->cand_score.p,
-                                         b->read_bucket.p, b->bucket_task_base.p, all_ext ? 0 : 1,
+                                         b->cand_flag.p, b->read_bucket.p, b->bucket_task_base.p, append_mode,
                                          b->queue_tasks.p, b->tie_count.p, b->best_score.p));
     if (!all_ext) {
         for (size_t i = 0; i < nb; ++i) {
@@ -479,8 +560,8 @@ static int run_1d(nra_batch* b)
         }
     }
     LAUNCH_TRY(nra_launch_select_final_1d(st, b->n_reads, b->kmin.p, b->kmax.p, b->coff.p, b->reads.p,
-                                          b->regions.p, b->cand_score.p, b->cand_tstart.p, b->cand_tend.p,
-                                          b->best_score.p, b->sum_k.p, b->n_ties.p, b->status.p));
+                                          b->regions.p, b->cand_score.p, b->cand_flag.p, b->cand_tstart.p,
+                                          b->cand_tend.p, b->best_score.p, b->sum_k.p, b->n_ties.p, b->status.p));
     HIP_TRY(hipEventRecord(b->ev[1], st));
     return NRA_OK;
 }
@@ -516,6 +597,7 @@ int nra_round3_1d(int device, const nra_region_t* regions, int32_t n_regions, in
 {
     if (n_reads > 0 && (!best_score || !sum_k || !n_ties || !status)) return fail(NRA_E_ARG, "NULL output array");
     nra_batch_t* b = nullptr;
+    if (cand_tstart || cand_tend) flags |= NRA_F_TIE_EXTENTS;
     int rc = nra_batch1d_create(device, regions, n_regions, n_reads, seqs, seq_off, read_region, kmin,
                                 kmax, sc, flags, &b);
     if (rc) return rc;

@@ -19,6 +19,7 @@ struct NraDevRegion {
     uint32_t p1_off;   // L + unit1 * k1max   (byte codes in the pool)
     uint32_t p2_off;   // mid + unit2 * k2max
     uint32_t p3_off;   // R
+    uint32_t pr_off;   // rev(R) + rev(unit1) * k1max  (1D reverse sweep)
     int32_t  l1, m1;   // left_len, unit1_len
     int32_t  l2, m2;   // mid_len,  unit2_len (both 0 for 1D regions)
     int32_t  l3;       // right_len
@@ -37,6 +38,13 @@ struct NraPairTask {
     int32_t k1a, k2a, k1b, k2b;
     int32_t out_a, out_b;  // index into the per-candidate score array; out_b < 0: no B half
     int32_t flags;         // bit 0: half B is the reverse complement of the template (strand probe)
+};
+
+// Two reads of one region swept together (int16 halves A / B) by the junction-decomposition
+// kernels; [kmin, kmax] is the union of their candidate windows.
+struct NraSweepTask {
+    int32_t read_a, read_b;   // read_b < 0: no second read
+    int32_t kmin, kmax;
 };
 
 // One candidate scored with a payload (extents / window kernels).
@@ -88,17 +96,32 @@ int nra_launch_payload_window(int R, int has_n, hipStream_t st, int n_waves,
                               NraScoreParams sp,
                               int32_t* out_score, int32_t* out_p, int32_t* out_tend);
 
-// 1D selectors (one wave per read)
+// junction decomposition (nra_sweep.hip): reverse sweep writes the R-side snapshot and A_k,
+// forward sweep combines and writes Score(k) + the flank-test verdict (0 fail, 1 pass, 2 ambiguous)
+int nra_launch_sweep_bwd(int R, int has_n, hipStream_t st, int n_tasks, const NraSweepTask* tasks,
+                         const NraDevRead* reads, const NraDevRegion* regions, const uint8_t* pool,
+                         const uint32_t* q2bit, const uint32_t* qnmask, NraScoreParams sp,
+                         const int32_t* kmin, const int32_t* kmax, const uint32_t* coff,
+                         int16_t* snap_h, int16_t* snap_e, int16_t* snap_e2, int32_t* arr_a);
+int nra_launch_sweep_fwd(int R, int has_n, hipStream_t st, int n_tasks, const NraSweepTask* tasks,
+                         const NraDevRead* reads, const NraDevRegion* regions, const uint8_t* pool,
+                         const uint32_t* q2bit, const uint32_t* qnmask, NraScoreParams sp,
+                         const int32_t* kmin, const int32_t* kmax, const uint32_t* coff,
+                         int16_t* snap_h, int16_t* snap_e, int16_t* snap_e2, int32_t* arr_a,
+                         int32_t* cand_score, uint8_t* cand_flag);
+
+// 1D selectors (one wave per read).  append_mode: 0 none, 1 ambiguous ties only, 2 every tie
 int nra_launch_select_best_1d(hipStream_t st, int n_reads, const int32_t* kmin, const int32_t* kmax,
-                              const uint32_t* coff, const int32_t* cand_score,
+                              const uint32_t* coff, const int32_t* cand_score, const uint8_t* cand_flag,
                               const int32_t* read_bucket, const uint32_t* bucket_task_base,
-                              int append_ties, NraTask* ext_tasks, int32_t* ext_count,
+                              int append_mode, NraTask* ext_tasks, int32_t* ext_count,
                               int32_t* best_score);
 int nra_launch_select_final_1d(hipStream_t st, int n_reads, const int32_t* kmin, const int32_t* kmax,
                                const uint32_t* coff, const NraDevRead* reads,
                                const NraDevRegion* regions,
-                               const int32_t* cand_score, const int32_t* cand_tstart,
-                               const int32_t* cand_tend, const int32_t* best_score,
+                               const int32_t* cand_score, const uint8_t* cand_flag,
+                               const int32_t* cand_tstart, const int32_t* cand_tend,
+                               const int32_t* best_score,
                                int64_t* sum_k, int32_t* n_ties, uint8_t* status);
 // 2D: strand choice from the probe scores, then the per-read selector over its cells
 int nra_launch_pick_strand(hipStream_t st, int n_reads, const int32_t* probe_score,

@@ -35,76 +35,7 @@
 #endif
 #define NRA_HAS_PART(n) (NRA_PART == 0 || NRA_PART == (n))
 
-#define WAVE 64
-
-typedef short s16x2 __attribute__((ext_vector_type(2)));
-typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
-
-// ------------------------------------------------------------------------------------
-// cross-lane moves (DPP, full-wave shifts exist on gfx9-family CDNA)
-// ------------------------------------------------------------------------------------
-__device__ __forceinline__ int dpp_shr1(int old, int src)   // lane l <- lane l-1 ; lane 0 keeps old
-{
-    return __builtin_amdgcn_update_dpp(old, src, 0x138 /*wave_shr:1*/, 0xf, 0xf, false);
-}
-__device__ __forceinline__ int dpp_rol1(int src)            // lane l <- lane l+1 ; lane 63 <- lane 0
-{
-    return __builtin_amdgcn_update_dpp(src, src, 0x134 /*wave_rol:1*/, 0xf, 0xf, false);
-}
-__device__ __forceinline__ s16x2 as_s(int v) { return __builtin_bit_cast(s16x2, v); }
-__device__ __forceinline__ int as_i(s16x2 v) { return __builtin_bit_cast(int, v); }
-__device__ __forceinline__ s16x2 pmax(s16x2 a, s16x2 b) { return __builtin_elementwise_max(a, b); }
-__device__ __forceinline__ s16x2 splat(int v) { s16x2 r; r.x = (short)v; r.y = (short)v; return r; }
-__device__ __forceinline__ int imax(int a, int b) { return a > b ? a : b; }
-__device__ __forceinline__ int imin(int a, int b) { return a < b ? a : b; }
-
-// ------------------------------------------------------------------------------------
-// implicit template: piece1[0:len1) + piece2[0:len2) + piece3[0:len3), optional revcomp
-// ------------------------------------------------------------------------------------
-struct Tmpl {
-    const uint8_t* p1; const uint8_t* p2; const uint8_t* p3;
-    int len1, len2, tlen, rc;
-};
-
-__device__ __forceinline__ Tmpl make_tmpl(const NraDevRegion& rg, const uint8_t* pool, int k1, int k2, int rc)
-{
-    Tmpl t;
-    t.p1 = pool + rg.p1_off; t.p2 = pool + rg.p2_off; t.p3 = pool + rg.p3_off;
-    t.len1 = rg.l1 + rg.m1 * k1;
-    t.len2 = rg.l2 + rg.m2 * k2;
-    t.tlen = t.len1 + t.len2 + rg.l3;
-    t.rc = rc;
-    return t;
-}
-
-__device__ __forceinline__ int tmpl_code(const Tmpl& t, int col)
-{
-    if (col < 0 || col >= t.tlen) return NRA_PAD_T;
-    int j = t.rc ? (t.tlen - 1 - col) : col;
-    int c;
-    if (j < t.len1) c = t.p1[j];
-    else {
-        j -= t.len1;
-        c = (j < t.len2) ? t.p2[j] : t.p3[j - t.len2];
-    }
-    if (t.rc && c < 4) c = 3 - c;
-    return c;
-}
-
-// query base of global row gi (PAD_Q beyond the read); 2-bit pool + optional N bitmap
-template <bool HAS_N>
-__device__ __forceinline__ int query_code(const NraDevRead& rd, const uint32_t* q2bit,
-                                          const uint32_t* qnmask, int gi)
-{
-    if (gi >= rd.qlen) return NRA_PAD_Q;
-    uint32_t b = rd.qoff + (uint32_t)(rd.rc ? (rd.qlen - 1 - gi) : gi);
-    int c = (q2bit[b >> 4] >> ((b & 15u) * 2u)) & 3u;
-    if (rd.rc) c = 3 - c;
-    if (HAS_N) {
-        if ((qnmask[b >> 5] >> (b & 31u)) & 1u) c = NRA_CODE_N;
-    }
-    return c;
-}
+#include "nra_device.h"
 
 #if NRA_HAS_PART(1)
 // ------------------------------------------------------------------------------------
@@ -379,9 +310,10 @@ __global__ __launch_bounds__(WAVE) void k_select_best_1d(int n_reads, const int3
                                                         const int32_t* __restrict__ kmax,
                                                         const uint32_t* __restrict__ coff,
                                                         const int32_t* __restrict__ cand_score,
+                                                        const uint8_t* __restrict__ cand_flag,
                                                         const int32_t* __restrict__ read_bucket,
                                                         const uint32_t* __restrict__ bucket_task_base,
-                                                        int append_ties, NraTask* __restrict__ ext_tasks,
+                                                        int append_mode, NraTask* __restrict__ ext_tasks,
                                                         int32_t* __restrict__ ext_count,
                                                         int32_t* __restrict__ best_score)
 {
@@ -394,10 +326,12 @@ __global__ __launch_bounds__(WAVE) void k_select_best_1d(int n_reads, const int3
     for (int c = lane; c < K; c += WAVE) best = imax(best, cand_score[base + c]);
     best = wave_max(best);
     if (lane == 0) best_score[r] = best;
-    if (!append_ties || best < 0) return;
+    if (!append_mode || best < 0) return;
     const int b = read_bucket[r];
     for (int c = lane; c < K; c += WAVE) {
-        if (cand_score[base + c] == best) {
+        // the explicit extents DP runs for every tie (mode 2) or only where the three-score
+        // flank verdict of the sweep is ambiguous (mode 1, flag 2)
+        if (cand_score[base + c] == best && (append_mode == 2 || cand_flag[base + c] == 2)) {
             const int slot = atomicAdd(&ext_count[b], 1);
             NraTask t; t.read = r; t.k1 = k0 + c; t.k2 = 0; t.out = (int)(base + c);
             ext_tasks[bucket_task_base[b] + slot] = t;
@@ -412,6 +346,7 @@ __global__ __launch_bounds__(WAVE) void k_select_final_1d(int n_reads, const int
                                                          const NraDevRead* __restrict__ reads,
                                                          const NraDevRegion* __restrict__ regions,
                                                          const int32_t* __restrict__ cand_score,
+                                                         const uint8_t* __restrict__ cand_flag,
                                                          const int32_t* __restrict__ cand_tstart,
                                                          const int32_t* __restrict__ cand_tend,
                                                          const int32_t* __restrict__ best_score,
@@ -433,7 +368,9 @@ __global__ __launch_bounds__(WAVE) void k_select_final_1d(int n_reads, const int
             const int k = k0 + c;
             const int tlen = rg.l1 + rg.m1 * k + rg.l3;
             const int ts = cand_tstart[base + c], te = cand_tend[base + c];
-            if (ts >= 0 && ts < rg.l1 && tlen - te < rg.l3) { sk += k; ++nt; }
+            // explicit extents when the extents kernel ran for this record, else the sweep's verdict
+            const bool pass = ts >= 0 ? (ts < rg.l1 && tlen - te < rg.l3) : (cand_flag[base + c] == 1);
+            if (pass) { sk += k; ++nt; }
         }
     }
     sk = wave_sum64(sk);
@@ -562,25 +499,27 @@ extern "C" int nra_launch_payload_window(int R, int has_n, hipStream_t st, int n
 #if NRA_HAS_PART(4)
 extern "C" int nra_launch_select_best_1d(hipStream_t st, int n_reads, const int32_t* kmin, const int32_t* kmax,
                                          const uint32_t* coff, const int32_t* cand_score,
+                                         const uint8_t* cand_flag,
                                          const int32_t* read_bucket, const uint32_t* bucket_task_base,
-                                         int append_ties, NraTask* ext_tasks, int32_t* ext_count,
+                                         int append_mode, NraTask* ext_tasks, int32_t* ext_count,
                                          int32_t* best_score)
 {
     if (n_reads <= 0) return 0;
-    k_select_best_1d<<<n_reads, WAVE, 0, st>>>(n_reads, kmin, kmax, coff, cand_score, read_bucket,
-                                               bucket_task_base, append_ties, ext_tasks, ext_count, best_score);
+    k_select_best_1d<<<n_reads, WAVE, 0, st>>>(n_reads, kmin, kmax, coff, cand_score, cand_flag, read_bucket,
+                                               bucket_task_base, append_mode, ext_tasks, ext_count, best_score);
     return (int)hipGetLastError();
 }
 
 extern "C" int nra_launch_select_final_1d(hipStream_t st, int n_reads, const int32_t* kmin, const int32_t* kmax,
                                           const uint32_t* coff, const NraDevRead* reads,
                                           const NraDevRegion* regions, const int32_t* cand_score,
+                                          const uint8_t* cand_flag,
                                           const int32_t* cand_tstart, const int32_t* cand_tend,
                                           const int32_t* best_score, int64_t* sum_k, int32_t* n_ties,
                                           uint8_t* status)
 {
     if (n_reads <= 0) return 0;
-    k_select_final_1d<<<n_reads, WAVE, 0, st>>>(n_reads, kmin, kmax, coff, reads, regions, cand_score,
+    k_select_final_1d<<<n_reads, WAVE, 0, st>>>(n_reads, kmin, kmax, coff, reads, regions, cand_score, cand_flag,
                                                 cand_tstart, cand_tend, best_score, sum_k, n_ties, status);
     return (int)hipGetLastError();
 }

@@ -1,0 +1,313 @@
+// nra_sweep.hip -- junction decomposition of the 1D candidate bank (gfx950).
+//
+// The K candidates of a read, L + unit^k + R for k in [kmin,kmax], share L + unit^k as a
+// prefix and R as a suffix.  An optimal local alignment of the read against candidate k
+// either lies entirely in L+unit^k, or entirely in unit^k+R, or consumes R[0].  So with
+//
+//   B_k = best score entirely inside L + unit^k          (forward sweep, running maximum)
+//   A_k = best score entirely inside unit^k + R          (reverse sweep, running maximum)
+//   S_k = best score of an alignment that consumes R[0]  (junction combine, below)
+//
+// Score(k) = max(S_k, B_k, A_k) is the oracle's score exactly (optimal DP decomposes at a
+// node column; a gap spanning the junction is handled per gap piece by refunding one open).
+// Both sweeps are ONE alignment-sized DP per read instead of K:
+//
+//   reverse sweep (DIR 0): reversed read vs  rev(R) + rev(unit)^kmax.  At the last column
+//     of rev(R) every lane stores H, E_in, E2_in of its rows (the "R side" of the junction:
+//     best paths starting at node (i, R[0]) -- closed, or inside a piece-1 / piece-2 gap).
+//     At every unit boundary lenR + m*k - 1 the running maximum over all cells so far is A_k.
+//   forward sweep (DIR 1): read vs L + unit^kmax.  At every unit boundary L + m*k - 1 each
+//     row combines its three states with the stored R side:
+//        max(H,0) + Hb,   E_in + Eb_in + q,   E2_in + E2b_in + q2        -> S_k
+//     and the running maximum gives B_k.
+//
+// Per-column results travel with the column through the lanes (DPP wave_shr:1, like the
+// DP hand-off), so lane 63 holds the wave-wide value of a boundary column when it finishes
+// it and writes Score(k) and the flank-test verdict:
+//   left  flank (tstart < |L|)      passes  iff A_k < Score   (oracle: largest tstart wins)
+//   right flank (tend > |L|+m*k)    passes  if  B_k < Score;  fails if B_k == Score > S_k;
+//                                   B_k == S_k == Score is ambiguous -> explicit extents DP.
+//
+// The two int16 halves of every VGPR hold two READS of the same region (paired by length
+// on the host); the template base is shared.  Inner loop = k_score_pk16's, with E updated
+// lazily (E_in of the current column stays in the register, which the combine needs).
+#include "nra_device.h"
+
+#ifndef NRA_PART
+#define NRA_PART 0
+#endif
+#define NRA_HAS_PART(n) (NRA_PART == 0 || NRA_PART == (n))
+
+#define FLAG_BOUNDARY 0x100
+#define FLAG_SNAPSHOT 0x200
+
+__device__ __forceinline__ int half_lo(int v) { return (short)(v & 0xffff); }
+__device__ __forceinline__ int half_hi(int v) { return (short)(v >> 16); }
+__device__ __forceinline__ int pack2(int lo, int hi) { return (lo & 0xffff) | (hi << 16); }
+
+// query base of row gi; rev = read the read back to front (no complement)
+template <bool HAS_N>
+__device__ __forceinline__ int sweep_query_code(const NraDevRead& rd, const uint32_t* q2bit,
+                                                const uint32_t* qnmask, int gi, bool rev)
+{
+    if (gi >= rd.qlen) return NRA_PAD_Q;
+    uint32_t b = rd.qoff + (uint32_t)(rev ? (rd.qlen - 1 - gi) : gi);
+    int c = (q2bit[b >> 4] >> ((b & 15u) * 2u)) & 3u;
+    if (HAS_N) {
+        if ((qnmask[b >> 5] >> (b & 31u)) & 1u) c = NRA_CODE_N;
+    }
+    return c;
+}
+
+template <int R, bool HAS_N, int DIR>
+__global__ __launch_bounds__(WAVE) void k_sweep_pk16(int n_tasks, const NraSweepTask* __restrict__ tasks,
+                                                     const NraDevRead* __restrict__ reads,
+                                                     const NraDevRegion* __restrict__ regions,
+                                                     const uint8_t* __restrict__ pool,
+                                                     const uint32_t* __restrict__ q2bit,
+                                                     const uint32_t* __restrict__ qnmask,
+                                                     NraScoreParams sp,
+                                                     const int32_t* __restrict__ kmin_arr,
+                                                     const int32_t* __restrict__ kmax_arr,
+                                                     const uint32_t* __restrict__ coff,
+                                                     int16_t* __restrict__ snap_h,
+                                                     int16_t* __restrict__ snap_e,
+                                                     int16_t* __restrict__ snap_e2,
+                                                     int32_t* __restrict__ arr_a,
+                                                     int32_t* __restrict__ cand_score,
+                                                     uint8_t* __restrict__ cand_flag)
+{
+    const int task = blockIdx.x;
+    if (task >= n_tasks) return;
+    const int lane = threadIdx.x;
+    const NraSweepTask tk = tasks[task];
+    const bool has_b = tk.read_b >= 0;
+    const int ra = tk.read_a, rb = has_b ? tk.read_b : tk.read_a;
+    const NraDevRead rda = reads[ra], rdb = reads[rb];
+    const NraDevRegion rg = regions[rda.region];
+    const int m = rg.m1;
+    const int flank = DIR ? rg.l1 : rg.l3;
+    const uint8_t* __restrict__ piece = pool + (DIR ? rg.p1_off : rg.pr_off);
+    const int ncols = flank + m * tk.kmax;
+    const int jfirst = flank + m * tk.kmin - 1;       // boundary column of k = kmin (>= 0: flank >= 1)
+    const int kmin_a = kmin_arr[ra], kmax_a = kmax_arr[ra];
+    const int kmin_b = kmin_arr[rb], kmax_b = kmax_arr[rb];
+    const uint32_t coff_a = coff[ra], coff_b = coff[rb];
+
+    const int o1 = sp.open1, o2 = sp.open2;
+    const s16x2 NEGP = splat(-8192);        // below any real state, and two of them still fit int16
+    const s16x2 v_floor = splat(-o1);                       // max(H,0) - o1
+    const s16x2 v_match = splat(sp.match + o1);             // substitution score + o1: the diagonal is read
+    const s16x2 v_negab = splat(-(sp.match + sp.mismatch)); // from Hq = H - o1, so d = max(Hq,-o1) + (s + o1)
+    const s16x2 v_negb = splat(o1 - sp.mismatch);
+    const s16x2 v_ambi = splat(o1 - sp.ambi);
+    const s16x2 v_o1 = splat(o1), v_e1 = splat(sp.ext1);
+    const s16x2 v_o2 = splat(o2), v_e2 = splat(sp.ext2);
+
+    int qc[R];
+#pragma unroll
+    for (int i = 0; i < R; ++i) {
+        const int gi = lane * R + i;
+        const int ca = sweep_query_code<HAS_N>(rda, q2bit, qnmask, gi, DIR == 0);
+        const int cb = sweep_query_code<HAS_N>(rdb, q2bit, qnmask, gi, DIR == 0);
+        qc[i] = ca | (cb << 16);
+    }
+
+    // forward sweep: the R side of the junction, row r pairs with reverse-sweep row Q-2-r
+    s16x2 Hbo[DIR ? R : 1], Ebo[DIR ? R : 1], E2bo[DIR ? R : 1];
+    if (DIR) {
+        const int q1 = sp.open1 - sp.ext1, q2 = sp.open2 - sp.ext2;     // the refunded gap opens
+#pragma unroll
+        for (int i = 0; i < R; ++i) {
+            const int r = lane * R + i;
+            int h[2], e[2], e2[2];
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+                const NraDevRead& rd = s ? rdb : rda;
+                const int a = rd.qlen - 2 - r;
+                if (a >= 0) {
+                    h[s] = snap_h[rd.qoff + a] + o1;      // cancels the -o1 carried by Hq in the combine
+                    e[s] = snap_e[rd.qoff + a] + q1;
+                    e2[s] = snap_e2[rd.qoff + a] + q2;
+                } else { h[s] = -8192; e[s] = -8192; e2[s] = -8192; }
+            }
+            Hbo[i] = as_s(pack2(h[0], h[1]));
+            Ebo[i] = as_s(pack2(e[0], e[1]));
+            E2bo[i] = as_s(pack2(e2[0], e2[1]));
+        }
+    }
+
+    s16x2 Hq[R], Hq2[R], E[R], E2[R];
+#pragma unroll
+    for (int i = 0; i < R; ++i) { Hq[i] = v_floor; Hq2[i] = NEGP; E[i] = NEGP; E2[i] = NEGP; }
+    s16x2 Hbot = v_floor, Fout = NEGP, F2out = NEGP, Hup_prev = v_floor, M = splat(0);
+    s16x2 accS = NEGP, accB = NEGP;
+    int tt = NRA_PAD_T | (NRA_PAD_T << 16);
+    int kcur = tk.kmin;                                   // meaningful in lane 63 only
+
+    const int nchunks = (ncols + 63 + 63) >> 6;
+    for (int c = 0; c < nchunks; ++c) {
+        const int col = c * 64 + lane;
+        int feed = NRA_PAD_T | (NRA_PAD_T << 16);
+        if (col < ncols) {
+            const int code = piece[col];
+            feed = code | (code << 16);
+            if (col >= jfirst && (col - jfirst) % m == 0) feed |= FLAG_BOUNDARY;
+            if (DIR == 0 && col == flank - 1) feed |= FLAG_SNAPSHOT;
+        }
+#pragma unroll 2
+        for (int s = 0; s < 64; ++s) {
+            s16x2 F = as_s(dpp_shr1(as_i(NEGP), as_i(Fout)));
+            s16x2 F2 = as_s(dpp_shr1(as_i(NEGP), as_i(F2out)));
+            tt = dpp_shr1(feed, tt);
+            feed = dpp_rol1(feed);
+            const s16x2 accS_in = as_s(dpp_shr1(as_i(NEGP), as_i(accS)));
+            const s16x2 accB_in = as_s(dpp_shr1(as_i(NEGP), as_i(accB)));
+            const int tcode = tt & 0x00ff00ff;
+#define NRA_SUBST(i, out)                                                                          \
+            {                                                                                      \
+                const s16x2 x_ = as_s(qc[i] ^ tcode);                                              \
+                out = pmax(x_ * v_negab + v_match, v_negb);                                        \
+                if (HAS_N) {                                                                       \
+                    const s16x2 n_ = as_s(((qc[i] | tcode) >> 2) & 0x00010001);                    \
+                    out = out + n_ * (v_ambi - out);                                               \
+                }                                                                                  \
+            }
+            s16x2 sc;
+            NRA_SUBST(0, sc);
+            s16x2 d = pmax(Hup_prev, v_floor) + sc;
+            Hup_prev = as_s(dpp_shr1(as_i(v_floor), as_i(Hbot)));
+#pragma unroll
+            for (int i = 0; i < R; ++i) {
+                s16x2 d_next = d;
+                if (i + 1 < R) {                   // uses H(i, j-1) before it is overwritten below
+                    NRA_SUBST(i + 1, sc);
+                    d_next = pmax(Hq[i], v_floor) + sc;
+                }
+                const s16x2 ein = pmax(E[i] - v_e1, Hq[i]);       // E(i,j) from column j-1, lazily
+                const s16x2 e2in = pmax(E2[i] - v_e2, Hq2[i]);
+                const s16x2 h = pmax(pmax(d, ein), pmax(F, pmax(e2in, F2)));   // H(i,j)
+                M = pmax(M, h);
+                E[i] = ein;
+                E2[i] = e2in;
+                const s16x2 hq = h - v_o1;                        // stored instead of H: feeds E, F and the diagonal
+                Hq[i] = hq;
+                const s16x2 hq2 = h - v_o2;
+                Hq2[i] = hq2;
+                F = pmax(F - v_e1, hq);
+                F2 = pmax(F2 - v_e2, hq2);
+                d = d_next;
+            }
+#undef NRA_SUBST
+            Hbot = Hq[R - 1]; Fout = F; F2out = F2;
+
+            const bool at_boundary = (tt & FLAG_BOUNDARY) != 0;
+            s16x2 tS = NEGP;
+            if (DIR) {
+                if (__builtin_amdgcn_ballot_w64(at_boundary) != 0) {
+#pragma unroll
+                    for (int i = 0; i < R; ++i) {
+                        const s16x2 t1 = pmax(Hq[i], v_floor) + Hbo[i];
+                        const s16x2 t2 = E[i] + Ebo[i];
+                        const s16x2 t3 = E2[i] + E2bo[i];
+                        tS = pmax(pmax(tS, t1), pmax(t2, t3));
+                    }
+                }
+            }
+            accS = pmax(accS_in, tS);
+            accB = pmax(accB_in, M);
+
+            if (DIR == 0 && (tt & FLAG_SNAPSHOT)) {
+#pragma unroll
+                for (int i = 0; i < R; ++i) {
+                    const int a = lane * R + i;
+                    const int hv = as_i(Hq[i]), ev = as_i(E[i]), e2v = as_i(E2[i]);
+                    if (a < rda.qlen) {
+                        snap_h[rda.qoff + a] = (int16_t)(half_lo(hv) + o1);      // H itself
+                        snap_e[rda.qoff + a] = (int16_t)half_lo(ev);
+                        snap_e2[rda.qoff + a] = (int16_t)half_lo(e2v);
+                    }
+                    if (has_b && a < rdb.qlen) {
+                        snap_h[rdb.qoff + a] = (int16_t)(half_hi(hv) + o1);
+                        snap_e[rdb.qoff + a] = (int16_t)half_hi(ev);
+                        snap_e2[rdb.qoff + a] = (int16_t)half_hi(e2v);
+                    }
+                }
+            }
+            if (lane == 63 && at_boundary) {
+                const int k = kcur++;
+                const int vS = as_i(accS), vB = as_i(accB);
+#pragma unroll
+                for (int s2 = 0; s2 < 2; ++s2) {
+                    const int lo_k = s2 ? kmin_b : kmin_a, hi_k = s2 ? kmax_b : kmax_a;
+                    if ((s2 == 0 || has_b) && k >= lo_k && k <= hi_k) {
+                        const uint32_t idx = (s2 ? coff_b : coff_a) + (uint32_t)(k - lo_k);
+                        const int B = s2 ? half_hi(vB) : half_lo(vB);
+                        if (DIR == 0) {
+                            arr_a[idx] = B;                       // running max of the reverse sweep = A_k
+                        } else {
+                            const int S = s2 ? half_hi(vS) : half_lo(vS);
+                            const int A = arr_a[idx];
+                            const int best = imax(imax(S, B), A);
+                            const int lo = sp.min_score > 1 ? sp.min_score : 1;
+                            int flag = 1;
+                            if (A >= best) flag = 0;                          // an optimal alignment starts in unit^k+R
+                            else if (B >= best) flag = (S >= best) ? 2 : 0;   // one ends inside L+unit^k
+                            cand_score[idx] = best >= lo ? best : -1;
+                            cand_flag[idx] = (uint8_t)flag;
+                        }
+                    }
+                }
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------
+// launchers
+// ------------------------------------------------------------------------------------
+template <int DIR>
+static int launch_sweep(int R, int has_n, hipStream_t st, int n_tasks, const NraSweepTask* tasks,
+                        const NraDevRead* reads, const NraDevRegion* regions, const uint8_t* pool,
+                        const uint32_t* q2bit, const uint32_t* qnmask, NraScoreParams sp,
+                        const int32_t* kmin, const int32_t* kmax, const uint32_t* coff,
+                        int16_t* snap_h, int16_t* snap_e, int16_t* snap_e2, int32_t* arr_a,
+                        int32_t* cand_score, uint8_t* cand_flag)
+{
+    if (n_tasks <= 0) return 0;
+#define CASE(r)                                                                                     \
+    case r:                                                                                         \
+        if (has_n) k_sweep_pk16<r, true, DIR><<<n_tasks, WAVE, 0, st>>>(n_tasks, tasks, reads, regions, pool, q2bit, qnmask, sp, kmin, kmax, coff, snap_h, snap_e, snap_e2, arr_a, cand_score, cand_flag); \
+        else k_sweep_pk16<r, false, DIR><<<n_tasks, WAVE, 0, st>>>(n_tasks, tasks, reads, regions, pool, q2bit, qnmask, sp, kmin, kmax, coff, snap_h, snap_e, snap_e2, arr_a, cand_score, cand_flag);       \
+        break;
+    switch (R) {
+        NRA_R_LIST(CASE)
+    default: return (int)hipErrorInvalidValue;
+    }
+#undef CASE
+    return (int)hipGetLastError();
+}
+
+#if NRA_HAS_PART(5)
+extern "C" int nra_launch_sweep_bwd(int R, int has_n, hipStream_t st, int n_tasks, const NraSweepTask* tasks,
+                                    const NraDevRead* reads, const NraDevRegion* regions, const uint8_t* pool,
+                                    const uint32_t* q2bit, const uint32_t* qnmask, NraScoreParams sp,
+                                    const int32_t* kmin, const int32_t* kmax, const uint32_t* coff,
+                                    int16_t* snap_h, int16_t* snap_e, int16_t* snap_e2, int32_t* arr_a)
+{
+    return launch_sweep<0>(R, has_n, st, n_tasks, tasks, reads, regions, pool, q2bit, qnmask, sp, kmin, kmax,
+                           coff, snap_h, snap_e, snap_e2, arr_a, nullptr, nullptr);
+}
+#endif
+#if NRA_HAS_PART(6)
+extern "C" int nra_launch_sweep_fwd(int R, int has_n, hipStream_t st, int n_tasks, const NraSweepTask* tasks,
+                                    const NraDevRead* reads, const NraDevRegion* regions, const uint8_t* pool,
+                                    const uint32_t* q2bit, const uint32_t* qnmask, NraScoreParams sp,
+                                    const int32_t* kmin, const int32_t* kmax, const uint32_t* coff,
+                                    int16_t* snap_h, int16_t* snap_e, int16_t* snap_e2, int32_t* arr_a,
+                                    int32_t* cand_score, uint8_t* cand_flag)
+{
+    return launch_sweep<1>(R, has_n, st, n_tasks, tasks, reads, regions, pool, q2bit, qnmask, sp, kmin, kmax,
+                           coff, snap_h, snap_e, snap_e2, arr_a, cand_score, cand_flag);
+}
+#endif

@@ -153,7 +153,7 @@ def test_1d_batch_rerun_is_idempotent(capi):
     for k in KEYS_1D:
         assert np.array_equal(first[k], again[k]), k
     assert st["n_alignments"] == 12 * 31 and st["score_kernel_ms"] > 0
-    assert st["executed_cells"] >= st["algorithmic_cells"] > 0
+    assert st["algorithmic_cells"] > st["executed_cells"] > 0     # the decomposition shares work across k
 
 
 def test_round3_estimation_golden_end_to_end(capi, golden_1d):
@@ -230,7 +230,7 @@ def test_joint_golden_end_to_end(capi, golden_2d):
 @pytest.fixture(scope="module")
 def config2_run(capi):
     d = synth.config2()
-    with capi.Batch.create_1d(d["regions"], d["reads"], d["kmin"], d["kmax"]) as b:
+    with capi.Batch.create_1d(d["regions"], d["reads"], d["kmin"], d["kmax"], flags=capi.F_TIE_EXTENTS) as b:
         b.run(); b.sync()
         return d, b.fetch(), b.stats()
 
@@ -272,3 +272,80 @@ def test_config2_order_and_batching_invariance(capi, config2_run):
                          per_candidate=False)
     for k in ("best_score", "sum_k", "n_ties", "status"):
         assert np.array_equal(sub[k], g[k][perm]), k
+
+
+# ------------------------------------------------------------------ junction decomposition vs brute force
+def _modes_agree(capi, oracle, d, sc_over=None):
+    """Every execution mode of the 1D path gives the oracle's per-read and per-candidate results:
+    0 = junction decomposition, flank verdict from three scores (extents DP only when ambiguous);
+    TIE_EXTENTS = decomposition + explicit extents for every tie; BRUTE_FORCE = K independent
+    alignments; ALL_EXTENTS = explicit extents for every candidate."""
+    sc_g = capi.default_scoring(**(sc_over or {}))
+    o = oracle.round3_1d(d["regions"], d["reads"], d["kmin"], d["kmax"], read_region=d.get("read_region"),
+                         sc=oracle.default_scoring(**(sc_over or {})))
+    res = {}
+    for flags in (0, capi.F_TIE_EXTENTS, capi.F_BRUTE_FORCE, capi.F_ALL_EXTENTS):
+        with capi.Batch.create_1d(d["regions"], d["reads"], d["kmin"], d["kmax"],
+                                  read_region=d.get("read_region"), sc=sc_g, flags=flags) as b:
+            b.run(); b.sync()
+            g = b.fetch()
+            res[flags] = (g, b.stats())
+        for k in ("best_score", "sum_k", "n_ties", "status", "cand_score"):
+            assert np.array_equal(g[k], o[k]), (flags, k, np.nonzero(g[k] != o[k])[0][:8], g[k][:12], o[k][:12])
+    # explicit extents, where a mode computed them, are the oracle's
+    g2 = res[capi.F_TIE_EXTENTS][0]
+    assert np.array_equal(g2["cand_tstart"], o["cand_tstart"]) and np.array_equal(g2["cand_tend"], o["cand_tend"])
+    return res
+
+
+def test_1d_decomposition_modes_agree(capi, oracle):
+    d = synth.make_1d(24, "TATTG", (8, 30), "ont", kwin=(0, 45), anchor=300, seed=101)
+    res = _modes_agree(capi, oracle, d)
+    st_fast, st_brute = res[0][1], res[capi.F_BRUTE_FORCE][1]
+    assert st_fast["executed_cells"] * 5 < st_brute["executed_cells"]
+    assert st_fast["algorithmic_cells"] == st_brute["algorithmic_cells"]
+    # different windows per read (reference rule), odd read count, several motifs
+    for unit, seed in (("CAG", 102), ("AT", 103), ("GGCCCC", 104), ("A", 105)):
+        _modes_agree(capi, oracle, synth.make_1d(15, unit, (4, 27), "ont_q20", kwin=None, anchor=200, flank=70, seed=seed))
+    _modes_agree(capi, oracle, synth.make_1d(9, "TATTG", (12, 20), "hifi", kwin=(10, 22), anchor=150, flank=60, seed=106),
+                 sc_over=dict(match=1, mismatch=3, gap_open1=5, gap_ext1=2, gap_open2=20, gap_ext2=1, min_dp_score=20))
+
+
+def test_1d_decomposition_adversarial(capi, oracle):
+    """Reads that break the flank tests or sit on the junction: no left / right flank, flank-only
+    reads, a read ending exactly at the repeat end, gaps spanning the junction, N bases, junk,
+    1-base flanks, one read per region (unpaired halves)."""
+    rng = np.random.default_rng(77)
+    L, R, u = synth.rand_seq(rng, 180), synth.rand_seq(rng, 160), "TATTG"
+    core = lambda k, fl=70, fr=70: L[len(L) - fl:] + u * k + R[:fr]
+    reads = [
+        core(9), core(9, 70, 0), core(9, 0, 70), core(9, 70, 1), core(9, 1, 70), core(9, 70, 3),
+        L[-70:], R[:70], u * 12, core(0), core(1),
+        core(9)[:70 + 45 - 7] + core(9)[70 + 45 + 6:],      # deletion across the unit/R junction
+        core(9)[:70 + 45] + "ACGTTGCAAC" + core(9)[70 + 45:],  # insertion at the junction
+        core(9)[:70 + 45 - 2] + "N" * 4 + core(9)[70 + 45 + 2:],
+        core(7) + synth.rand_seq(rng, 60), synth.rand_seq(rng, 60) + core(7),
+        synth.rand_seq(rng, 150), "ACG", "",
+        core(14), core(15), core(16),
+    ]
+    n = len(reads)
+    d = dict(regions=[(L, u, R)], reads=reads, kmin=np.zeros(n, np.int32), kmax=np.full(n, 20, np.int32))
+    d["kmin"][3] = 5; d["kmax"][3] = 4          # skipped read among paired ones
+    _modes_agree(capi, oracle, d)
+    _modes_agree(capi, oracle, d, sc_over=dict(min_dp_score=0))
+    # 1-base flanks and a flank-less region (falls back to brute force inside the library)
+    for Lx, Rx in ((L[-1:], R[:1]), (L[-1:], R), ("", R), (L, "")):
+        dx = dict(regions=[(Lx, u, Rx)], reads=[u * 7, Lx + u * 5 + Rx, "GG" + u * 6 + "TT"], kmin=[0, 0, 2], kmax=[12, 9, 9])
+        _modes_agree(capi, oracle, dx, sc_over=dict(min_dp_score=10))
+    # many regions with one or two reads each
+    regions, rds, rr, kmin, kmax = [], [], [], [], []
+    for g in range(7):
+        unit = synth.rand_unit(rng, 2 + g % 5)
+        Lg, Rg = synth.rand_seq(rng, 60 + 7 * g), synth.rand_seq(rng, 90 - 5 * g)
+        regions.append((Lg, unit, Rg))
+        for j in range(1 + g % 2):
+            k = int(rng.integers(0, 25))
+            rds.append(synth.apply_errors(rng, Lg[-50:] + unit * k + Rg[:50], "ont")); rr.append(g)
+            kmin.append(max(0, k - 6)); kmax.append(k + 6 + j)
+    _modes_agree(capi, oracle, dict(regions=regions, reads=rds, kmin=kmin, kmax=kmax, read_region=rr),
+                 sc_over=dict(min_dp_score=30))
