@@ -170,6 +170,9 @@ struct nra_batch {
     DevBuf<int8_t> strand_in, strand_out;
     bool have_strand_in = false;
 
+    std::vector<hipStream_t> bstreams;   // one per bucket: the sweep chains of different buckets overlap
+    std::vector<hipEvent_t> bdone;       // bucket chain finished
+    hipEvent_t fork_ev = nullptr;
     std::vector<hipEvent_t> ev;    // [0]=run start, [1]=run end, then pairs per dominant launch
     int n_score_ev = 0, n_ext_ev = 0;
     bool ran = false;
@@ -178,6 +181,9 @@ struct nra_batch {
     ~nra_batch()
     {
         for (hipEvent_t e : ev) (void)hipEventDestroy(e);
+        for (hipEvent_t e : bdone) (void)hipEventDestroy(e);
+        if (fork_ev) (void)hipEventDestroy(fork_ev);
+        for (hipStream_t q : bstreams) (void)hipStreamDestroy(q);
         if (stream) (void)hipStreamDestroy(stream);
     }
 };
@@ -474,6 +480,14 @@ int nra_batch1d_create(int device, const nra_region_t* regions, int32_t n_region
     HIP_TRY(b->status.alloc((size_t)n_reads));
     rc = make_events(b, 2 + 6 * (int)nb + 2);
     if (rc) return rc;
+    if (!brute) {
+        b->bstreams.resize(nb); b->bdone.resize(nb);
+        for (size_t i = 0; i < nb; ++i) {
+            HIP_TRY(hipStreamCreateWithFlags(&b->bstreams[i], hipStreamNonBlocking));
+            HIP_TRY(hipEventCreateWithFlags(&b->bdone[i], hipEventDisableTiming));
+        }
+        HIP_TRY(hipEventCreateWithFlags(&b->fork_ev, hipEventDisableTiming));
+    }
 
     b->stats.n_alignments = total;
     b->stats.algorithmic_cells = alg_cells;
@@ -502,24 +516,28 @@ static int run_1d(nra_batch* b)
     const int max_waves = 256 * 16;
     const bool tie_ext = (b->flags & NRA_F_TIE_EXTENTS) != 0;
     if (!b->brute) {
-        // junction decomposition: reverse sweeps of every bucket, then forward sweeps
-        for (int dir = 0; dir < 2; ++dir) {
-            for (size_t i = 0; i < nb; ++i) {
-                const Bucket& bk = b->buckets[i];
-                HIP_TRY(hipEventRecord(b->ev[ev++], st));
-                if (dir == 0)
-                    LAUNCH_TRY(nra_launch_sweep_bwd(bk.R, b->has_n, st, bk.n_sweep, b->sweep_tasks.p + bk.sweep_off,
-                                                    b->reads.p, b->regions.p, b->pool.p, b->q2bit.p, b->qnmask.p, b->sp,
-                                                    b->kmin.p, b->kmax.p, b->coff.p, b->snap_h.p, b->snap_e.p,
-                                                    b->snap_e2.p, b->arr_a.p));
-                else
-                    LAUNCH_TRY(nra_launch_sweep_fwd(bk.R, b->has_n, st, bk.n_sweep, b->sweep_tasks.p + bk.sweep_off,
-                                                    b->reads.p, b->regions.p, b->pool.p, b->q2bit.p, b->qnmask.p, b->sp,
-                                                    b->kmin.p, b->kmax.p, b->coff.p, b->snap_h.p, b->snap_e.p,
-                                                    b->snap_e2.p, b->arr_a.p, b->cand_score.p, b->cand_flag.p));
-                HIP_TRY(hipEventRecord(b->ev[ev++], st));
-                b->n_score_ev++;
-            }
+        // junction decomposition: per bucket a chain reverse sweep -> forward sweep, each chain on
+        // its own stream so that short buckets fill the SIMDs a long bucket's tail leaves idle
+        HIP_TRY(hipEventRecord(b->fork_ev, st));
+        for (size_t i = 0; i < nb; ++i) {
+            const Bucket& bk = b->buckets[i];
+            hipStream_t q = b->bstreams[i];
+            HIP_TRY(hipStreamWaitEvent(q, b->fork_ev, 0));
+            HIP_TRY(hipEventRecord(b->ev[ev++], q));
+            LAUNCH_TRY(nra_launch_sweep_bwd(bk.R, b->has_n, q, bk.n_sweep, b->sweep_tasks.p + bk.sweep_off,
+                                            b->reads.p, b->regions.p, b->pool.p, b->q2bit.p, b->qnmask.p, b->sp,
+                                            b->kmin.p, b->kmax.p, b->coff.p, b->snap_h.p, b->snap_e.p,
+                                            b->snap_e2.p, b->arr_a.p));
+            HIP_TRY(hipEventRecord(b->ev[ev++], q));
+            HIP_TRY(hipEventRecord(b->ev[ev++], q));
+            LAUNCH_TRY(nra_launch_sweep_fwd(bk.R, b->has_n, q, bk.n_sweep, b->sweep_tasks.p + bk.sweep_off,
+                                            b->reads.p, b->regions.p, b->pool.p, b->q2bit.p, b->qnmask.p, b->sp,
+                                            b->kmin.p, b->kmax.p, b->coff.p, b->snap_h.p, b->snap_e.p,
+                                            b->snap_e2.p, b->arr_a.p, b->cand_score.p, b->cand_flag.p));
+            HIP_TRY(hipEventRecord(b->ev[ev++], q));
+            b->n_score_ev += 2;
+            HIP_TRY(hipEventRecord(b->bdone[i], q));
+            HIP_TRY(hipStreamWaitEvent(st, b->bdone[i], 0));
         }
     } else {
         for (size_t i = 0; i < nb; ++i) {
