@@ -365,6 +365,10 @@ int nra_batch1d_create(int device, const nra_region_t* regions, int32_t n_region
     bool brute = all_ext || (flags & NRA_F_BRUTE_FORCE) != 0;
     for (int32_t g = 0; g < n_regions; ++g)       // the junction needs a base on either side
         if (regions[g].left_len < 1 || regions[g].right_len < 1) brute = true;
+    {   // the sweep kernels keep (substitution score + gap-open cost) in unsigned table bytes
+        const int o1 = sc->gap_open1 + sc->gap_ext1;
+        if (o1 < sc->mismatch || o1 < sc->sc_ambi || sc->match + o1 > 127) brute = true;
+    }
     b->brute = brute;
     std::vector<NraSweepTask> sweep_tasks;
     std::vector<std::vector<int32_t>> by_bucket((size_t)kNumR);

@@ -38,23 +38,32 @@
 #endif
 #define NRA_HAS_PART(n) (NRA_PART == 0 || NRA_PART == (n))
 
-#define FLAG_BOUNDARY 0x100
-#define FLAG_SNAPSHOT 0x200
+// Registers hold (value + BIAS) in both int16 halves, so that every add/subtract of a small
+// constant or of another biased value is carry-safe as ONE full-rate 32-bit v_add/v_sub_u32
+// (2 cycles per wave) instead of a half-rate VOP3P v_pk_add/sub_i16 (4 cycles); only the
+// maxima need the packed op.  The substitution score is one v_perm_b32 through a 4-entry
+// byte table that travels with the template base.  (Issue rates: profiles/r01_valu_ubench_*.)
+#define BIAS 8192
+#define NEGB 1024                     // biased "minus infinity" (value -7168): below any real state (>= -1100),
+                                      // survives a subtraction of any gap constant, and two of them still fit
+#define FLAG_BOUNDARY 0x00000080      // bit 7 of table byte 0
+#define FLAG_SNAPSHOT 0x00008000      // bit 7 of table byte 1
 
-__device__ __forceinline__ int half_lo(int v) { return (short)(v & 0xffff); }
-__device__ __forceinline__ int half_hi(int v) { return (short)(v >> 16); }
+__device__ __forceinline__ int half_lo(int v) { return v & 0xffff; }
+__device__ __forceinline__ int half_hi(int v) { return (v >> 16) & 0xffff; }
 __device__ __forceinline__ int pack2(int lo, int hi) { return (lo & 0xffff) | (hi << 16); }
+__device__ __forceinline__ int pmaxi(int a, int b) { return as_i(pmax(as_s(a), as_s(b))); }
 
-// query base of row gi; rev = read the read back to front (no complement)
+// selector byte of one query row for v_perm_b32: 0..3 base, 4 padding row, 5 N
 template <bool HAS_N>
-__device__ __forceinline__ int sweep_query_code(const NraDevRead& rd, const uint32_t* q2bit,
-                                                const uint32_t* qnmask, int gi, bool rev)
+__device__ __forceinline__ int sweep_query_sel(const NraDevRead& rd, const uint32_t* q2bit,
+                                               const uint32_t* qnmask, int gi, bool rev)
 {
-    if (gi >= rd.qlen) return NRA_PAD_Q;
+    if (gi >= rd.qlen) return 4;
     uint32_t b = rd.qoff + (uint32_t)(rev ? (rd.qlen - 1 - gi) : gi);
     int c = (q2bit[b >> 4] >> ((b & 15u) * 2u)) & 3u;
     if (HAS_N) {
-        if ((qnmask[b >> 5] >> (b & 31u)) & 1u) c = NRA_CODE_N;
+        if ((qnmask[b >> 5] >> (b & 31u)) & 1u) c = 5;
     }
     return c;
 }
@@ -95,26 +104,26 @@ __global__ __launch_bounds__(WAVE) void k_sweep_pk16(int n_tasks, const NraSweep
     const uint32_t coff_a = coff[ra], coff_b = coff[rb];
 
     const int o1 = sp.open1, o2 = sp.open2;
-    const s16x2 NEGP = splat(-8192);        // below any real state, and two of them still fit int16
-    const s16x2 v_floor = splat(-o1);                       // max(H,0) - o1
-    const s16x2 v_match = splat(sp.match + o1);             // substitution score + o1: the diagonal is read
-    const s16x2 v_negab = splat(-(sp.match + sp.mismatch)); // from Hq = H - o1, so d = max(Hq,-o1) + (s + o1)
-    const s16x2 v_negb = splat(o1 - sp.mismatch);
-    const s16x2 v_ambi = splat(o1 - sp.ambi);
-    const s16x2 v_o1 = splat(o1), v_e1 = splat(sp.ext1);
-    const s16x2 v_o2 = splat(o2), v_e2 = splat(sp.ext2);
+    const int P1 = 0x00010001;
+    const int v_floor = (BIAS - o1) * P1;                   // max(H,0) - o1
+    const int v_o1 = o1 * P1, v_e1 = sp.ext1 * P1, v_o2 = o2 * P1, v_e2 = sp.ext2 * P1;
+    const int NEG1 = NEGB * P1, NEG2 = 2 * NEGB * P1;       // biased once / twice
+    // substitution scores + o1 (the diagonal is read from Hq = H - o1): all in [0, 127]
+    const int s_match = sp.match + o1, s_mis = o1 - sp.mismatch, s_ambi = o1 - sp.ambi;
+    const int tbl_hi = s_mis | (s_ambi << 8);               // selector 4: padding row, 5: N in the read
+    const int tbl_mis4 = s_mis * 0x01010101, tbl_ambi4 = s_ambi * 0x01010101;
 
-    int qc[R];
+    int qc[R];       // v_perm selectors: {selA, zero, selB, zero}
 #pragma unroll
     for (int i = 0; i < R; ++i) {
         const int gi = lane * R + i;
-        const int ca = sweep_query_code<HAS_N>(rda, q2bit, qnmask, gi, DIR == 0);
-        const int cb = sweep_query_code<HAS_N>(rdb, q2bit, qnmask, gi, DIR == 0);
-        qc[i] = ca | (cb << 16);
+        const int ca = sweep_query_sel<HAS_N>(rda, q2bit, qnmask, gi, DIR == 0);
+        const int cb = sweep_query_sel<HAS_N>(rdb, q2bit, qnmask, gi, DIR == 0);
+        qc[i] = ca | (0x0c << 8) | (cb << 16) | (0x0c << 24);
     }
 
     // forward sweep: the R side of the junction, row r pairs with reverse-sweep row Q-2-r
-    s16x2 Hbo[DIR ? R : 1], Ebo[DIR ? R : 1], E2bo[DIR ? R : 1];
+    int Hbo[DIR ? R : 1], Ebo[DIR ? R : 1], E2bo[DIR ? R : 1];
     if (DIR) {
         const int q1 = sp.open1 - sp.ext1, q2 = sp.open2 - sp.ext2;     // the refunded gap opens
 #pragma unroll
@@ -126,127 +135,111 @@ __global__ __launch_bounds__(WAVE) void k_sweep_pk16(int n_tasks, const NraSweep
                 const NraDevRead& rd = s ? rdb : rda;
                 const int a = rd.qlen - 2 - r;
                 if (a >= 0) {
-                    h[s] = snap_h[rd.qoff + a] + o1;      // cancels the -o1 carried by Hq in the combine
-                    e[s] = snap_e[rd.qoff + a] + q1;
-                    e2[s] = snap_e2[rd.qoff + a] + q2;
-                } else { h[s] = -8192; e[s] = -8192; e2[s] = -8192; }
+                    h[s] = snap_h[rd.qoff + a] + o1 + BIAS;   // +o1 cancels the -o1 carried by Hq
+                    e[s] = snap_e[rd.qoff + a] + q1 + BIAS;
+                    e2[s] = snap_e2[rd.qoff + a] + q2 + BIAS;
+                } else { h[s] = NEGB; e[s] = NEGB; e2[s] = NEGB; }
             }
-            Hbo[i] = as_s(pack2(h[0], h[1]));
-            Ebo[i] = as_s(pack2(e[0], e[1]));
-            E2bo[i] = as_s(pack2(e2[0], e2[1]));
+            Hbo[i] = pack2(h[0], h[1]);
+            Ebo[i] = pack2(e[0], e[1]);
+            E2bo[i] = pack2(e2[0], e2[1]);
         }
     }
 
-    s16x2 Hq[R], Hq2[R], E[R], E2[R];
+    int Hq[R], Hq2[R], E[R], E2[R];
 #pragma unroll
-    for (int i = 0; i < R; ++i) { Hq[i] = v_floor; Hq2[i] = NEGP; E[i] = NEGP; E2[i] = NEGP; }
-    s16x2 Hbot = v_floor, Fout = NEGP, F2out = NEGP, Hup_prev = v_floor, M = splat(0);
-    s16x2 accS = NEGP, accB = NEGP;
-    int tt = NRA_PAD_T | (NRA_PAD_T << 16);
+    for (int i = 0; i < R; ++i) { Hq[i] = v_floor; Hq2[i] = NEG1; E[i] = NEG1; E2[i] = NEG1; }
+    int Hbot = v_floor, Fout = NEG1, F2out = NEG1, Hup_prev = v_floor, M = BIAS * P1;
+    int accS = NEG2, accB = NEG1;
+    int tt = tbl_mis4;                                    // padding column: everything mismatches
     int kcur = tk.kmin;                                   // meaningful in lane 63 only
 
     const int nchunks = (ncols + 63 + 63) >> 6;
     for (int c = 0; c < nchunks; ++c) {
         const int col = c * 64 + lane;
-        int feed = NRA_PAD_T | (NRA_PAD_T << 16);
+        int feed = tbl_mis4;
         if (col < ncols) {
             const int code = piece[col];
-            feed = code | (code << 16);
+            feed = code < 4 ? tbl_mis4 + ((s_match - s_mis) << (8 * code)) : tbl_ambi4;
             if (col >= jfirst && (col - jfirst) % m == 0) feed |= FLAG_BOUNDARY;
             if (DIR == 0 && col == flank - 1) feed |= FLAG_SNAPSHOT;
         }
 #pragma unroll 2
         for (int s = 0; s < 64; ++s) {
-            s16x2 F = as_s(dpp_shr1(as_i(NEGP), as_i(Fout)));
-            s16x2 F2 = as_s(dpp_shr1(as_i(NEGP), as_i(F2out)));
+            int F = dpp_shr1(NEG1, Fout);
+            int F2 = dpp_shr1(NEG1, F2out);
             tt = dpp_shr1(feed, tt);
             feed = dpp_rol1(feed);
-            const s16x2 accS_in = as_s(dpp_shr1(as_i(NEGP), as_i(accS)));
-            const s16x2 accB_in = as_s(dpp_shr1(as_i(NEGP), as_i(accB)));
-            const int tcode = tt & 0x00ff00ff;
-#define NRA_SUBST(i, out)                                                                          \
-            {                                                                                      \
-                const s16x2 x_ = as_s(qc[i] ^ tcode);                                              \
-                out = pmax(x_ * v_negab + v_match, v_negb);                                        \
-                if (HAS_N) {                                                                       \
-                    const s16x2 n_ = as_s(((qc[i] | tcode) >> 2) & 0x00010001);                    \
-                    out = out + n_ * (v_ambi - out);                                               \
-                }                                                                                  \
-            }
-            s16x2 sc;
-            NRA_SUBST(0, sc);
-            s16x2 d = pmax(Hup_prev, v_floor) + sc;
-            Hup_prev = as_s(dpp_shr1(as_i(v_floor), as_i(Hbot)));
+            const int accS_in = dpp_shr1(NEG2, accS);
+            const int accB_in = dpp_shr1(NEG1, accB);
+            const int tbl = tt & 0x7f7f7f7f;
+            int d = pmaxi(Hup_prev, v_floor) + (int)__builtin_amdgcn_perm(tbl_hi, tbl, qc[0]);
+            Hup_prev = dpp_shr1(v_floor, Hbot);
 #pragma unroll
             for (int i = 0; i < R; ++i) {
-                s16x2 d_next = d;
-                if (i + 1 < R) {                   // uses H(i, j-1) before it is overwritten below
-                    NRA_SUBST(i + 1, sc);
-                    d_next = pmax(Hq[i], v_floor) + sc;
-                }
-                const s16x2 ein = pmax(E[i] - v_e1, Hq[i]);       // E(i,j) from column j-1, lazily
-                const s16x2 e2in = pmax(E2[i] - v_e2, Hq2[i]);
-                const s16x2 h = pmax(pmax(d, ein), pmax(F, pmax(e2in, F2)));   // H(i,j)
-                M = pmax(M, h);
+                int d_next = d;
+                if (i + 1 < R)                     // uses H(i, j-1) before it is overwritten below
+                    d_next = pmaxi(Hq[i], v_floor) + (int)__builtin_amdgcn_perm(tbl_hi, tbl, qc[i + 1]);
+                const int ein = pmaxi(E[i] - v_e1, Hq[i]);        // E(i,j) from column j-1, lazily
+                const int e2in = pmaxi(E2[i] - v_e2, Hq2[i]);
+                const int h = pmaxi(pmaxi(d, ein), pmaxi(F, pmaxi(e2in, F2)));   // H(i,j)
+                M = pmaxi(M, h);
                 E[i] = ein;
                 E2[i] = e2in;
-                const s16x2 hq = h - v_o1;                        // stored instead of H: feeds E, F and the diagonal
+                const int hq = h - v_o1;           // stored instead of H: feeds E, F and the diagonal
                 Hq[i] = hq;
-                const s16x2 hq2 = h - v_o2;
+                const int hq2 = h - v_o2;
                 Hq2[i] = hq2;
-                F = pmax(F - v_e1, hq);
-                F2 = pmax(F2 - v_e2, hq2);
+                F = pmaxi(F - v_e1, hq);
+                F2 = pmaxi(F2 - v_e2, hq2);
                 d = d_next;
             }
-#undef NRA_SUBST
             Hbot = Hq[R - 1]; Fout = F; F2out = F2;
 
             const bool at_boundary = (tt & FLAG_BOUNDARY) != 0;
-            s16x2 tS = NEGP;
+            int tS = NEG2;
             if (DIR) {
                 if (__builtin_amdgcn_ballot_w64(at_boundary) != 0) {
 #pragma unroll
                     for (int i = 0; i < R; ++i) {
-                        const s16x2 t1 = pmax(Hq[i], v_floor) + Hbo[i];
-                        const s16x2 t2 = E[i] + Ebo[i];
-                        const s16x2 t3 = E2[i] + E2bo[i];
-                        tS = pmax(pmax(tS, t1), pmax(t2, t3));
+                        const int t1 = pmaxi(Hq[i], v_floor) + Hbo[i];     // biased twice from here on
+                        const int t2 = E[i] + Ebo[i];
+                        const int t3 = E2[i] + E2bo[i];
+                        tS = pmaxi(pmaxi(tS, t1), pmaxi(t2, t3));
                     }
                 }
             }
-            accS = pmax(accS_in, tS);
-            accB = pmax(accB_in, M);
+            accS = pmaxi(accS_in, tS);
+            accB = pmaxi(accB_in, M);
 
             if (DIR == 0 && (tt & FLAG_SNAPSHOT)) {
 #pragma unroll
                 for (int i = 0; i < R; ++i) {
                     const int a = lane * R + i;
-                    const int hv = as_i(Hq[i]), ev = as_i(E[i]), e2v = as_i(E2[i]);
                     if (a < rda.qlen) {
-                        snap_h[rda.qoff + a] = (int16_t)(half_lo(hv) + o1);      // H itself
-                        snap_e[rda.qoff + a] = (int16_t)half_lo(ev);
-                        snap_e2[rda.qoff + a] = (int16_t)half_lo(e2v);
+                        snap_h[rda.qoff + a] = (int16_t)(half_lo(Hq[i]) + o1 - BIAS);      // H itself
+                        snap_e[rda.qoff + a] = (int16_t)(half_lo(E[i]) - BIAS);
+                        snap_e2[rda.qoff + a] = (int16_t)(half_lo(E2[i]) - BIAS);
                     }
                     if (has_b && a < rdb.qlen) {
-                        snap_h[rdb.qoff + a] = (int16_t)(half_hi(hv) + o1);
-                        snap_e[rdb.qoff + a] = (int16_t)half_hi(ev);
-                        snap_e2[rdb.qoff + a] = (int16_t)half_hi(e2v);
+                        snap_h[rdb.qoff + a] = (int16_t)(half_hi(Hq[i]) + o1 - BIAS);
+                        snap_e[rdb.qoff + a] = (int16_t)(half_hi(E[i]) - BIAS);
+                        snap_e2[rdb.qoff + a] = (int16_t)(half_hi(E2[i]) - BIAS);
                     }
                 }
             }
             if (lane == 63 && at_boundary) {
                 const int k = kcur++;
-                const int vS = as_i(accS), vB = as_i(accB);
 #pragma unroll
                 for (int s2 = 0; s2 < 2; ++s2) {
                     const int lo_k = s2 ? kmin_b : kmin_a, hi_k = s2 ? kmax_b : kmax_a;
                     if ((s2 == 0 || has_b) && k >= lo_k && k <= hi_k) {
                         const uint32_t idx = (s2 ? coff_b : coff_a) + (uint32_t)(k - lo_k);
-                        const int B = s2 ? half_hi(vB) : half_lo(vB);
+                        const int B = (s2 ? half_hi(accB) : half_lo(accB)) - BIAS;
                         if (DIR == 0) {
                             arr_a[idx] = B;                       // running max of the reverse sweep = A_k
                         } else {
-                            const int S = s2 ? half_hi(vS) : half_lo(vS);
+                            const int S = (s2 ? half_hi(accS) : half_lo(accS)) - 2 * BIAS;
                             const int A = arr_a[idx];
                             const int best = imax(imax(S, B), A);
                             const int lo = sp.min_score > 1 ? sp.min_score : 1;
