@@ -157,7 +157,10 @@ def main():
     exact = float(np.mean(est == data["k_true"][ok])) if ok.any() else 0.0
 
     if rank == 0:
-        kernel_s = st["score_kernel_ms"] / 1e3      # sum of the scoring kernels' launch durations (HIP events)
+        # device wall time of the scoring phase (HIP events on the batch stream).  The launches of
+        # different read-length buckets overlap on their own streams, so this is what the kernels
+        # achieve together; the sum of their individual launch durations is reported beside it.
+        kernel_s = st["score_phase_ms"] / 1e3
         alg_cells_per_s = st["algorithmic_cells"] / kernel_s
         exe_cells_per_s = st["executed_cells"] / kernel_s
         achieved = alg_cells_per_s * LANEOPS_PER_CELL / 1e12
@@ -195,7 +198,8 @@ def main():
                                       "cells_per_step": st["executed_cells"],
                                       "Tcell_per_s": exe_cells_per_s / 1e12},
                          "kernel": "k_score_pk16<R>" if args.brute else "k_sweep_pk16<R,dir> (reverse + forward sweeps, all R)",
-                         "kernel_ms_per_step": st["score_kernel_ms"],
+                         "kernel_ms_per_step": st["score_phase_ms"],
+                         "sum_of_launch_durations_ms": st["score_kernel_ms"],
                          "n_launches_per_step": st["n_score_launches"],
                          "algorithmic_cells_per_step": st["algorithmic_cells"],
                          "Tcell_per_s": alg_cells_per_s / 1e12,

@@ -106,6 +106,9 @@ typedef struct nra_stats {
     double  total_ms;         /* first launch -> last launch of the run, HIP events */
     int32_t n_score_launches;
     int32_t reserved;
+    double  score_phase_ms;   /* wall time of the scoring phase on the device (first scoring launch ->
+                                 last one done); < score_kernel_ms when launches of different read-length
+                                 buckets overlap on their own streams */
 } nra_stats_t;
 
 typedef struct nra_batch nra_batch_t;   /* device-resident inputs + outputs of one call */

@@ -53,7 +53,8 @@ class Stats(C.Structure):
                 ("executed_cells", C.c_int64), ("algorithmic_bytes", C.c_int64),
                 ("n_extent_tasks", C.c_int64), ("score_kernel_ms", C.c_double),
                 ("extent_kernel_ms", C.c_double), ("total_ms", C.c_double),
-                ("n_score_launches", C.c_int32), ("reserved", C.c_int32)]
+                ("n_score_launches", C.c_int32), ("reserved", C.c_int32),
+                ("score_phase_ms", C.c_double)]
 
     def as_dict(self):
         return {n: getattr(self, n) for n, _ in self._fields_ if n != "reserved"}

@@ -173,6 +173,7 @@ struct nra_batch {
     std::vector<hipStream_t> bstreams;   // one per bucket: the sweep chains of different buckets overlap
     std::vector<hipEvent_t> bdone;       // bucket chain finished
     hipEvent_t fork_ev = nullptr;
+    hipEvent_t phase_ev[2] = {nullptr, nullptr};   // scoring phase start / end (timing)
     std::vector<hipEvent_t> ev;    // [0]=run start, [1]=run end, then pairs per dominant launch
     int n_score_ev = 0, n_ext_ev = 0;
     bool ran = false;
@@ -183,6 +184,7 @@ struct nra_batch {
         for (hipEvent_t e : ev) (void)hipEventDestroy(e);
         for (hipEvent_t e : bdone) (void)hipEventDestroy(e);
         if (fork_ev) (void)hipEventDestroy(fork_ev);
+        for (hipEvent_t e : phase_ev) if (e) (void)hipEventDestroy(e);
         for (hipStream_t q : bstreams) (void)hipStreamDestroy(q);
         if (stream) (void)hipStreamDestroy(stream);
     }
@@ -260,6 +262,7 @@ int make_events(nra_batch* b, int n)
 {
     b->ev.resize((size_t)n);
     for (int i = 0; i < n; ++i) HIP_TRY(hipEventCreate(&b->ev[i]));
+    for (int i = 0; i < 2; ++i) HIP_TRY(hipEventCreate(&b->phase_ev[i]));
     return NRA_OK;
 }
 
@@ -519,6 +522,7 @@ static int run_1d(nra_batch* b)
     b->n_score_ev = 0; b->n_ext_ev = 0;
     const int max_waves = 256 * 16;
     const bool tie_ext = (b->flags & NRA_F_TIE_EXTENTS) != 0;
+    HIP_TRY(hipEventRecord(b->phase_ev[0], st));
     if (!b->brute) {
         // junction decomposition: per bucket a chain reverse sweep -> forward sweep, each chain on
         // its own stream so that short buckets fill the SIMDs a long bucket's tail leaves idle
@@ -562,6 +566,7 @@ static int run_1d(nra_batch* b)
             b->n_score_ev++;
         }
     }
+    HIP_TRY(hipEventRecord(b->phase_ev[1], st));
     // ties that need the explicit extents DP: all of them (brute force / TIE_EXTENTS), or only those
     // whose three-score flank verdict is ambiguous
     const int append_mode = all_ext ? 0 : ((b->brute || tie_ext) ? 2 : 1);
@@ -786,6 +791,7 @@ static int run_2d(nra_batch* b)
     }
     LAUNCH_TRY(nra_launch_pick_strand(st, b->n_reads, b->probe_score.p,
                                       b->have_strand_in ? b->strand_in.p : nullptr, b->strand_out.p, b->reads.p));
+    HIP_TRY(hipEventRecord(b->phase_ev[0], st));
     for (size_t i = 0; i < nb; ++i) {
         const Bucket& bk = b->buckets[i];
         HIP_TRY(hipEventRecord(b->ev[ev++], st));
@@ -797,6 +803,7 @@ static int run_2d(nra_batch* b)
         HIP_TRY(hipEventRecord(b->ev[ev++], st));
         b->n_score_ev++;
     }
+    HIP_TRY(hipEventRecord(b->phase_ev[1], st));
     LAUNCH_TRY(nra_launch_select_2d(st, b->n_reads, b->cell_first.p, b->cell_cnt.p, b->cell_k1.p, b->cell_k2.p,
                                     b->cand_score.p, b->cand_tstart.p, b->best_score.p, b->sum_k.p,
                                     b->sum_k2.p, b->n_ties.p, b->status.p));
@@ -871,6 +878,8 @@ int nra_batch_stats(nra_batch_t* b, nra_stats_t* st)
         float ms = 0.f;
         HIP_TRY(hipEventElapsedTime(&ms, b->ev[0], b->ev[1]));
         b->stats.total_ms = ms;
+        HIP_TRY(hipEventElapsedTime(&ms, b->phase_ev[0], b->phase_ev[1]));
+        b->stats.score_phase_ms = ms;
         // event pairs were recorded in launch order: 1D: score..., extents...; 2D: probe..., window...
         double first = 0, second = 0;
         const int n_first = b->kind == 1 ? b->n_score_ev : b->n_ext_ev;
