@@ -381,6 +381,17 @@ int nra_batch1d_create(int device, const nra_region_t* regions, int32_t n_region
         read_bucket[r] = bi;
         by_bucket[bi].push_back(r);
     }
+    // a bucket with a handful of reads would run as its own under-filled launch: fold it into the
+    // next larger rows-per-lane instantiation (the extra rows are padding)
+    for (int bi = 0; bi + 1 < kNumR; ++bi) {
+        if (by_bucket[bi].empty() || by_bucket[bi].size() >= 1024) continue;
+        int up = -1;
+        for (int bj = bi + 1; bj < kNumR && kRList[bj] <= kRList[bi] + 2; ++bj)
+            if (!by_bucket[bj].empty()) { up = bj; break; }
+        if (up < 0) continue;
+        by_bucket[up].insert(by_bucket[up].end(), by_bucket[bi].begin(), by_bucket[bi].end());
+        by_bucket[bi].clear();
+    }
     std::vector<NraPairTask> pair_tasks;
     std::vector<NraTask> queue_tasks;       // ALL_EXTENTS only; otherwise just capacity
     std::vector<int32_t> queue_count;

@@ -68,6 +68,79 @@ __device__ __forceinline__ int sweep_query_sel(const NraDevRead& rd, const uint3
     return c;
 }
 
+// One virtual systolic cell: rows [OFF, OFF+N) of the lane's arrays, one template column.
+// diag = H(row above, j-1) - o1; F/F2 enter from the row above at this column and leave for the
+// row below.  Returns nothing; the cell's last-row Hq is Hq[OFF+N-1].
+template <int OFF, int N, int R>
+__device__ __forceinline__ void sweep_cell(int (&Hq)[R], int (&Hq2)[R], int (&E)[R], int (&E2)[R],
+                                           const int (&qc)[R], int diag, int& F, int& F2, int& M,
+                                           int tbl, int tbl_hi, int v_floor, int v_e1, int v_e2,
+                                           int v_o1, int v_o2)
+{
+    if (N == 0) return;
+    int d = pmaxi(diag, v_floor) + (int)__builtin_amdgcn_perm(tbl_hi, tbl, qc[OFF]);
+#pragma unroll
+    for (int n = 0; n < N; ++n) {
+        const int i = OFF + n;
+        int d_next = d;
+        if (n + 1 < N)                         // uses H(i, j-1) before it is overwritten below
+            d_next = pmaxi(Hq[i], v_floor) + (int)__builtin_amdgcn_perm(tbl_hi, tbl, qc[i + 1]);
+        const int ein = pmaxi(E[i] - v_e1, Hq[i]);            // E(i,j) from column j-1, lazily
+        const int e2in = pmaxi(E2[i] - v_e2, Hq2[i]);
+        const int h = pmaxi(pmaxi(d, ein), pmaxi(F, pmaxi(e2in, F2)));   // H(i,j)
+        M = pmaxi(M, h);
+        E[i] = ein;
+        E2[i] = e2in;
+        const int hq = h - v_o1;               // stored instead of H: feeds E, F and the diagonal
+        Hq[i] = hq;
+        const int hq2 = h - v_o2;
+        Hq2[i] = hq2;
+        F = pmaxi(F - v_e1, hq);
+        F2 = pmaxi(F2 - v_e2, hq2);
+        d = d_next;
+    }
+}
+
+// junction combine of one cell's rows at a boundary column (values biased twice)
+template <int OFF, int N, int R>
+__device__ __forceinline__ int sweep_combine(const int (&Hq)[R], const int (&E)[R], const int (&E2)[R],
+                                             const int (&Hbo)[R], const int (&Ebo)[R],
+                                             const int (&E2bo)[R], int v_floor, int tS)
+{
+#pragma unroll
+    for (int n = 0; n < N; ++n) {
+        const int i = OFF + n;
+        const int t1 = pmaxi(Hq[i], v_floor) + Hbo[i];
+        const int t2 = E[i] + Ebo[i];
+        const int t3 = E2[i] + E2bo[i];
+        tS = pmaxi(pmaxi(tS, t1), pmaxi(t2, t3));
+    }
+    return tS;
+}
+
+template <int OFF, int N, int R>
+__device__ __forceinline__ void sweep_snapshot(const int (&Hq)[R], const int (&E)[R], const int (&E2)[R],
+                                               int row0, const NraDevRead& rda, const NraDevRead& rdb,
+                                               bool has_b, int o1, int16_t* __restrict__ snap_h,
+                                               int16_t* __restrict__ snap_e, int16_t* __restrict__ snap_e2)
+{
+#pragma unroll
+    for (int n = 0; n < N; ++n) {
+        const int i = OFF + n;
+        const int a = row0 + i;
+        if (a < rda.qlen) {
+            snap_h[rda.qoff + a] = (int16_t)(half_lo(Hq[i]) + o1 - BIAS);      // H itself
+            snap_e[rda.qoff + a] = (int16_t)(half_lo(E[i]) - BIAS);
+            snap_e2[rda.qoff + a] = (int16_t)(half_lo(E2[i]) - BIAS);
+        }
+        if (has_b && a < rdb.qlen) {
+            snap_h[rdb.qoff + a] = (int16_t)(half_hi(Hq[i]) + o1 - BIAS);
+            snap_e[rdb.qoff + a] = (int16_t)(half_hi(E[i]) - BIAS);
+            snap_e2[rdb.qoff + a] = (int16_t)(half_hi(E2[i]) - BIAS);
+        }
+    }
+}
+
 template <int R, bool HAS_N, int DIR>
 __global__ __launch_bounds__(WAVE) void k_sweep_pk16(int n_tasks, const NraSweepTask* __restrict__ tasks,
                                                      const NraDevRead* __restrict__ reads,
@@ -149,12 +222,20 @@ __global__ __launch_bounds__(WAVE) void k_sweep_pk16(int n_tasks, const NraSweep
     int Hq[R], Hq2[R], E[R], E2[R];
 #pragma unroll
     for (int i = 0; i < R; ++i) { Hq[i] = v_floor; Hq2[i] = NEG1; E[i] = NEG1; E2[i] = NEG1; }
-    int Hbot = v_floor, Fout = NEG1, F2out = NEG1, Hup_prev = v_floor, M = BIAS * P1;
-    int accS = NEG2, accB = NEG1;
-    int tt = tbl_mis4;                                    // padding column: everything mismatches
+
+    // Every lane hosts TWO virtual systolic cells -- A = its first RA rows, B = the other RB --
+    // one template column apart (cell v works on column t - v, lane l hosts cells 2l and 2l+1).
+    // A is fed by lane l-1's B through DPP, B by this lane's A from the previous step, so each
+    // step carries two independent dependency chains per wave: the sweeps run with only a few
+    // waves per SIMD and need the instruction-level parallelism.
+    constexpr int RA = (R + 1) / 2, RB = R - RA;
+    int HbotA = v_floor, FoutA = NEG1, F2outA = NEG1, HupA_prev = v_floor, MA = BIAS * P1;
+    int HbotB = v_floor, FoutB = NEG1, F2outB = NEG1, HupB_prev = v_floor, MB = BIAS * P1;
+    int accS_A = NEG2, accB_A = NEG1, accS_B = NEG2, accB_B = NEG1;
+    int ttA = tbl_mis4, ttB = tbl_mis4;                   // padding column: everything mismatches
     int kcur = tk.kmin;                                   // meaningful in lane 63 only
 
-    const int nchunks = (ncols + 63 + 63) >> 6;
+    const int nchunks = (ncols + 127 + 63) >> 6;          // 128 cells deep
     for (int c = 0; c < nchunks; ++c) {
         const int col = c * 64 + lane;
         int feed = tbl_mis4;
@@ -166,80 +247,64 @@ __global__ __launch_bounds__(WAVE) void k_sweep_pk16(int n_tasks, const NraSweep
         }
 #pragma unroll 2
         for (int s = 0; s < 64; ++s) {
-            int F = dpp_shr1(NEG1, Fout);
-            int F2 = dpp_shr1(NEG1, F2out);
-            tt = dpp_shr1(feed, tt);
+            // inputs of cell A: cell B of the lane above, as it stood after the previous step
+            const int hupA = dpp_shr1(v_floor, HbotB);
+            int FA = dpp_shr1(NEG1, FoutB);
+            int F2A = dpp_shr1(NEG1, F2outB);
+            const int ttA_new = dpp_shr1(feed, ttB);      // lane 0 takes the next template column
             feed = dpp_rol1(feed);
-            const int accS_in = dpp_shr1(NEG2, accS);
-            const int accB_in = dpp_shr1(NEG1, accB);
-            const int tbl = tt & 0x7f7f7f7f;
-            int d = pmaxi(Hup_prev, v_floor) + (int)__builtin_amdgcn_perm(tbl_hi, tbl, qc[0]);
-            Hup_prev = dpp_shr1(v_floor, Hbot);
-#pragma unroll
-            for (int i = 0; i < R; ++i) {
-                int d_next = d;
-                if (i + 1 < R)                     // uses H(i, j-1) before it is overwritten below
-                    d_next = pmaxi(Hq[i], v_floor) + (int)__builtin_amdgcn_perm(tbl_hi, tbl, qc[i + 1]);
-                const int ein = pmaxi(E[i] - v_e1, Hq[i]);        // E(i,j) from column j-1, lazily
-                const int e2in = pmaxi(E2[i] - v_e2, Hq2[i]);
-                const int h = pmaxi(pmaxi(d, ein), pmaxi(F, pmaxi(e2in, F2)));   // H(i,j)
-                M = pmaxi(M, h);
-                E[i] = ein;
-                E2[i] = e2in;
-                const int hq = h - v_o1;           // stored instead of H: feeds E, F and the diagonal
-                Hq[i] = hq;
-                const int hq2 = h - v_o2;
-                Hq2[i] = hq2;
-                F = pmaxi(F - v_e1, hq);
-                F2 = pmaxi(F2 - v_e2, hq2);
-                d = d_next;
-            }
-            Hbot = Hq[R - 1]; Fout = F; F2out = F2;
+            const int accS_Ain = dpp_shr1(NEG2, accS_B);
+            const int accB_Ain = dpp_shr1(NEG1, accB_B);
+            // inputs of cell B: this lane's cell A after the previous step
+            const int hupB = HbotA;
+            int FB = FoutA, F2B = F2outA;
+            const int ttB_new = ttA;
+            const int accS_Bin = accS_A, accB_Bin = accB_A;
 
-            const bool at_boundary = (tt & FLAG_BOUNDARY) != 0;
-            int tS = NEG2;
-            if (DIR) {
-                if (__builtin_amdgcn_ballot_w64(at_boundary) != 0) {
-#pragma unroll
-                    for (int i = 0; i < R; ++i) {
-                        const int t1 = pmaxi(Hq[i], v_floor) + Hbo[i];     // biased twice from here on
-                        const int t2 = E[i] + Ebo[i];
-                        const int t3 = E2[i] + E2bo[i];
-                        tS = pmaxi(pmaxi(tS, t1), pmaxi(t2, t3));
-                    }
+            sweep_cell<0, RA, R>(Hq, Hq2, E, E2, qc, HupA_prev, FA, F2A, MA, ttA_new & 0x7f7f7f7f, tbl_hi,
+                                 v_floor, v_e1, v_e2, v_o1, v_o2);
+            HupA_prev = hupA; HbotA = Hq[RA - 1]; FoutA = FA; F2outA = F2A;
+            if (RB > 0) {
+                sweep_cell<RA, RB, R>(Hq, Hq2, E, E2, qc, HupB_prev, FB, F2B, MB, ttB_new & 0x7f7f7f7f, tbl_hi,
+                                      v_floor, v_e1, v_e2, v_o1, v_o2);
+                HbotB = Hq[R - 1];
+            } else {
+                HbotB = hupB;                             // empty cell: hand everything through
+            }
+            HupB_prev = hupB; FoutB = FB; F2outB = F2B;
+            ttA = ttA_new; ttB = ttB_new;
+
+            const bool atA = (ttA & FLAG_BOUNDARY) != 0, atB = (ttB & FLAG_BOUNDARY) != 0;
+            int tSA = NEG2, tSB = NEG2;
+            if constexpr (DIR != 0) {
+                if (__builtin_amdgcn_ballot_w64(atA || atB) != 0) {
+                    tSA = sweep_combine<0, RA, R>(Hq, E, E2, Hbo, Ebo, E2bo, v_floor, tSA);
+                    tSB = sweep_combine<RA, RB, R>(Hq, E, E2, Hbo, Ebo, E2bo, v_floor, tSB);
                 }
             }
-            accS = pmaxi(accS_in, tS);
-            accB = pmaxi(accB_in, M);
+            accS_A = pmaxi(accS_Ain, tSA);
+            accB_A = pmaxi(accB_Ain, MA);
+            accS_B = pmaxi(accS_Bin, tSB);
+            accB_B = RB > 0 ? pmaxi(accB_Bin, MB) : accB_Bin;   // an empty cell adds nothing of its own
 
-            if (DIR == 0 && (tt & FLAG_SNAPSHOT)) {
-#pragma unroll
-                for (int i = 0; i < R; ++i) {
-                    const int a = lane * R + i;
-                    if (a < rda.qlen) {
-                        snap_h[rda.qoff + a] = (int16_t)(half_lo(Hq[i]) + o1 - BIAS);      // H itself
-                        snap_e[rda.qoff + a] = (int16_t)(half_lo(E[i]) - BIAS);
-                        snap_e2[rda.qoff + a] = (int16_t)(half_lo(E2[i]) - BIAS);
-                    }
-                    if (has_b && a < rdb.qlen) {
-                        snap_h[rdb.qoff + a] = (int16_t)(half_hi(Hq[i]) + o1 - BIAS);
-                        snap_e[rdb.qoff + a] = (int16_t)(half_hi(E[i]) - BIAS);
-                        snap_e2[rdb.qoff + a] = (int16_t)(half_hi(E2[i]) - BIAS);
-                    }
-                }
+            if (DIR == 0) {
+                if (ttA & FLAG_SNAPSHOT)
+                    sweep_snapshot<0, RA, R>(Hq, E, E2, lane * R, rda, rdb, has_b, o1, snap_h, snap_e, snap_e2);
+                if (ttB & FLAG_SNAPSHOT)
+                    sweep_snapshot<RA, RB, R>(Hq, E, E2, lane * R, rda, rdb, has_b, o1, snap_h, snap_e, snap_e2);
             }
-            if (lane == 63 && at_boundary) {
+            if (lane == 63 && atB) {                      // cell 127 has finished a boundary column
                 const int k = kcur++;
 #pragma unroll
                 for (int s2 = 0; s2 < 2; ++s2) {
                     const int lo_k = s2 ? kmin_b : kmin_a, hi_k = s2 ? kmax_b : kmax_a;
                     if ((s2 == 0 || has_b) && k >= lo_k && k <= hi_k) {
                         const uint32_t idx = (s2 ? coff_b : coff_a) + (uint32_t)(k - lo_k);
-                        const int B = (s2 ? half_hi(accB) : half_lo(accB)) - BIAS;
+                        const int B = (s2 ? half_hi(accB_B) : half_lo(accB_B)) - BIAS;
                         if (DIR == 0) {
                             arr_a[idx] = B;                       // running max of the reverse sweep = A_k
                         } else {
-                            const int S = (s2 ? half_hi(accS) : half_lo(accS)) - 2 * BIAS;
+                            const int S = (s2 ? half_hi(accS_B) : half_lo(accS_B)) - 2 * BIAS;
                             const int A = arr_a[idx];
                             const int best = imax(imax(S, B), A);
                             const int lo = sp.min_score > 1 ? sp.min_score : 1;
