@@ -43,6 +43,9 @@ def parse():
     ap.add_argument("--reads", type=int, default=10000, help="reads per GPU (config 2: 10000)")
     ap.add_argument("--brute", action="store_true",
                     help="score K independent alignments per read (k_score_pk16) instead of the decomposition")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL)")
+    ap.add_argument("--same-device", action="store_true",
+                    help="rehearsal only: every rank uses GPU 0 (with --backend gloo on a one-GPU box)")
     ap.add_argument("--cpu-sample", type=int, default=-1,
                     help="reads in the CPU-baseline sample (-1: sized for ~15 s, 0: skip)")
     return ap.parse_args()
@@ -108,11 +111,17 @@ def main():
 
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: no HIP device visible (there is no CPU path)")
+    if args.same_device:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dist = None
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        if args.backend == "nccl":
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend=args.backend)
+    gather_dev = torch.device("cuda", local_rank) if args.backend == "nccl" else torch.device("cpu")
 
     # every rank owns its own reads (weak scaling); rank 0's are BASELINE config 2 exactly
     data = synth.config2(n_reads=args.reads, seed=synth.SEED + rank)
@@ -131,7 +140,7 @@ def main():
         if dist is not None:
             out = batch.fetch(per_candidate=False)
             mine = torch.from_numpy(np.stack([out["sum_k"], out["n_ties"].astype(np.int64),
-                                              out["status"].astype(np.int64)], 1)).cuda()
+                                              out["status"].astype(np.int64)], 1)).to(gather_dev)
             gathered = [torch.empty_like(mine) for _ in range(world)]
             dist.all_gather(gathered, mine)
             return gathered
@@ -146,7 +155,7 @@ def main():
     barrier()
     dt = time.perf_counter() - t0
     if dist is not None:
-        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        t = torch.tensor([dt], dtype=torch.float64, device=gather_dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
 

@@ -69,14 +69,20 @@ __global__ __launch_bounds__(WAVE) void k_score_pk16(int n_tasks, const NraPairT
         qc[i] = c | (c << 16);
     }
 
-    const s16x2 NEGP = splat(-16384);
-    const s16x2 ZERO = splat(0);
+    // Registers hold (value + 8192) in both halves: subtracting a gap constant is then carry-safe
+    // as one full-rate 32-bit v_sub_u32 (2 cycles per wave) instead of a half-rate v_pk_sub_i16
+    // (4 cycles); maxima and the signed substitution add stay packed.
+    constexpr int KB = 8192;
+    const s16x2 NEGP = splat(1024);          // biased "minus infinity" (-7168): below any real state
+    const s16x2 ZERO = splat(KB);
     const s16x2 v_match = splat(sp.match);
     const s16x2 v_negab = splat(-(sp.match + sp.mismatch));
-    const s16x2 v_open1 = splat(sp.open1), v_ext1 = splat(sp.ext1);
-    const s16x2 v_open2 = splat(sp.open2), v_ext2 = splat(sp.ext2);
+    const int P1 = 0x00010001;
+    const int v_open1 = sp.open1 * P1, v_ext1 = sp.ext1 * P1;
+    const int v_open2 = sp.open2 * P1, v_ext2 = sp.ext2 * P1;
     const s16x2 v_negambi = splat(-sp.ambi);
     const s16x2 v_negb = splat(-sp.mismatch);
+#define SUB32(a, b) as_s(as_i(a) - (b))
 
     s16x2 Hprev[R], E[R], E2[R];
 #pragma unroll
@@ -109,7 +115,7 @@ __global__ __launch_bounds__(WAVE) void k_score_pk16(int n_tasks, const NraPairT
             s16x2 sc;
             NRA_SUBST(0, sc);
             s16x2 d = pmax(Hup_prev, ZERO) + sc;   // diagonal of my first row came in one step ago
-            Hup_prev = as_s(dpp_shr1(0, as_i(Hbot)));
+            Hup_prev = as_s(dpp_shr1(as_i(ZERO), as_i(Hbot)));
             s16x2 h = ZERO;
 #pragma unroll
             for (int i = 0; i < R; ++i) {
@@ -121,24 +127,25 @@ __global__ __launch_bounds__(WAVE) void k_score_pk16(int n_tasks, const NraPairT
                 h = pmax(pmax(d, E[i]), pmax(F, pmax(E2[i], F2)));
                 M = pmax(M, h);
                 Hprev[i] = h;
-                const s16x2 hq = h - v_open1;
-                E[i] = pmax(E[i] - v_ext1, hq);
-                F = pmax(F - v_ext1, hq);
-                const s16x2 hq2 = h - v_open2;
-                E2[i] = pmax(E2[i] - v_ext2, hq2);
-                F2 = pmax(F2 - v_ext2, hq2);
+                const s16x2 hq = SUB32(h, v_open1);
+                E[i] = pmax(SUB32(E[i], v_ext1), hq);
+                F = pmax(SUB32(F, v_ext1), hq);
+                const s16x2 hq2 = SUB32(h, v_open2);
+                E2[i] = pmax(SUB32(E2[i], v_ext2), hq2);
+                F2 = pmax(SUB32(F2, v_ext2), hq2);
                 d = d_next;
             }
 #undef NRA_SUBST
             Hbot = h; Fout = F; F2out = F2;
         }
     }
+#undef SUB32
     // wave-wide max of both halves
     int m = as_i(M);
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) m = as_i(pmax(as_s(m), as_s(__shfl_xor(m, off, WAVE))));
     if (lane == 0) {
-        const int sa = (short)(m & 0xffff), sb = (short)(m >> 16);
+        const int sa = (m & 0xffff) - KB, sb = ((m >> 16) & 0xffff) - KB;
         const int lo = sp.min_score > 1 ? sp.min_score : 1;
         out_score[tk.out_a] = sa >= lo ? sa : -1;
         if (has_b) out_score[tk.out_b] = sb >= lo ? sb : -1;

@@ -349,3 +349,60 @@ def test_1d_decomposition_adversarial(capi, oracle):
             kmin.append(max(0, k - 6)); kmax.append(k + 6 + j)
     _modes_agree(capi, oracle, dict(regions=regions, reads=rds, kmin=kmin, kmax=kmax, read_region=rr),
                  sc_over=dict(min_dp_score=30))
+
+
+# ------------------------------------------------------------------ the other BASELINE configs (reduced)
+def test_config5_wide_sweep_sample(capi, oracle):
+    """Config 5 shape: HiFi error model, k in [5,500] (496 candidates), 2.3 kb cores (R = 40)."""
+    d = synth.config5(n_reads=6, seed=55)
+    g = capi.round3_1d(d["regions"], d["reads"], d["kmin"], d["kmax"])
+    o = oracle.round3_1d(d["regions"], d["reads"], d["kmin"], d["kmax"])
+    for k in KEYS_1D:
+        assert np.array_equal(g[k], o[k]), k
+    assert (g["status"] == 0).all()
+    assert np.array_equal(g["sum_k"] // g["n_ties"], d["k_true"])
+    gb = capi.round3_1d(d["regions"], d["reads"][:2], d["kmin"][:2], d["kmax"][:2], flags=capi.F_BRUTE_FORCE)
+    for k in KEYS_1D:
+        assert np.array_equal(gb[k][:2 if "cand" not in k else 2 * 496], o[k][:2 if "cand" not in k else 2 * 496]), k
+
+
+def test_config4_many_regions_sample(capi, oracle):
+    """Config 4 shape: many regions, mixed 3-6 bp motifs, the reference's window rule."""
+    d = synth.config4(n_regions=12, reads_per_region=25, seed=44)
+    g = capi.round3_1d(d["regions"], d["reads"], d["kmin"], d["kmax"], read_region=d["read_region"])
+    o = oracle.round3_1d(d["regions"], d["reads"], d["kmin"], d["kmax"], read_region=d["read_region"])
+    for k in KEYS_1D:
+        assert np.array_equal(g[k], o[k]), k
+    ok = g["status"] == 0
+    assert ok.mean() > 0.95
+    # the same reads shuffled across the batch give the same per-read answers
+    perm = np.random.default_rng(4).permutation(len(d["reads"]))
+    gp = capi.round3_1d(d["regions"], [d["reads"][i] for i in perm], d["kmin"][perm], d["kmax"][perm],
+                        read_region=d["read_region"][perm], per_candidate=False)
+    for k in ("best_score", "sum_k", "n_ties", "status"):
+        assert np.array_equal(gp[k], g[k][perm]), k
+
+
+def test_config3_joint_sample(capi, oracle):
+    """Config 3 shape: HTT-like CAG+CCG joint grid through the host mirror (both rounds)."""
+    j = synth.make_joint(6, seed=33)                  # alleles (17,10) / (55,7), 1.2 kb amplicon reads
+    init = J.Round1Estimation()
+    fq = {}
+    for i, s in enumerate(j["reads"]):
+        init.repeat1_count_range_dict[f"r{i}"] = tuple(int(x) for x in j["range1"][i])
+        init.repeat2_count_range_dict[f"r{i}"] = tuple(int(x) for x in j["range2"][i])
+        fq[f"r{i}"] = f"@r{i}\n{s}\n+\n{'!' * len(s)}\n"
+    left, u1, mid, u2, right = j["region"]
+    chrom = left + u1 * 19 + mid + u2 * 7 + right
+    a = J.Repeat().init_from_string(f"chr4:{len(left)}:{len(left) + 57}:{u1}:200")
+    b = J.Repeat().init_from_string(f"chr4:{len(left) + 57 + len(mid)}:{len(left) + 57 + len(mid) + 21}:{u2}:20")
+    a.max_size += 10; b.max_size += 10
+    import copy
+    res = {}
+    for name, scorer in (("gpu", None), ("oracle", oracle.joint_2d)):
+        fin = J.fine_tune_read_count(init, fq, chrom, copy.deepcopy(a), copy.deepcopy(b), scorer=scorer)
+        res[name] = ({k: float(v) for k, v in fin.repeat1_count_dict.items()},
+                     {k: float(v) for k, v in fin.repeat2_count_dict.items()}, fin.step_size1, fin.step_size2)
+    assert res["gpu"] == res["oracle"]
+    k1 = np.array([res["gpu"][0][f"r{i}"] for i in range(6)]); k2 = np.array([res["gpu"][1][f"r{i}"] for i in range(6)])
+    assert np.mean(np.abs(k1 - j["truth"][:, 0]) <= 1) >= 0.8 and np.mean(np.abs(k2 - j["truth"][:, 1]) <= 1) >= 0.8
