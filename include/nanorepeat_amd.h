@@ -175,6 +175,22 @@ int nra_joint_2d(int device,
                  int32_t* best_wscore, int64_t* sum_k1, int64_t* sum_k2,
                  int32_t* n_ties, uint8_t* status);
 
+/* ---- generic batched local alignment: the DP engine of the path, exposed for the rows
+ *      around it: anchor finding nanoRepeat_bam.py:260-286 (anchors vs
+ *      reads, pymm2.main at :281) and the round-2 estimate :334-393 (cores vs left + unit*T,
+ *      pymm2.main at :362), each of which is one aligner call over many reads in the reference.
+ *
+ * n_seqs sequences concatenated in `seqs` (offsets seq_off[n_seqs+1]); n_pairs pairs
+ * (pair_query[i], pair_target[i]) of sequence indices.  A sequence used as a query holds at
+ * most 3072 bases, as a target at most 65000.  Outputs per pair: score (AS; -1 when below
+ * min_dp_score), tstart, tend (target coordinates, 0-based half-open; oracle tie-breaks:
+ * largest tstart, then smallest tend; -1 when no record). */
+int nra_align_pairs(int device,
+                    int32_t n_seqs, const char* seqs, const int64_t* seq_off,
+                    int64_t n_pairs, const int32_t* pair_query, const int32_t* pair_target,
+                    const nra_scoring_t* sc, int32_t flags,
+                    int32_t* score, int32_t* tstart, int32_t* tend);
+
 /* ---- device-resident batches (what bench.py times): create = encode + H2D,
  *      run = kernels only (asynchronous on the batch's own stream), fetch = D2H ------- */
 int  nra_batch1d_create(int device,

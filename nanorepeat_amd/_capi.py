@@ -19,7 +19,7 @@ F_BRUTE_FORCE = 4     # K independent alignments per read instead of the junctio
 
 # every symbol include/nanorepeat_amd.h declares
 EXPORTS = ("nra_abi_version", "nra_version", "nra_last_error", "nra_device_count",
-           "nra_default_scoring", "nra_round3_1d", "nra_joint_2d", "nra_batch1d_create",
+           "nra_default_scoring", "nra_round3_1d", "nra_joint_2d", "nra_align_pairs", "nra_batch1d_create",
            "nra_batch2d_create", "nra_batch_run", "nra_batch_sync", "nra_batch_stats",
            "nra_batch1d_fetch", "nra_batch2d_fetch", "nra_batch_destroy")
 
@@ -88,6 +88,9 @@ def load():
     lib.nra_joint_2d.argtypes = [C.c_int, C.POINTER(JointRegion), C.c_int32, C.c_char_p, pi64, pi8,
                                  C.c_int64, pi32, pi32, pi32, C.POINTER(Scoring), C.c_int32,
                                  pi32, pi32, pi32, pi64, pi64, pi32, p8]
+    lib.nra_align_pairs.restype = C.c_int
+    lib.nra_align_pairs.argtypes = [C.c_int, C.c_int32, C.c_char_p, pi64, C.c_int64, pi32, pi32,
+                                    C.POINTER(Scoring), C.c_int32, pi32, pi32, pi32]
     lib.nra_batch1d_create.restype = C.c_int
     lib.nra_batch1d_create.argtypes = [C.c_int, C.POINTER(Region), C.c_int32, C.c_int32, C.c_char_p,
                                        pi64, pi32, pi32, pi32, C.POINTER(Scoring), C.c_int32,
@@ -218,6 +221,22 @@ def joint_2d(region, reads, cell_read, cell_k1, cell_k2, read_strand=None, sc=No
                             _ptr(out["best_wscore"], C.c_int32), _ptr(out["sum_k1"], C.c_int64),
                             _ptr(out["sum_k2"], C.c_int64), _ptr(out["n_ties"], C.c_int32),
                             _ptr(out["status"], C.c_uint8)))
+    return out
+
+
+def align_pairs(seqs, pair_query, pair_target, sc=None, flags=0, device=0):
+    """nra_align_pairs: optimal local alignment of seqs[pair_query[i]] (query) against
+    seqs[pair_target[i]] (target) -> dict(score, tstart, tend) in target coordinates."""
+    lib = load()
+    sc = sc or default_scoring()
+    data, off = pack_reads(seqs)
+    pq = np.ascontiguousarray(pair_query, np.int32)
+    pt = np.ascontiguousarray(pair_target, np.int32)
+    n = len(pq)
+    out = dict(score=np.zeros(n, np.int32), tstart=np.zeros(n, np.int32), tend=np.zeros(n, np.int32))
+    _check(lib.nra_align_pairs(device, len(seqs), data, _ptr(off, C.c_int64), n, _ptr(pq, C.c_int32),
+                               _ptr(pt, C.c_int32), C.byref(sc), flags, _ptr(out["score"], C.c_int32),
+                               _ptr(out["tstart"], C.c_int32), _ptr(out["tend"], C.c_int32)))
     return out
 
 

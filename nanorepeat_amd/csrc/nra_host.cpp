@@ -862,6 +862,112 @@ int nra_joint_2d(int device, const nra_joint_region_t* region, int32_t n_reads, 
     return rc;
 }
 
+// ---- generic pairs --------------------------------------------------------------------
+int nra_align_pairs(int device, int32_t n_seqs, const char* seqs, const int64_t* seq_off, int64_t n_pairs,
+                    const int32_t* pair_query, const int32_t* pair_target, const nra_scoring_t* sc,
+                    int32_t flags, int32_t* score, int32_t* tstart, int32_t* tend)
+{
+    (void)flags;
+    if (n_seqs < 0 || n_pairs < 0) return fail(NRA_E_ARG, "negative count");
+    if (n_seqs > 0 && (!seqs || !seq_off)) return fail(NRA_E_ARG, "NULL sequence array");
+    if (n_pairs > 0 && (!pair_query || !pair_target || !score || !tstart || !tend)) return fail(NRA_E_ARG, "NULL pair array");
+    if (n_pairs > 0x7ff00000ll) return fail(NRA_E_RANGE, "too many pairs");
+    if (!scoring_ok(sc)) return fail(NRA_E_ARG, "scoring parameters out of range");
+    if (n_pairs == 0) return NRA_OK;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
+        return fail(NRA_E_DEVICE, "no HIP device: nanorepeat_amd has no CPU path");
+    if (device < 0 || device >= ndev) return fail(NRA_E_ARG, "device index out of range");
+    HIP_TRY(hipSetDevice(device));
+
+    // which sequences are queries (2-bit pool, <= 3072 bases) / targets (byte pool, <= 65000)
+    std::vector<int32_t> as_query((size_t)n_seqs, -1), as_target((size_t)n_seqs, -1);
+    for (int64_t i = 0; i < n_pairs; ++i) {
+        const int32_t q = pair_query[i], t = pair_target[i];
+        if (q < 0 || q >= n_seqs || t < 0 || t >= n_seqs) return fail(NRA_E_ARG, "pair index out of range");
+        as_query[q] = 0; as_target[t] = 0;
+    }
+    std::vector<uint8_t> pool;
+    std::vector<NraDevRegion> dregs;
+    std::vector<NraDevRead> dreads;
+    std::vector<uint32_t> q2bit, nmask;
+    bool has_n = false;
+    uint64_t base = 0;
+    for (int32_t s = 0; s < n_seqs; ++s) {
+        const int64_t len = seq_off[s + 1] - seq_off[s];
+        if (len < 0) return fail(NRA_E_ARG, "seq_off must be non-decreasing");
+        if (as_target[s] == 0) {
+            if (len > NRA_MAX_TLEN) return fail(NRA_E_RANGE, "target longer than " + std::to_string(NRA_MAX_TLEN));
+            NraDevRegion d{};
+            d.p1_off = pool_append(pool, seqs + seq_off[s], (int32_t)len, nullptr, 0, 0, has_n);
+            d.p2_off = d.p3_off = d.pr_off = (uint32_t)pool.size();
+            d.l1 = (int32_t)len; d.m1 = 0; d.l2 = 0; d.m2 = 0; d.l3 = 0;
+            as_target[s] = (int32_t)dregs.size();
+            dregs.push_back(d);
+            if (pool.size() > 0xfff00000ull) return fail(NRA_E_RANGE, "target pool exceeds 4 GB");
+        }
+        if (as_query[s] == 0) {
+            if (len > NRA_MAX_QLEN) return fail(NRA_E_RANGE, "query longer than " + std::to_string(NRA_MAX_QLEN));
+            NraDevRead r{};
+            r.qoff = (uint32_t)base; r.qlen = (int32_t)len; r.region = 0; r.rc = 0;
+            as_query[s] = (int32_t)dreads.size();
+            dreads.push_back(r);
+            base += ((uint64_t)len + 31) / 32 * 32;
+            if (base > 0xfff00000ull) return fail(NRA_E_RANGE, "query pool exceeds 4G bases");
+        }
+    }
+    pool.push_back(0);
+    q2bit.assign((size_t)(base / 16) + 1, 0);
+    nmask.assign((size_t)(base / 32) + 1, 0);
+    for (int32_t s = 0; s < n_seqs; ++s) {
+        if (as_query[s] < 0) continue;
+        const NraDevRead& r = dreads[as_query[s]];
+        const char* p = seqs + seq_off[s];
+        for (int32_t i = 0; i < r.qlen; ++i) {
+            uint8_t c = encode_base(p[i]);
+            const uint32_t b = r.qoff + (uint32_t)i;
+            if (c >= 4) { nmask[b >> 5] |= 1u << (b & 31); has_n = true; c = 0; }
+            q2bit[b >> 4] |= (uint32_t)c << ((b & 15) * 2);
+        }
+    }
+    // tasks by rows-per-lane bucket of the query
+    std::vector<std::vector<NraTask>> by_bucket((size_t)kNumR);
+    for (int64_t i = 0; i < n_pairs; ++i) {
+        const int32_t qi = as_query[pair_query[i]];
+        if (dreads[qi].qlen == 0) continue;
+        by_bucket[rows_for_qlen(dreads[qi].qlen)].push_back(NraTask{qi, as_target[pair_target[i]], -1, (int32_t)i});
+    }
+    std::vector<NraTask> tasks;
+    std::vector<int32_t> counts;
+    std::vector<std::pair<int, size_t>> launches;     // (R, offset)
+    for (int bi = kNumR - 1; bi >= 0; --bi) {
+        if (by_bucket[bi].empty()) continue;
+        launches.push_back({kRList[bi], tasks.size()});
+        counts.push_back((int32_t)by_bucket[bi].size());
+        tasks.insert(tasks.end(), by_bucket[bi].begin(), by_bucket[bi].end());
+    }
+    DevBuf<uint8_t> d_pool; DevBuf<uint32_t> d_q2, d_nm; DevBuf<NraDevRegion> d_regs; DevBuf<NraDevRead> d_reads;
+    DevBuf<NraTask> d_tasks; DevBuf<int32_t> d_counts, d_score, d_ts, d_te;
+    HIP_TRY(d_pool.upload(pool)); HIP_TRY(d_q2.upload(q2bit)); HIP_TRY(d_nm.upload(nmask));
+    HIP_TRY(d_regs.upload(dregs)); HIP_TRY(d_reads.upload(dreads)); HIP_TRY(d_tasks.upload(tasks));
+    HIP_TRY(d_counts.upload(counts));
+    HIP_TRY(d_score.alloc((size_t)n_pairs)); HIP_TRY(d_ts.alloc((size_t)n_pairs)); HIP_TRY(d_te.alloc((size_t)n_pairs));
+    HIP_TRY(hipMemset(d_score.p, 0xff, (size_t)n_pairs * 4));
+    HIP_TRY(hipMemset(d_ts.p, 0xff, (size_t)n_pairs * 4));
+    HIP_TRY(hipMemset(d_te.p, 0xff, (size_t)n_pairs * 4));
+    const NraScoreParams sp = to_params(*sc);
+    for (size_t i = 0; i < launches.size(); ++i) {
+        LAUNCH_TRY(nra_launch_payload_origin(launches[i].first, has_n ? 1 : 0, nullptr, std::min(counts[i], 256 * 16),
+                                             d_tasks.p + launches[i].second, d_counts.p + i, d_reads.p, d_regs.p,
+                                             d_pool.p, d_q2.p, d_nm.p, sp, d_score.p, d_ts.p, d_te.p));
+    }
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipMemcpy(score, d_score.p, (size_t)n_pairs * 4, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(tstart, d_ts.p, (size_t)n_pairs * 4, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(tend, d_te.p, (size_t)n_pairs * 4, hipMemcpyDeviceToHost));
+    return NRA_OK;
+}
+
 // ---- common -------------------------------------------------------------------------
 int nra_batch_run(nra_batch_t* b)
 {

@@ -181,8 +181,10 @@ __global__ __launch_bounds__(WAVE) void k_payload_i32(const NraTask* __restrict_
     for (int task = blockIdx.x; task < n_tasks; task += gridDim.x) {
         const NraTask tk = tasks[task];
         const NraDevRead rd = reads[tk.read];
-        const NraDevRegion rg = regions[rd.region];
-        const Tmpl tm = make_tmpl(rg, pool, tk.k1, tk.k2, 0);
+        // k2 < 0 marks a free (query, target) pair of nra_align_pairs: k1 is the target's region
+        const bool pair = tk.k2 < 0;
+        const NraDevRegion rg = regions[pair ? tk.k1 : rd.region];
+        const Tmpl tm = make_tmpl(rg, pool, pair ? 0 : tk.k1, pair ? 0 : tk.k2, 0);
         const int ncols = tm.tlen;
         // window of nanoRepeat_joint.py:445-448 (WINDOW mode only)
         const int wa = imax(0, rg.l1 - 10);

@@ -1,0 +1,154 @@
+"""Rows upstream of the hot path: anchor finding, core trimming and the
+round-1 / round-2 estimates that produce the path's inputs (core sequence, k window).
+
+Mirrors nanoRepeat_bam.py:165-393 with the reference's names.  The two aligner calls --
+anchors vs region reads (`pymm2.main` at :281) and cores vs `left + unit*T` (:362) -- become
+one `nra_align_pairs` call each (the same DP engine as the path).  Differences from a
+minimap2 run, all consequences of scoring an optimal DP instead of a heuristic mapper:
+at most one record per (read, anchor, strand) -- no secondary hits -- and no mapping
+quality, so `check_anchor_mapping`'s `mapq > 30` is taken as satisfied (mapq = 60).
+"""
+import numpy as np
+
+from . import _capi
+from .round3 import Read
+
+_COMP = str.maketrans("ACGTNacgtn", "TGCANtgcan")
+
+
+def rev_comp(seq):
+    """tk.rev_comp (tk.py:346-357); N maps to N here (the reference raises KeyError, D3)."""
+    return seq[::-1].translate(_COMP)
+
+
+class AnchorHit:
+    """The PAF fields find_anchor_locations_for1read reads (paf.py:32-79), with qstart/qend
+    already on the read's own strand for '-' records, as PAF.__init__ leaves them (:70-74)."""
+
+    def __init__(self, qname, qlen, qstart, qend, strand, tname, align_score, align_len, mapq=60):
+        self.qname, self.qlen, self.qstart, self.qend = qname, qlen, qstart, qend
+        self.strand, self.tname = strand, tname
+        self.align_score, self.align_len, self.mapq = align_score, align_len, mapq
+
+
+def check_anchor_mapping(one_read_anchor_paf_list):
+    """nanoRepeat_bam.py:165-179."""
+    if len(one_read_anchor_paf_list) == 0:
+        return False
+    if len(one_read_anchor_paf_list) == 1:
+        return True
+    if one_read_anchor_paf_list[0].align_len < 10:
+        return False
+    return (one_read_anchor_paf_list[0].align_score > 1.5 * one_read_anchor_paf_list[1].align_score
+            and one_read_anchor_paf_list[0].mapq > 30)
+
+
+def find_anchor_locations_for1read(read_paf_list, repeat_region):
+    """nanoRepeat_bam.py:181-236: accept a read when both anchors map uniquely, derive the core
+    (anchors' inner edges +- 100 bp) and middle coordinates, all on the read's own strand."""
+    if len(read_paf_list) == 0:
+        return
+    left = sorted((p for p in read_paf_list if p.tname.startswith("left_anchor")),
+                  key=lambda p: p.align_score, reverse=True)
+    right = sorted((p for p in read_paf_list if p.tname.startswith("right_anchor")),
+                   key=lambda p: p.align_score, reverse=True)
+    read = Read()
+    read.read_name = read_paf_list[0].qname
+    read.full_read_len = read_paf_list[0].qlen
+    read.both_anchors_are_good = False
+    read.left_anchor_is_good = check_anchor_mapping(left)
+    read.right_anchor_is_good = check_anchor_mapping(right)
+    if not read.left_anchor_is_good or not read.right_anchor_is_good:
+        return
+    repeat_region_length = 0
+    read.left_anchor_paf, read.right_anchor_paf = left[0], right[0]
+    if left[0].strand == right[0].strand:
+        repeat_region_length = right[0].qstart - left[0].qend
+    if repeat_region_length > -10:                       # :210 (also true when the strands differ, as upstream)
+        read.both_anchors_are_good = True
+        read.dist_between_anchors = repeat_region_length
+    if not read.both_anchors_are_good:
+        return
+    repeat_region.read_dict[read.read_name] = read
+    repeat_region.buffer_len = 100
+    read.core_seq_start_pos = max(0, left[0].qend - repeat_region.buffer_len)
+    read.core_seq_end_pos = min(read.full_read_len, right[0].qstart + repeat_region.buffer_len)
+    read.mid_seq_start_pos = left[0].qend
+    read.mid_seq_end_pos = right[0].qstart
+    read.left_buffer_len = left[0].qend - read.core_seq_start_pos
+    read.right_buffer_len = read.core_seq_end_pos - right[0].qstart
+    read.strand = "+" if left[0].strand == "+" else "-"
+
+
+def find_anchor_locations_in_reads(data_type, repeat_region, num_cpu=1, region_reads=None, device=0,
+                                   scoring=None, aligner=None):
+    """nanoRepeat_bam.py:260-286.  `region_reads` = {read_name: sequence} in file order (the
+    reference reads them from region_fq_file)."""
+    aligner = aligner or _capi.align_pairs
+    region_reads = region_reads if region_reads is not None else repeat_region.region_reads
+    names = list(region_reads)
+    if not names:
+        return
+    # sequences: 0 = left anchor, 1 = right anchor, then read i forward at 2+2i, reverse at 3+2i.
+    # The anchor is the DP's query (<= 3072 rows), the read its target (columns), so the extents
+    # come back in read coordinates -- what the reference takes from the PAF's query columns.
+    seqs = [repeat_region.left_anchor_seq, repeat_region.right_anchor_seq]
+    pq, pt = [], []
+    for i, n in enumerate(names):
+        s = region_reads[n].strip()
+        seqs += [s, rev_comp(s)]
+        for a in (0, 1):
+            for o in (0, 1):
+                pq.append(a); pt.append(2 + 2 * i + o)
+    out = aligner(seqs, np.array(pq, np.int32), np.array(pt, np.int32), sc=scoring, device=device)
+    for i, n in enumerate(names):
+        recs = []
+        qlen = len(region_reads[n].strip())
+        for a, tname in ((0, "left_anchor"), (1, "right_anchor")):
+            for o, strand in ((0, "+"), (1, "-")):
+                j = 4 * i + 2 * a + o
+                if out["score"][j] < 0:
+                    continue
+                ts, te = int(out["tstart"][j]), int(out["tend"][j])
+                recs.append(AnchorHit(n, qlen, ts, te, strand, tname, int(out["score"][j]), te - ts))
+        find_anchor_locations_for1read(recs, repeat_region)
+
+
+def make_core_seq(repeat_region, region_reads=None):
+    """nanoRepeat_bam.py:288-331 without the FASTQ files: fills read_core_seq_dict."""
+    region_reads = region_reads if region_reads is not None else repeat_region.region_reads
+    for read_name, seq in region_reads.items():
+        if read_name not in repeat_region.read_dict:
+            continue
+        read = repeat_region.read_dict[read_name]
+        read_sequence = seq.strip()
+        if read.strand == "-":
+            read_sequence = rev_comp(read_sequence)
+        repeat_region.read_core_seq_dict[read_name] = read_sequence[read.core_seq_start_pos:read.core_seq_end_pos]
+
+
+def round1_and_round2_estimation(data_type, repeat_region, num_cpu=1, device=0, scoring=None, aligner=None):
+    """nanoRepeat_bam.py:334-393: round 1 = anchor distance / unit length; round 2 = where the core's
+    alignment against left + unit*T ends."""
+    if len(repeat_region.read_dict) == 0:
+        return
+    aligner = aligner or _capi.align_pairs
+    unit = repeat_region.repeat_unit_seq
+    round1 = []
+    for read in repeat_region.read_dict.values():
+        read.round1_repeat_size = float(read.dist_between_anchors) / len(unit)
+        round1.append(read.round1_repeat_size)
+    template_repeat_size = int(max(round1) * 1.5) + 1
+    if template_repeat_size < max(round1) + 10:
+        template_repeat_size = int(max(round1) + 10)
+    left = repeat_region.left_anchor_seq
+    names = [n for n in repeat_region.read_dict if n in repeat_region.read_core_seq_dict]
+    seqs = [left + unit * template_repeat_size] + [repeat_region.read_core_seq_dict[n] for n in names]
+    out = aligner(seqs, np.arange(1, len(seqs), dtype=np.int32), np.zeros(len(names), np.int32),
+                  sc=scoring, device=device)
+    for i, n in enumerate(names):
+        if out["score"][i] < 0:
+            continue
+        ts, te = int(out["tstart"][i]), int(out["tend"][i])
+        if ts <= len(left) and te >= len(left):                              # :371
+            repeat_region.read_dict[n].round2_repeat_size = float(te - len(left)) / len(unit)

@@ -469,6 +469,35 @@ int nro_round3_1d(const nro_region_t* regions, int32_t n_regions,
     return bad ? -1 : 0;
 }
 
+/* ---- generic pairs (anchor finding nanoRepeat_bam.py:281, round 2 :362) ------------ */
+int nro_align_pairs(int32_t n_seqs, const char* seqs, const int64_t* seq_off,
+                    int64_t n_pairs, const int32_t* pair_query, const int32_t* pair_target,
+                    const nro_scoring_t* sc, int32_t flags,
+                    int32_t* score, int32_t* tstart, int32_t* tend)
+{
+    (void)flags;
+    if (n_seqs < 0 || n_pairs < 0 || !check_scoring(sc)) return -1;
+    if (n_pairs > 0 && (!seqs || !seq_off || !pair_query || !pair_target || !score || !tstart || !tend)) return -1;
+    for (int64_t i = 0; i < n_pairs; ++i)
+        if (pair_query[i] < 0 || pair_query[i] >= n_seqs || pair_target[i] < 0 || pair_target[i] >= n_seqs) return -1;
+    uint8_t* codes = (uint8_t*)malloc((size_t)seq_off[n_seqs] + 1);
+    nro_encode(seqs, seq_off[n_seqs], codes);
+#ifdef _OPENMP
+#pragma omp parallel for schedule(dynamic, 1) num_threads(nro_get_threads())
+#endif
+    for (int64_t i = 0; i < n_pairs; ++i) {
+        const int32_t q = pair_query[i], t = pair_target[i];
+        int32_t ts = 0, te = 0;
+        int32_t s = nro_align(codes + seq_off[q], (int32_t)(seq_off[q + 1] - seq_off[q]),
+                              codes + seq_off[t], (int32_t)(seq_off[t + 1] - seq_off[t]),
+                              sc, NRO_MODE_ORIGIN, 0, 0, &ts, &te);
+        if (s < sc->min_dp_score || s <= 0) { score[i] = -1; tstart[i] = -1; tend[i] = -1; }
+        else { score[i] = s; tstart[i] = ts; tend[i] = te; }
+    }
+    free(codes);
+    return 0;
+}
+
 /* ---- 2D ------------------------------------------------------------------------- */
 static int32_t build_joint_template(uint8_t* tgt, const uint8_t* L, int32_t ll,
                                     const uint8_t* U1, int32_t m1, int32_t k1,

@@ -85,6 +85,12 @@ int nro_round3_1d(const nro_region_t* regions, int32_t n_regions,
                   int32_t* best_score, int64_t* sum_k, int32_t* n_ties, uint8_t* status,
                   int32_t* cand_score, int32_t* cand_tstart, int32_t* cand_tend);
 
+/* Mirrors nra_align_pairs. */
+int nro_align_pairs(int32_t n_seqs, const char* seqs, const int64_t* seq_off,
+                    int64_t n_pairs, const int32_t* pair_query, const int32_t* pair_target,
+                    const nro_scoring_t* sc, int32_t flags,
+                    int32_t* score, int32_t* tstart, int32_t* tend);
+
 /* Mirrors nra_joint_2d. */
 int nro_joint_2d(const nro_joint_region_t* region,
                  int32_t n_reads, const char* seqs, const int64_t* seq_off,

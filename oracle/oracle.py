@@ -75,6 +75,9 @@ def load():
     lib.nro_round3_1d.argtypes = [C.POINTER(Region), C.c_int32, C.c_int32, C.c_char_p, pi64, pi32,
                                   pi32, pi32, C.POINTER(Scoring), C.c_int32,
                                   pi32, pi64, pi32, p8, pi32, pi32, pi32]
+    lib.nro_align_pairs.restype = C.c_int
+    lib.nro_align_pairs.argtypes = [C.c_int32, C.c_char_p, pi64, C.c_int64, pi32, pi32,
+                                    C.POINTER(Scoring), C.c_int32, pi32, pi32, pi32]
     lib.nro_joint_2d.restype = C.c_int
     lib.nro_joint_2d.argtypes = [C.POINTER(JointRegion), C.c_int32, C.c_char_p, pi64,
                                  C.POINTER(C.c_int8), C.c_int64, pi32, pi32, pi32,
@@ -190,6 +193,25 @@ def round3_1d(regions, reads, kmin, kmax, read_region=None, sc=None, flags=0, th
                            _ptr(out["cand_tend"], C.c_int32))
     if rc != 0:
         raise ValueError("nro_round3_1d: bad argument")
+    return out
+
+
+def align_pairs(seqs, pair_query, pair_target, sc=None, flags=0, threads=None, **_ignored):
+    """Oracle twin of nra_align_pairs."""
+    lib = load()
+    if threads is not None:
+        lib.nro_set_threads(int(threads))
+    sc = _scoring(sc)
+    data, off = _pack_reads(seqs)
+    pq = np.ascontiguousarray(pair_query, np.int32)
+    pt = np.ascontiguousarray(pair_target, np.int32)
+    n = len(pq)
+    out = dict(score=np.zeros(n, np.int32), tstart=np.zeros(n, np.int32), tend=np.zeros(n, np.int32))
+    rc = lib.nro_align_pairs(len(seqs), data, _ptr(off, C.c_int64), n, _ptr(pq, C.c_int32),
+                             _ptr(pt, C.c_int32), C.byref(sc), flags, _ptr(out["score"], C.c_int32),
+                             _ptr(out["tstart"], C.c_int32), _ptr(out["tend"], C.c_int32))
+    if rc != 0:
+        raise ValueError("nro_align_pairs: bad argument")
     return out
 
 

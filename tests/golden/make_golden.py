@@ -467,14 +467,117 @@ def gen_2d(tmp):
     return fx
 
 
+# --------------------------------------------------------------------------- upstream rows (8f-1)
+def anchor_aligner(min_score=80):
+    """Stand-in for the anchors-vs-reads call (nanoRepeat_bam.py:281): reads are the PAF queries,
+    the two anchors the targets.  One record per (read, anchor, strand) from the CPU oracle,
+    computed with the anchor as DP query so that the extents are read coordinates."""
+
+    def answer(cmd, toks, rec):
+        tfile, qfile = rec["files"][-2], rec["files"][-1]
+        anchors = read_fasta(tfile)
+        out = []
+        for qname, qseq in read_fastx_names_seqs(qfile):
+            for tname, tseq in anchors:
+                for strand, s in (("+", qseq), ("-", revcomp(qseq))):
+                    sc, ts, te = O.align(tseq, s)
+                    if sc < min_score:
+                        continue
+                    qs, qe = (ts, te) if strand == "+" else (len(qseq) - te, len(qseq) - ts)
+                    out.append("\t".join(map(str, [qname, len(qseq), qs, qe, strand, tname, len(tseq), 0, len(tseq),
+                                                   te - ts, te - ts, 60, "tp:A:P", f"AS:i:{sc}"])))
+        return "\n".join(out) + ("\n" if out else ""), ""
+
+    return answer
+
+
+def read_fields(rd):
+    keys = ("read_name", "full_read_len", "left_anchor_is_good", "right_anchor_is_good", "both_anchors_are_good",
+            "core_seq_start_pos", "core_seq_end_pos", "mid_seq_start_pos", "mid_seq_end_pos",
+            "dist_between_anchors", "strand", "left_buffer_len", "right_buffer_len",
+            "round1_repeat_size", "round2_repeat_size", "round3_repeat_size")
+    return {k: (fnum(getattr(rd, k)) if k.startswith("round") else getattr(rd, k)) for k in keys}
+
+
+def gen_upstream(tmp):
+    fx = {}
+    rng = random.Random(23)
+    # -- anchor logic on canned PAF (nanoRepeat_bam.py:165-258)
+    def P(q, qlen, qs, qe, st, t, AS, alen=900, mapq=60):
+        return "\t".join(map(str, [q, qlen, qs, qe, st, t, 1000, 0, 1000, alen, alen, mapq, "tp:A:P", f"AS:i:{AS}"]))
+    cases = [
+        [P("a", 5000, 1000, 2000, "+", "left_anchor", 1800), P("a", 5000, 2100, 3100, "+", "right_anchor", 1700)],
+        [P("b", 5000, 1000, 2000, "-", "left_anchor", 1800), P("b", 5000, 2100, 3100, "-", "right_anchor", 1700)],
+        [P("c", 5000, 1000, 2000, "+", "left_anchor", 1800), P("c", 5000, 2100, 3100, "-", "right_anchor", 1700)],
+        [P("d", 5000, 1000, 2000, "+", "left_anchor", 1800), P("d", 5000, 1985, 2985, "+", "right_anchor", 1700)],
+        [P("e", 5000, 1000, 2000, "+", "left_anchor", 1800), P("e", 5000, 1991, 2991, "+", "right_anchor", 1700)],
+        [P("f", 5000, 1000, 2000, "+", "left_anchor", 1800)],
+        [P("g", 5000, 1000, 2000, "+", "left_anchor", 1800), P("g", 5000, 3000, 3600, "+", "left_anchor", 1300),
+         P("g", 5000, 2100, 3100, "+", "right_anchor", 1700)],
+        [P("h", 5000, 1000, 2000, "+", "left_anchor", 1800), P("h", 5000, 3000, 3600, "+", "left_anchor", 1100),
+         P("h", 5000, 2100, 3100, "+", "right_anchor", 1700)],
+        [P("i", 5000, 1000, 2000, "+", "left_anchor", 1800, mapq=20), P("i", 5000, 3000, 3600, "+", "left_anchor", 100),
+         P("i", 5000, 2100, 3100, "+", "right_anchor", 1700)],
+        [P("j", 2150, 40, 1040, "+", "left_anchor", 1800), P("j", 2150, 1100, 2100, "+", "right_anchor", 1700)],
+        [P("k", 5000, 1000, 2000, "+", "left_anchor", 1800, alen=9), P("k", 5000, 3000, 3600, "+", "left_anchor", 100),
+         P("k", 5000, 2100, 3100, "+", "right_anchor", 1700)],
+    ]
+    out = []
+    for lines in cases:
+        rr = make_region("A" * 1000, "TATTG", "C" * 1000, tmp)
+        ref_bam.find_anchor_locations_from_paf(rr, "\n".join(lines) + "\n")
+        out.append({"lines": lines, "reads": {n: read_fields(rd) for n, rd in rr.read_dict.items()}})
+    # several reads in one PAF text (grouping by consecutive qname)
+    rr = make_region("A" * 1000, "TATTG", "C" * 1000, tmp)
+    allines = [l for c in cases[:6] for l in c]
+    ref_bam.find_anchor_locations_from_paf(rr, "\n".join(allines) + "\n")
+    out.append({"lines": allines, "reads": {n: read_fields(rd) for n, rd in rr.read_dict.items()}})
+    fx["anchor_logic"] = out
+
+    # -- end to end: steps 1-3 of quantify1repeat_from_bam (:656-679) with the oracle as aligner
+    e2e = []
+    for cid, (unit, alleles, errs, nreads, anchor_len) in enumerate([
+        ("TATTG", (7, 19), (0.02, 0.01, 0.02), 8, 300),
+        ("CAG", (11, 33), (0.03, 0.02, 0.03), 6, 250),
+    ]):
+        d = os.path.join(tmp, f"u{cid}"); shutil.rmtree(d, ignore_errors=True); os.makedirs(d)
+        left, right = rand_seq(anchor_len, rng), rand_seq(anchor_len, rng)
+        far_l, far_r = rand_seq(400, rng), rand_seq(400, rng)
+        rr = make_region(left, unit, right, d)
+        rr.region_fq_file = os.path.join(d, "region.fastq")
+        reads = []
+        with open(rr.region_fq_file, "w") as f:
+            for i in range(nreads):
+                kt = alleles[i % 2]
+                s = mutate(far_l[rng.randint(0, 300):] + left + unit * kt + right + far_r[:rng.randint(100, 400)], *errs, rng)
+                if i == nreads - 1:
+                    s = mutate(far_l + left + unit * kt, *errs, rng)        # no right anchor: read rejected
+                if i % 3 == 1:
+                    s = revcomp(s)
+                f.write(f"@rd{i}\n{s}\n+\n{'I' * len(s)}\n")
+                reads.append({"name": f"rd{i}", "seq": s})
+        ref_bam.pymm2.main = Recorder(anchor_aligner(80))
+        ref_bam.find_anchor_locations_in_reads("ont", rr, 4)
+        ref_bam.make_core_seq_fastq(rr)
+        ref_bam.pymm2.main = Recorder(oracle_aligner(80))
+        ref_bam.round1_and_round2_estimation("ont", rr, 4)
+        ref_bam.round3_estimation("ont", False, rr, 4)
+        e2e.append({"left": left, "unit": unit, "right": right, "reads": reads,
+                    "read_dict": {n: read_fields(rd) for n, rd in rr.read_dict.items()},
+                    "core": dict(rr.read_core_seq_dict)})
+    fx["e2e"] = e2e
+    return fx
+
+
 def main():
     tmp = tempfile.mkdtemp(prefix="nr_golden_")
     try:
         one = gen_1d(tmp)
         two = gen_2d(tmp)
+        up = gen_upstream(tmp)
     finally:
         shutil.rmtree(tmp, ignore_errors=True)
-    for name, fx in (("ref_1d.json", one), ("ref_2d.json", two)):
+    for name, fx in (("ref_1d.json", one), ("ref_2d.json", two), ("ref_upstream.json", up)):
         with open(os.path.join(HERE, name), "w") as f:
             json.dump(fx, f, indent=1, sort_keys=True)
             f.write("\n")

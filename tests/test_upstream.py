@@ -1,0 +1,115 @@
+"""Rows upstream of the hot path: anchor logic, core trimming, rounds 1-2,
+against fixtures captured from the reference's Python (tests/golden/ref_upstream.json)."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+from nanorepeat_amd import upstream as U, round3 as R3
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "ref_upstream.json")
+FIELDS = ("read_name", "full_read_len", "left_anchor_is_good", "right_anchor_is_good", "both_anchors_are_good",
+          "core_seq_start_pos", "core_seq_end_pos", "mid_seq_start_pos", "mid_seq_end_pos",
+          "dist_between_anchors", "strand", "left_buffer_len", "right_buffer_len")
+
+
+@pytest.fixture(scope="module")
+def golden():
+    return json.load(open(GOLDEN))
+
+
+def _region(left, unit, right):
+    rr = R3.RepeatRegion()
+    rr.left_anchor_seq, rr.repeat_unit_seq, rr.right_anchor_seq = left, unit, right
+    rr.left_anchor_len, rr.right_anchor_len = len(left), len(right)
+    return rr
+
+
+def _hits_from_paf(lines):
+    """PAF text -> AnchorHit records, grouped by consecutive qname like
+    find_anchor_locations_from_paf (nanoRepeat_bam.py:238-258)."""
+    groups = []
+    for line in lines:
+        c = line.split("\t")
+        qlen, qs, qe = int(c[1]), int(c[2]), int(c[3])
+        if c[4] == "-":
+            qs, qe = qlen - qe, qlen - qs                       # paf.py:70-74
+        AS = int([x for x in c[12:] if x.startswith("AS:i:")][0][5:])
+        hit = U.AnchorHit(c[0], qlen, qs, qe, c[4], c[5], AS, int(c[10]), int(c[11]))
+        if groups and groups[-1][0].qname == hit.qname:
+            groups[-1].append(hit)
+        else:
+            groups.append([hit])
+    return groups
+
+
+def test_anchor_logic_matches_reference(golden):
+    for case in golden["anchor_logic"]:
+        rr = _region("A" * 1000, "TATTG", "C" * 1000)
+        for g in _hits_from_paf(case["lines"]):
+            U.find_anchor_locations_for1read(g, rr)
+        assert list(rr.read_dict) == list(case["reads"])
+        for n, want in case["reads"].items():
+            got = rr.read_dict[n]
+            for f in FIELDS:
+                assert getattr(got, f) == want[f], (n, f)
+
+
+def _run_flow(e, aligner=None, scorer=None):
+    rr = _region(e["left"], e["unit"], e["right"])
+    reads = {r["name"]: r["seq"] for r in e["reads"]}
+    U.find_anchor_locations_in_reads("ont", rr, 4, region_reads=reads, aligner=aligner)
+    U.make_core_seq(rr, reads)
+    U.round1_and_round2_estimation("ont", rr, 4, aligner=aligner)
+    R3.round3_estimation("ont", False, rr, 4, scorer=scorer)
+    return rr
+
+
+def _check_flow(e, rr):
+    assert list(rr.read_dict) == list(e["read_dict"])
+    assert rr.read_core_seq_dict == e["core"]
+    for n, want in e["read_dict"].items():
+        got = rr.read_dict[n]
+        for f in FIELDS:
+            assert getattr(got, f) == want[f], (n, f)
+        for f in ("round1_repeat_size", "round2_repeat_size", "round3_repeat_size"):
+            g = getattr(got, f)
+            assert (None if g is None else float(g)) == want[f], (n, f)
+
+
+def test_steps_1_to_3_match_reference_with_oracle(oracle, golden):
+    """quantify1repeat_from_bam steps 1-3 (nanoRepeat_bam.py:656-679): the reference's own run
+    (fixture) vs this repo's host logic with the CPU oracle as the aligner."""
+    for e in golden["e2e"]:
+        _check_flow(e, _run_flow(e, aligner=oracle.align_pairs, scorer=oracle.round3_1d))
+
+
+@pytest.mark.gpu
+def test_steps_1_to_3_match_reference_on_gpu(capi, golden):
+    for e in golden["e2e"]:
+        _check_flow(e, _run_flow(e))
+
+
+@pytest.mark.gpu
+def test_align_pairs_matches_oracle(capi, oracle):
+    from nanorepeat_amd import synth
+    rng = np.random.default_rng(12)
+    seqs, pq, pt = [], [], []
+    for i in range(12):
+        t = synth.rand_seq(rng, int(rng.integers(50, 4000)))
+        a = int(rng.integers(0, max(1, len(t) - 40)))
+        q = synth.apply_errors(rng, t[a:a + int(rng.integers(30, 900))], "ont")
+        if i % 4 == 0:
+            q = synth.revcomp(q)
+        seqs += [t, q]
+        pq += [2 * i + 1, 2 * i + 1]; pt += [2 * i, (2 * i + 2) % 24]
+    seqs += ["", "ACGTNNNN" * 30, synth.rand_seq(rng, 3072), synth.rand_seq(rng, 20000)]
+    pq += [24, 25, 26, 25, 1]; pt += [0, 25, 27, 24, 1]
+    for over in ({}, {"min_dp_score": 0}):
+        g = capi.align_pairs(seqs, pq, pt, sc=capi.default_scoring(**over))
+        o = oracle.align_pairs(seqs, pq, pt, sc=oracle.default_scoring(**over))
+        for k in ("score", "tstart", "tend"):
+            assert np.array_equal(g[k], o[k]), (k, g[k], o[k])
+    with pytest.raises(capi.NraError):
+        capi.align_pairs([synth.rand_seq(rng, 3073), "ACGT"], [0], [1])
