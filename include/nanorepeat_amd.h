@@ -51,6 +51,8 @@ extern "C" {
 #define NRA_F_TIE_EXTENTS  2  /* explicit extents DP for every top-score tie, so cand_tstart/cand_tend are
                                  filled for them (the one-shot call sets it when those arrays are given);
                                  without it only ties whose flank verdict is ambiguous are re-run */
+#define NRA_F_TEST_CHAIN   8  /* testing only: sweep every read in chained 128-row blocks (the mechanism reads
+                                 longer than 3072 bases use with 1536-row blocks) */
 #define NRA_F_BRUTE_FORCE  4  /* score the K candidates of a read as K independent alignments
                                  (k_score_pk16) instead of the junction decomposition (k_sweep_pk16) */
 
@@ -127,6 +129,8 @@ void        nra_default_scoring(nra_scoring_t* sc);
  * Inputs: n_regions regions; n_reads oriented core sequences concatenated in `seqs`
  * with offsets seq_off[n_reads+1]; read_region[i] = region index of read i (NULL when
  * n_regions == 1); candidate window kmin[i]..kmax[i] inclusive (kmin > kmax = skipped).
+ * A read holds at most 8000 bases (NRA_E_RANGE beyond; reads over 3072 bases are swept in
+ * chained row blocks and need the junction decomposition: no NRA_F_BRUTE_FORCE / ALL_EXTENTS).
  *
  * Per-read outputs (all caller-allocated, n_reads entries):
  *   best_score  max AS over the read's candidates (0 when no record)

@@ -96,6 +96,7 @@ struct DevBuf {
 
 struct Bucket {
     int R = 0;
+    bool chain = false;        // reads longer than one register block: chained row blocks
     int n_pair = 0;            // pk16 tasks (1D score / 2D strand probe)
     size_t pair_off = 0;       // offset into pair_tasks
     int n_queue = 0;           // payload tasks prebuilt on the host (ALL_EXTENTS / 2D cells)
@@ -154,6 +155,8 @@ struct nra_batch {
     DevBuf<int32_t> arr_a;                     // A_k per candidate
     DevBuf<uint8_t> cand_flag;                 // flank verdict per candidate
     bool brute = false;                        // K independent alignments instead of the sweeps
+    DevBuf<int32_t> chain_sweep, chain_payload; // scratch strips of the chained row blocks
+    int chain_cap = 0;
     DevBuf<NraTask> queue_tasks;
     DevBuf<int32_t> queue_count;   // per bucket: prebuilt queue length (constant)
     DevBuf<int32_t> tie_count;     // per bucket: tie queue length (device-written)
@@ -200,16 +203,16 @@ struct PackedReads {
 };
 
 int pack_reads(int32_t n_reads, const char* seqs, const int64_t* seq_off, const int32_t* read_region,
-               int32_t n_regions, PackedReads& out)
+               int32_t n_regions, PackedReads& out, int64_t max_len = NRA_MAX_QLEN_1BLOCK)
 {
     out.reads.resize((size_t)n_reads);
     uint64_t base = 0;
     for (int32_t r = 0; r < n_reads; ++r) {
         int64_t len = seq_off[r + 1] - seq_off[r];
         if (len < 0) return fail(NRA_E_ARG, "seq_off must be non-decreasing");
-        if (len > NRA_MAX_QLEN)
+        if (len > max_len)
             return fail(NRA_E_RANGE, "read " + std::to_string(r) + " has " + std::to_string(len) +
-                                         " bases; the kernels hold at most " + std::to_string(NRA_MAX_QLEN));
+                                         " bases; this entry point holds at most " + std::to_string(max_len));
         int32_t g = read_region ? read_region[r] : 0;
         if (g < 0 || g >= n_regions) return fail(NRA_E_ARG, "read_region out of range");
         out.reads[r].qoff = (uint32_t)base;
@@ -318,7 +321,7 @@ int nra_batch1d_create(int device, const nra_region_t* regions, int32_t n_region
     if (rc) return rc;
 
     PackedReads pr;
-    rc = pack_reads(n_reads, seqs, seq_off, read_region, n_regions, pr);
+    rc = pack_reads(n_reads, seqs, seq_off, read_region, n_regions, pr, NRA_MAX_QLEN);
     if (rc) return rc;
 
     // per-region largest k, candidate offsets
@@ -374,13 +377,24 @@ int nra_batch1d_create(int device, const nra_region_t* regions, int32_t n_region
     }
     b->brute = brute;
     std::vector<NraSweepTask> sweep_tasks;
-    std::vector<std::vector<int32_t>> by_bucket((size_t)kNumR);
+    // bucket kNumR = reads longer than one register block (or every read with NRA_F_TEST_CHAIN)
+    std::vector<std::vector<int32_t>> by_bucket((size_t)kNumR + 1);
+    const bool test_chain = (flags & NRA_F_TEST_CHAIN) != 0;
+    int chain_cols = 0;
     for (int32_t r = 0; r < n_reads; ++r) {
         if (kmin[r] > kmax[r] || pr.reads[r].qlen == 0) continue;
-        int bi = rows_for_qlen(pr.reads[r].qlen);
+        int bi = (test_chain || pr.reads[r].qlen > NRA_MAX_QLEN_1BLOCK) ? kNumR : rows_for_qlen(pr.reads[r].qlen);
         read_bucket[r] = bi;
         by_bucket[bi].push_back(r);
+        if (bi == kNumR) {
+            const nra_region_t& rg = regions[pr.reads[r].region];
+            chain_cols = std::max(chain_cols, rg.left_len + rg.unit_len * kmax[r] + rg.right_len);
+        }
     }
+    if (!by_bucket[kNumR].empty() && brute)
+        return fail(NRA_E_RANGE, "reads longer than " + std::to_string(NRA_MAX_QLEN_1BLOCK) +
+                                     " bases need the junction decomposition (no brute force / ALL_EXTENTS, flanks >= 1)");
+    b->chain_cap = (chain_cols + 127) / 64 * 64 + 64;
     // a bucket with a handful of reads would run as its own under-filled launch: fold it into the
     // next larger rows-per-lane instantiation (the extra rows are padding)
     for (int bi = 0; bi + 1 < kNumR; ++bi) {
@@ -398,9 +412,11 @@ int nra_batch1d_create(int device, const nra_region_t* regions, int32_t n_region
     std::vector<uint32_t> task_base;
     size_t queue_total = 0;
     int64_t alg_cells = 0;
-    for (int bi = kNumR - 1; bi >= 0; --bi) {       // longest reads first
+    for (int bi = kNumR; bi >= 0; --bi) {           // longest reads first
         if (by_bucket[bi].empty()) continue;
-        Bucket bk; bk.R = kRList[bi];
+        Bucket bk;
+        bk.chain = bi == kNumR;
+        bk.R = bk.chain ? (test_chain ? NRA_CHAIN_R_TEST : NRA_CHAIN_R) : kRList[bi];
         bk.pair_off = pair_tasks.size();
         bk.queue_off = queue_total;
         for (int32_t r : by_bucket[bi]) {
@@ -449,7 +465,10 @@ int nra_batch1d_create(int device, const nra_region_t* regions, int32_t n_region
                     i += 1;
                 }
                 const NraDevRegion& d = dregs[pr.reads[t.read_a].region];
-                bk.cells_sweep += 2 * (sweep_cells(bk.R, d.l1 + d.m1 * t.kmax) + sweep_cells(bk.R, d.l3 + d.m1 * t.kmax));
+                int qmax = pr.reads[t.read_a].qlen;
+                if (t.read_b >= 0) qmax = std::max(qmax, pr.reads[t.read_b].qlen);
+                const int nblk = bk.chain ? (qmax + 64 * bk.R - 1) / (64 * bk.R) : 1;
+                bk.cells_sweep += (int64_t)nblk * 2 * (sweep_cells(bk.R, d.l1 + d.m1 * t.kmax + 64) + sweep_cells(bk.R, d.l3 + d.m1 * t.kmax + 64));
                 sweep_tasks.push_back(t);
             }
             bk.n_sweep = (int)(sweep_tasks.size() - bk.sweep_off);
@@ -478,6 +497,11 @@ int nra_batch1d_create(int device, const nra_region_t* regions, int32_t n_region
         HIP_TRY(b->arr_a.alloc((size_t)total));
     }
     HIP_TRY(b->cand_flag.alloc((size_t)total));
+    for (const Bucket& bk : b->buckets) {
+        if (!bk.chain) continue;
+        HIP_TRY(b->chain_sweep.alloc((size_t)bk.n_sweep * 10 * (size_t)b->chain_cap));
+        HIP_TRY(b->chain_payload.alloc((size_t)512 * 6 * (size_t)b->chain_cap));
+    }
     if (all_ext) HIP_TRY(b->queue_tasks.upload(queue_tasks));
     else HIP_TRY(b->queue_tasks.alloc(queue_total));
     HIP_TRY(b->queue_count.upload(queue_count));
@@ -543,16 +567,17 @@ static int run_1d(nra_batch* b)
             hipStream_t q = b->bstreams[i];
             HIP_TRY(hipStreamWaitEvent(q, b->fork_ev, 0));
             HIP_TRY(hipEventRecord(b->ev[ev++], q));
-            LAUNCH_TRY(nra_launch_sweep_bwd(bk.R, b->has_n, q, bk.n_sweep, b->sweep_tasks.p + bk.sweep_off,
+            LAUNCH_TRY(nra_launch_sweep_bwd(bk.R, b->has_n, bk.chain ? 1 : 0, q, bk.n_sweep, b->sweep_tasks.p + bk.sweep_off,
                                             b->reads.p, b->regions.p, b->pool.p, b->q2bit.p, b->qnmask.p, b->sp,
                                             b->kmin.p, b->kmax.p, b->coff.p, b->snap_h.p, b->snap_e.p,
-                                            b->snap_e2.p, b->arr_a.p));
+                                            b->snap_e2.p, b->arr_a.p, b->chain_sweep.p, b->chain_cap));
             HIP_TRY(hipEventRecord(b->ev[ev++], q));
             HIP_TRY(hipEventRecord(b->ev[ev++], q));
-            LAUNCH_TRY(nra_launch_sweep_fwd(bk.R, b->has_n, q, bk.n_sweep, b->sweep_tasks.p + bk.sweep_off,
+            LAUNCH_TRY(nra_launch_sweep_fwd(bk.R, b->has_n, bk.chain ? 1 : 0, q, bk.n_sweep, b->sweep_tasks.p + bk.sweep_off,
                                             b->reads.p, b->regions.p, b->pool.p, b->q2bit.p, b->qnmask.p, b->sp,
                                             b->kmin.p, b->kmax.p, b->coff.p, b->snap_h.p, b->snap_e.p,
-                                            b->snap_e2.p, b->arr_a.p, b->cand_score.p, b->cand_flag.p));
+                                            b->snap_e2.p, b->arr_a.p, b->cand_score.p, b->cand_flag.p,
+                                            b->chain_sweep.p, b->chain_cap));
             HIP_TRY(hipEventRecord(b->ev[ev++], q));
             b->n_score_ev += 2;
             HIP_TRY(hipEventRecord(b->bdone[i], q));
@@ -571,7 +596,7 @@ static int run_1d(nra_batch* b)
                                                   b->queue_tasks.p + bk.queue_off, b->queue_count.p + i,
                                                   b->reads.p, b->regions.p, b->pool.p,
                                                   b->q2bit.p, b->qnmask.p, b->sp, b->cand_score.p,
-                                                  b->cand_tstart.p, b->cand_tend.p));
+                                                  b->cand_tstart.p, b->cand_tend.p, nullptr, 0));
             }
             HIP_TRY(hipEventRecord(b->ev[ev++], st));
             b->n_score_ev++;
@@ -588,11 +613,13 @@ static int run_1d(nra_batch* b)
         for (size_t i = 0; i < nb; ++i) {
             const Bucket& bk = b->buckets[i];
             HIP_TRY(hipEventRecord(b->ev[ev++], st));
-            LAUNCH_TRY(nra_launch_payload_origin(bk.R, b->has_n, st, (int)std::min<size_t>(bk.queue_cap, max_waves),
+            LAUNCH_TRY(nra_launch_payload_origin(bk.R, b->has_n, st,
+                                              (int)std::min<size_t>(bk.queue_cap, bk.chain ? 512 : max_waves),
                                               b->queue_tasks.p + bk.queue_off, b->tie_count.p + i,
                                               b->reads.p, b->regions.p, b->pool.p,
                                               b->q2bit.p, b->qnmask.p, b->sp, b->cand_score.p,
-                                              b->cand_tstart.p, b->cand_tend.p));
+                                              b->cand_tstart.p, b->cand_tend.p,
+                                              bk.chain ? b->chain_payload.p : nullptr, b->chain_cap));
             HIP_TRY(hipEventRecord(b->ev[ev++], st));
             b->n_ext_ev++;
         }
@@ -907,7 +934,7 @@ int nra_align_pairs(int device, int32_t n_seqs, const char* seqs, const int64_t*
             if (pool.size() > 0xfff00000ull) return fail(NRA_E_RANGE, "target pool exceeds 4 GB");
         }
         if (as_query[s] == 0) {
-            if (len > NRA_MAX_QLEN) return fail(NRA_E_RANGE, "query longer than " + std::to_string(NRA_MAX_QLEN));
+            if (len > NRA_MAX_QLEN_1BLOCK) return fail(NRA_E_RANGE, "query longer than " + std::to_string(NRA_MAX_QLEN_1BLOCK));
             NraDevRead r{};
             r.qoff = (uint32_t)base; r.qlen = (int32_t)len; r.region = 0; r.rc = 0;
             as_query[s] = (int32_t)dreads.size();
@@ -959,7 +986,7 @@ int nra_align_pairs(int device, int32_t n_seqs, const char* seqs, const int64_t*
     for (size_t i = 0; i < launches.size(); ++i) {
         LAUNCH_TRY(nra_launch_payload_origin(launches[i].first, has_n ? 1 : 0, nullptr, std::min(counts[i], 256 * 16),
                                              d_tasks.p + launches[i].second, d_counts.p + i, d_reads.p, d_regs.p,
-                                             d_pool.p, d_q2.p, d_nm.p, sp, d_score.p, d_ts.p, d_te.p));
+                                             d_pool.p, d_q2.p, d_nm.p, sp, d_score.p, d_ts.p, d_te.p, nullptr, 0));
     }
     HIP_TRY(hipDeviceSynchronize());
     HIP_TRY(hipMemcpy(score, d_score.p, (size_t)n_pairs * 4, hipMemcpyDeviceToHost));

@@ -68,7 +68,12 @@ struct NraScoreParams {
                       X(15) X(16) X(18) X(20) X(22) X(24) X(28) X(32) X(40) X(48)
 #endif
 #define NRA_MAX_R 48
-#define NRA_MAX_QLEN (64 * NRA_MAX_R)
+#define NRA_MAX_QLEN_1BLOCK (64 * NRA_MAX_R)   // rows one wave holds in registers
+// longer reads are swept in row blocks of 64*NRA_CHAIN_R rows chained through a scratch strip;
+// the int16 cells (biased twice in the junction combine) hold scores up to 2 * 8000
+#define NRA_CHAIN_R 24
+#define NRA_CHAIN_R_TEST 2                     // tiny row blocks, for the tests (NRA_F_TEST_CHAIN)
+#define NRA_MAX_QLEN 8000
 #define NRA_MAX_TLEN 65000     // payload (tstart) is 16 bits; + 64 pipeline columns
 
 #ifdef __cplusplus
@@ -88,7 +93,8 @@ int nra_launch_payload_origin(int R, int has_n, hipStream_t st, int n_waves,
                               const NraDevRead* reads, const NraDevRegion* regions,
                               const uint8_t* pool, const uint32_t* q2bit, const uint32_t* qnmask,
                               NraScoreParams sp,
-                              int32_t* out_score, int32_t* out_p, int32_t* out_tend);
+                              int32_t* out_score, int32_t* out_p, int32_t* out_tend,
+                              int32_t* chain_buf, int chain_cap);   // chain_buf != NULL: row-block chaining
 int nra_launch_payload_window(int R, int has_n, hipStream_t st, int n_waves,
                               const NraTask* tasks, const int32_t* count,
                               const NraDevRead* reads, const NraDevRegion* regions,
@@ -98,17 +104,18 @@ int nra_launch_payload_window(int R, int has_n, hipStream_t st, int n_waves,
 
 // junction decomposition (nra_sweep.hip): reverse sweep writes the R-side snapshot and A_k,
 // forward sweep combines and writes Score(k) + the flank-test verdict (0 fail, 1 pass, 2 ambiguous)
-int nra_launch_sweep_bwd(int R, int has_n, hipStream_t st, int n_tasks, const NraSweepTask* tasks,
-                         const NraDevRead* reads, const NraDevRegion* regions, const uint8_t* pool,
-                         const uint32_t* q2bit, const uint32_t* qnmask, NraScoreParams sp,
-                         const int32_t* kmin, const int32_t* kmax, const uint32_t* coff,
-                         int16_t* snap_h, int16_t* snap_e, int16_t* snap_e2, int32_t* arr_a);
-int nra_launch_sweep_fwd(int R, int has_n, hipStream_t st, int n_tasks, const NraSweepTask* tasks,
+int nra_launch_sweep_bwd(int R, int has_n, int chain, hipStream_t st, int n_tasks, const NraSweepTask* tasks,
                          const NraDevRead* reads, const NraDevRegion* regions, const uint8_t* pool,
                          const uint32_t* q2bit, const uint32_t* qnmask, NraScoreParams sp,
                          const int32_t* kmin, const int32_t* kmax, const uint32_t* coff,
                          int16_t* snap_h, int16_t* snap_e, int16_t* snap_e2, int32_t* arr_a,
-                         int32_t* cand_score, uint8_t* cand_flag);
+                         int32_t* chain_buf, int chain_cap);
+int nra_launch_sweep_fwd(int R, int has_n, int chain, hipStream_t st, int n_tasks, const NraSweepTask* tasks,
+                         const NraDevRead* reads, const NraDevRegion* regions, const uint8_t* pool,
+                         const uint32_t* q2bit, const uint32_t* qnmask, NraScoreParams sp,
+                         const int32_t* kmin, const int32_t* kmax, const uint32_t* coff,
+                         int16_t* snap_h, int16_t* snap_e, int16_t* snap_e2, int32_t* arr_a,
+                         int32_t* cand_score, uint8_t* cand_flag, int32_t* chain_buf, int chain_cap);
 
 // 1D selectors (one wave per read).  append_mode: 0 none, 1 ambiguous ties only, 2 every tie
 int nra_launch_select_best_1d(hipStream_t st, int n_reads, const int32_t* kmin, const int32_t* kmax,

@@ -161,7 +161,7 @@ __global__ __launch_bounds__(WAVE) void k_score_pk16(int n_tasks, const NraPairT
 #define NEG32 (-(1 << 29))
 #define WBIAS 0x8000
 
-template <int R, bool HAS_N, int MODE>
+template <int R, bool HAS_N, int MODE, bool CHAIN>
 __global__ __launch_bounds__(WAVE) void k_payload_i32(const NraTask* __restrict__ tasks,
                                                       const int32_t* __restrict__ count,
                                                       const NraDevRead* __restrict__ reads,
@@ -172,7 +172,8 @@ __global__ __launch_bounds__(WAVE) void k_payload_i32(const NraTask* __restrict_
                                                       NraScoreParams sp,
                                                       int32_t* __restrict__ out_score,
                                                       int32_t* __restrict__ out_p,
-                                                      int32_t* __restrict__ out_tend)
+                                                      int32_t* __restrict__ out_tend,
+                                                      int32_t* chain_buf, int chain_cap)
 {
     const int lane = threadIdx.x;
     const int n_tasks = *count;       // written by an earlier kernel on the same stream (or the host)
@@ -190,15 +191,25 @@ __global__ __launch_bounds__(WAVE) void k_payload_i32(const NraTask* __restrict_
         const int wa = imax(0, rg.l1 - 10);
         const int wb = imin(tm.tlen, tm.len1 + tm.len2 + 10);
 
+        int best = 0xffff, bestj = -1;     // (0, max payload): only cells with score >= 1 can beat it
+        // CHAIN: a read longer than 64*R rows is swept in row blocks, one after the other in this wave;
+        // lane 63 leaves its per-column hand-off (H, F, F2) in a wave-private strip for the next block
+        const int n_blk = CHAIN ? (rd.qlen + 64 * R - 1) / (64 * R) : 1;
+        volatile int32_t* strip = CHAIN ? chain_buf + (size_t)blockIdx.x * 6 * chain_cap : nullptr;
+      for (int blk = 0; blk < n_blk; ++blk) {
+        const int row_base = blk * 64 * R;
+        const bool first_blk = blk == 0, last_blk = blk == n_blk - 1;
+        volatile int32_t* cin = CHAIN ? strip + ((blk + 1) & 1) * 3 * chain_cap : nullptr;
+        volatile int32_t* cout = CHAIN ? strip + (blk & 1) * 3 * chain_cap : nullptr;
+
         int qc[R];
 #pragma unroll
-        for (int i = 0; i < R; ++i) qc[i] = query_code<HAS_N>(rd, q2bit, qnmask, lane * R + i);
+        for (int i = 0; i < R; ++i) qc[i] = query_code<HAS_N>(rd, q2bit, qnmask, row_base + lane * R + i);
 
         int Hprev[R], E[R], E2[R];
 #pragma unroll
         for (int i = 0; i < R; ++i) { Hprev[i] = NEG32; E[i] = NEG32; E2[i] = NEG32; }
         int Hbot = NEG32, Fout = NEG32, F2out = NEG32, Hup_prev = NEG32;
-        int best = 0xffff, bestj = -1;     // (0, max payload): only cells with score >= 1 can beat it
         int tt = NRA_PAD_T;
         int j = -lane;
 
@@ -209,10 +220,15 @@ __global__ __launch_bounds__(WAVE) void k_payload_i32(const NraTask* __restrict_
         const int nchunks = (ncols + 63 + 63) >> 6;
         for (int c = 0; c < nchunks; ++c) {
             int feed = tmpl_code(tm, c * 64 + lane);
+            int inH = NEG32, inF = NEG32, inF2 = NEG32;      // what enters lane 0 at each column
+            if (CHAIN) {
+                const int col = c * 64 + lane;
+                if (!first_blk && col < ncols) { inH = cin[col]; inF = cin[chain_cap + col]; inF2 = cin[2 * chain_cap + col]; }
+            }
 #pragma unroll 2
             for (int s = 0; s < 64; ++s) {
-                int F = dpp_shr1(NEG32, Fout);
-                int F2 = dpp_shr1(NEG32, F2out);
+                int F = dpp_shr1(CHAIN ? inF : NEG32, Fout);
+                int F2 = dpp_shr1(CHAIN ? inF2 : NEG32, F2out);
                 tt = dpp_shr1(feed, tt);
                 feed = dpp_rol1(feed);
 
@@ -246,7 +262,8 @@ __global__ __launch_bounds__(WAVE) void k_payload_i32(const NraTask* __restrict_
                 int sc;
                 NRA_SUBST(0, sc);
                 int d = imax(Hup_prev, fresh) + sc;   // diagonal of my first row came in one step ago
-                Hup_prev = dpp_shr1(NEG32, Hbot);
+                Hup_prev = dpp_shr1(CHAIN ? inH : NEG32, Hbot);
+                if (CHAIN) { inH = dpp_rol1(inH); inF = dpp_rol1(inF); inF2 = dpp_rol1(inF2); }
                 int colmax = NEG32, h = NEG32;
 #pragma unroll
                 for (int i = 0; i < R; ++i) {
@@ -268,9 +285,15 @@ __global__ __launch_bounds__(WAVE) void k_payload_i32(const NraTask* __restrict_
 #undef NRA_SUBST
                 if (colmax > best) { best = colmax; bestj = j; }
                 Hbot = h; Fout = F; F2out = F2;
+                if (CHAIN) {
+                    if (lane == 63 && !last_blk && j >= 0 && j < ncols) {
+                        cout[j] = Hbot; cout[chain_cap + j] = Fout; cout[2 * chain_cap + j] = F2out;
+                    }
+                }
                 ++j;
             }
         }
+      }   // row blocks
         // wave reduce: max packed value, then the smallest column holding it
         int vmax = best;
 #pragma unroll
@@ -464,18 +487,31 @@ static int launch_payload(int R, int has_n, hipStream_t st, int n_waves, const N
                           const int32_t* count, const NraDevRead* reads,
                           const NraDevRegion* regions, const uint8_t* pool, const uint32_t* q2bit,
                           const uint32_t* qnmask, NraScoreParams sp, int32_t* out_score,
-                          int32_t* out_p, int32_t* out_tend)
+                          int32_t* out_p, int32_t* out_tend, int32_t* chain_buf = nullptr, int chain_cap = 0)
 {
+#define PARGS tasks, count, reads, regions, pool, q2bit, qnmask, sp, out_score, out_p, out_tend, chain_buf, chain_cap
+    if (chain_buf) {   // row-block chaining (ORIGIN only): the instantiations long reads and the tests use
+        if (MODE != 0) return (int)hipErrorInvalidValue;
+        if (R == NRA_CHAIN_R) {
+            if (has_n) k_payload_i32<NRA_CHAIN_R, true, 0, true><<<n_waves, WAVE, 0, st>>>(PARGS);
+            else k_payload_i32<NRA_CHAIN_R, false, 0, true><<<n_waves, WAVE, 0, st>>>(PARGS);
+        } else if (R == NRA_CHAIN_R_TEST) {
+            if (has_n) k_payload_i32<NRA_CHAIN_R_TEST, true, 0, true><<<n_waves, WAVE, 0, st>>>(PARGS);
+            else k_payload_i32<NRA_CHAIN_R_TEST, false, 0, true><<<n_waves, WAVE, 0, st>>>(PARGS);
+        } else return (int)hipErrorInvalidValue;
+        return (int)hipGetLastError();
+    }
 #define CASE(r)                                                                                     \
     case r:                                                                                         \
-        if (has_n) k_payload_i32<r, true, MODE><<<n_waves, WAVE, 0, st>>>(tasks, count, reads, regions, pool, q2bit, qnmask, sp, out_score, out_p, out_tend); \
-        else k_payload_i32<r, false, MODE><<<n_waves, WAVE, 0, st>>>(tasks, count, reads, regions, pool, q2bit, qnmask, sp, out_score, out_p, out_tend);       \
+        if (has_n) k_payload_i32<r, true, MODE, false><<<n_waves, WAVE, 0, st>>>(PARGS); \
+        else k_payload_i32<r, false, MODE, false><<<n_waves, WAVE, 0, st>>>(PARGS);       \
         break;
     switch (R) {
         NRA_R_LIST(CASE)
     default: return (int)hipErrorInvalidValue;
     }
 #undef CASE
+#undef PARGS
     return (int)hipGetLastError();
 }
 
@@ -485,10 +521,10 @@ extern "C" int nra_launch_payload_origin(int R, int has_n, hipStream_t st, int n
                                          const NraDevRead* reads, const NraDevRegion* regions,
                                          const uint8_t* pool, const uint32_t* q2bit, const uint32_t* qnmask,
                                          NraScoreParams sp, int32_t* out_score, int32_t* out_p,
-                                         int32_t* out_tend)
+                                         int32_t* out_tend, int32_t* chain_buf, int chain_cap)
 {
     if (n_waves <= 0) return 0;
-    return launch_payload<0>(R, has_n, st, n_waves, tasks, count, reads, regions, pool, q2bit, qnmask, sp, out_score, out_p, out_tend);
+    return launch_payload<0>(R, has_n, st, n_waves, tasks, count, reads, regions, pool, q2bit, qnmask, sp, out_score, out_p, out_tend, chain_buf, chain_cap);
 }
 #endif
 #if NRA_HAS_PART(3)

@@ -141,7 +141,7 @@ __device__ __forceinline__ void sweep_snapshot(const int (&Hq)[R], const int (&E
     }
 }
 
-template <int R, bool HAS_N, int DIR>
+template <int R, bool HAS_N, int DIR, bool CHAIN>
 __global__ __launch_bounds__(WAVE) void k_sweep_pk16(int n_tasks, const NraSweepTask* __restrict__ tasks,
                                                      const NraDevRead* __restrict__ reads,
                                                      const NraDevRegion* __restrict__ regions,
@@ -157,7 +157,8 @@ __global__ __launch_bounds__(WAVE) void k_sweep_pk16(int n_tasks, const NraSweep
                                                      int16_t* __restrict__ snap_e2,
                                                      int32_t* __restrict__ arr_a,
                                                      int32_t* __restrict__ cand_score,
-                                                     uint8_t* __restrict__ cand_flag)
+                                                     uint8_t* __restrict__ cand_flag,
+                                                     int32_t* chain_buf, int chain_cap)
 {
     const int task = blockIdx.x;
     if (task >= n_tasks) return;
@@ -186,10 +187,21 @@ __global__ __launch_bounds__(WAVE) void k_sweep_pk16(int n_tasks, const NraSweep
     const int tbl_hi = s_mis | (s_ambi << 8);               // selector 4: padding row, 5: N in the read
     const int tbl_mis4 = s_mis * 0x01010101, tbl_ambi4 = s_ambi * 0x01010101;
 
+    // CHAIN: reads longer than 64*R rows are swept in row blocks of 64*R, one after the other in this
+    // wave; the last virtual cell of block b leaves its per-column hand-off (H, F, F2 and the two
+    // travelling accumulators) in a wave-private scratch strip that block b+1's first cell picks up.
+    const int n_blk = CHAIN ? (imax(rda.qlen, rdb.qlen) + 64 * R - 1) / (64 * R) : 1;
+    volatile int32_t* strip = CHAIN ? chain_buf + (size_t)task * 10 * chain_cap : nullptr;
+  for (int blk = 0; blk < n_blk; ++blk) {
+    const int row_base = blk * 64 * R;
+    const bool first_blk = blk == 0, last_blk = blk == n_blk - 1;
+    volatile int32_t* cin = CHAIN ? strip + ((blk + 1) & 1) * 5 * chain_cap : nullptr;
+    volatile int32_t* cout = CHAIN ? strip + (blk & 1) * 5 * chain_cap : nullptr;
+
     int qc[R];       // v_perm selectors: {selA, zero, selB, zero}
 #pragma unroll
     for (int i = 0; i < R; ++i) {
-        const int gi = lane * R + i;
+        const int gi = row_base + lane * R + i;
         const int ca = sweep_query_sel<HAS_N>(rda, q2bit, qnmask, gi, DIR == 0);
         const int cb = sweep_query_sel<HAS_N>(rdb, q2bit, qnmask, gi, DIR == 0);
         qc[i] = ca | (0x0c << 8) | (cb << 16) | (0x0c << 24);
@@ -201,7 +213,7 @@ __global__ __launch_bounds__(WAVE) void k_sweep_pk16(int n_tasks, const NraSweep
         const int q1 = sp.open1 - sp.ext1, q2 = sp.open2 - sp.ext2;     // the refunded gap opens
 #pragma unroll
         for (int i = 0; i < R; ++i) {
-            const int r = lane * R + i;
+            const int r = row_base + lane * R + i;
             int h[2], e[2], e2[2];
 #pragma unroll
             for (int s = 0; s < 2; ++s) {
@@ -245,16 +257,28 @@ __global__ __launch_bounds__(WAVE) void k_sweep_pk16(int n_tasks, const NraSweep
             if (col >= jfirst && (col - jfirst) % m == 0) feed |= FLAG_BOUNDARY;
             if (DIR == 0 && col == flank - 1) feed |= FLAG_SNAPSHOT;
         }
+        // what enters cell 0 at each column: constants for the first row block, else the strip
+        int inH = v_floor, inF = NEG1, inF2 = NEG1, inS = NEG2, inB = NEG1;
+        if (CHAIN) {
+            if (!first_blk && col < ncols) {
+                inH = cin[col]; inF = cin[chain_cap + col]; inF2 = cin[2 * chain_cap + col];
+                inS = cin[3 * chain_cap + col]; inB = cin[4 * chain_cap + col];
+            }
+        }
 #pragma unroll 2
         for (int s = 0; s < 64; ++s) {
             // inputs of cell A: cell B of the lane above, as it stood after the previous step
-            const int hupA = dpp_shr1(v_floor, HbotB);
-            int FA = dpp_shr1(NEG1, FoutB);
-            int F2A = dpp_shr1(NEG1, F2outB);
+            const int hupA = dpp_shr1(CHAIN ? inH : v_floor, HbotB);
+            int FA = dpp_shr1(CHAIN ? inF : NEG1, FoutB);
+            int F2A = dpp_shr1(CHAIN ? inF2 : NEG1, F2outB);
             const int ttA_new = dpp_shr1(feed, ttB);      // lane 0 takes the next template column
             feed = dpp_rol1(feed);
-            const int accS_Ain = dpp_shr1(NEG2, accS_B);
-            const int accB_Ain = dpp_shr1(NEG1, accB_B);
+            const int accS_Ain = dpp_shr1(CHAIN ? inS : NEG2, accS_B);
+            const int accB_Ain = dpp_shr1(CHAIN ? inB : NEG1, accB_B);
+            if (CHAIN) {
+                inH = dpp_rol1(inH); inF = dpp_rol1(inF); inF2 = dpp_rol1(inF2);
+                inS = dpp_rol1(inS); inB = dpp_rol1(inB);
+            }
             // inputs of cell B: this lane's cell A after the previous step
             const int hupB = HbotA;
             int FB = FoutA, F2B = F2outA;
@@ -289,11 +313,18 @@ __global__ __launch_bounds__(WAVE) void k_sweep_pk16(int n_tasks, const NraSweep
 
             if (DIR == 0) {
                 if (ttA & FLAG_SNAPSHOT)
-                    sweep_snapshot<0, RA, R>(Hq, E, E2, lane * R, rda, rdb, has_b, o1, snap_h, snap_e, snap_e2);
+                    sweep_snapshot<0, RA, R>(Hq, E, E2, row_base + lane * R, rda, rdb, has_b, o1, snap_h, snap_e, snap_e2);
                 if (ttB & FLAG_SNAPSHOT)
-                    sweep_snapshot<RA, RB, R>(Hq, E, E2, lane * R, rda, rdb, has_b, o1, snap_h, snap_e, snap_e2);
+                    sweep_snapshot<RA, RB, R>(Hq, E, E2, row_base + lane * R, rda, rdb, has_b, o1, snap_h, snap_e, snap_e2);
             }
-            if (lane == 63 && atB) {                      // cell 127 has finished a boundary column
+            if (CHAIN) {
+                const int col_out = c * 64 + s - 127;     // the column cell 127 has just finished
+                if (lane == 63 && !last_blk && col_out >= 0 && col_out < ncols) {
+                    cout[col_out] = HbotB; cout[chain_cap + col_out] = FoutB; cout[2 * chain_cap + col_out] = F2outB;
+                    cout[3 * chain_cap + col_out] = accS_B; cout[4 * chain_cap + col_out] = accB_B;
+                }
+            }
+            if (lane == 63 && atB && last_blk) {          // cell 127 has finished a boundary column
                 const int k = kcur++;
 #pragma unroll
                 for (int s2 = 0; s2 < 2; ++s2) {
@@ -319,53 +350,67 @@ __global__ __launch_bounds__(WAVE) void k_sweep_pk16(int n_tasks, const NraSweep
             }
         }
     }
+  }   // row blocks
 }
 
 // ------------------------------------------------------------------------------------
 // launchers
 // ------------------------------------------------------------------------------------
 template <int DIR>
-static int launch_sweep(int R, int has_n, hipStream_t st, int n_tasks, const NraSweepTask* tasks,
+static int launch_sweep(int R, int has_n, int chain, hipStream_t st, int n_tasks, const NraSweepTask* tasks,
                         const NraDevRead* reads, const NraDevRegion* regions, const uint8_t* pool,
                         const uint32_t* q2bit, const uint32_t* qnmask, NraScoreParams sp,
                         const int32_t* kmin, const int32_t* kmax, const uint32_t* coff,
                         int16_t* snap_h, int16_t* snap_e, int16_t* snap_e2, int32_t* arr_a,
-                        int32_t* cand_score, uint8_t* cand_flag)
+                        int32_t* cand_score, uint8_t* cand_flag, int32_t* chain_buf, int chain_cap)
 {
     if (n_tasks <= 0) return 0;
+#define ARGS n_tasks, tasks, reads, regions, pool, q2bit, qnmask, sp, kmin, kmax, coff, snap_h, snap_e, snap_e2, arr_a, cand_score, cand_flag, chain_buf, chain_cap
+    if (chain) {      // row-block chaining: only the instantiations long reads (and the tests) use
+        if (R == NRA_CHAIN_R) {
+            if (has_n) k_sweep_pk16<NRA_CHAIN_R, true, DIR, true><<<n_tasks, WAVE, 0, st>>>(ARGS);
+            else k_sweep_pk16<NRA_CHAIN_R, false, DIR, true><<<n_tasks, WAVE, 0, st>>>(ARGS);
+        } else if (R == NRA_CHAIN_R_TEST) {
+            if (has_n) k_sweep_pk16<NRA_CHAIN_R_TEST, true, DIR, true><<<n_tasks, WAVE, 0, st>>>(ARGS);
+            else k_sweep_pk16<NRA_CHAIN_R_TEST, false, DIR, true><<<n_tasks, WAVE, 0, st>>>(ARGS);
+        } else return (int)hipErrorInvalidValue;
+        return (int)hipGetLastError();
+    }
 #define CASE(r)                                                                                     \
     case r:                                                                                         \
-        if (has_n) k_sweep_pk16<r, true, DIR><<<n_tasks, WAVE, 0, st>>>(n_tasks, tasks, reads, regions, pool, q2bit, qnmask, sp, kmin, kmax, coff, snap_h, snap_e, snap_e2, arr_a, cand_score, cand_flag); \
-        else k_sweep_pk16<r, false, DIR><<<n_tasks, WAVE, 0, st>>>(n_tasks, tasks, reads, regions, pool, q2bit, qnmask, sp, kmin, kmax, coff, snap_h, snap_e, snap_e2, arr_a, cand_score, cand_flag);       \
+        if (has_n) k_sweep_pk16<r, true, DIR, false><<<n_tasks, WAVE, 0, st>>>(ARGS); \
+        else k_sweep_pk16<r, false, DIR, false><<<n_tasks, WAVE, 0, st>>>(ARGS);       \
         break;
     switch (R) {
         NRA_R_LIST(CASE)
     default: return (int)hipErrorInvalidValue;
     }
 #undef CASE
+#undef ARGS
     return (int)hipGetLastError();
 }
 
 #if NRA_HAS_PART(5)
-extern "C" int nra_launch_sweep_bwd(int R, int has_n, hipStream_t st, int n_tasks, const NraSweepTask* tasks,
-                                    const NraDevRead* reads, const NraDevRegion* regions, const uint8_t* pool,
-                                    const uint32_t* q2bit, const uint32_t* qnmask, NraScoreParams sp,
-                                    const int32_t* kmin, const int32_t* kmax, const uint32_t* coff,
-                                    int16_t* snap_h, int16_t* snap_e, int16_t* snap_e2, int32_t* arr_a)
-{
-    return launch_sweep<0>(R, has_n, st, n_tasks, tasks, reads, regions, pool, q2bit, qnmask, sp, kmin, kmax,
-                           coff, snap_h, snap_e, snap_e2, arr_a, nullptr, nullptr);
-}
-#endif
-#if NRA_HAS_PART(6)
-extern "C" int nra_launch_sweep_fwd(int R, int has_n, hipStream_t st, int n_tasks, const NraSweepTask* tasks,
+extern "C" int nra_launch_sweep_bwd(int R, int has_n, int chain, hipStream_t st, int n_tasks, const NraSweepTask* tasks,
                                     const NraDevRead* reads, const NraDevRegion* regions, const uint8_t* pool,
                                     const uint32_t* q2bit, const uint32_t* qnmask, NraScoreParams sp,
                                     const int32_t* kmin, const int32_t* kmax, const uint32_t* coff,
                                     int16_t* snap_h, int16_t* snap_e, int16_t* snap_e2, int32_t* arr_a,
-                                    int32_t* cand_score, uint8_t* cand_flag)
+                                    int32_t* chain_buf, int chain_cap)
 {
-    return launch_sweep<1>(R, has_n, st, n_tasks, tasks, reads, regions, pool, q2bit, qnmask, sp, kmin, kmax,
-                           coff, snap_h, snap_e, snap_e2, arr_a, cand_score, cand_flag);
+    return launch_sweep<0>(R, has_n, chain, st, n_tasks, tasks, reads, regions, pool, q2bit, qnmask, sp, kmin, kmax,
+                           coff, snap_h, snap_e, snap_e2, arr_a, nullptr, nullptr, chain_buf, chain_cap);
+}
+#endif
+#if NRA_HAS_PART(6)
+extern "C" int nra_launch_sweep_fwd(int R, int has_n, int chain, hipStream_t st, int n_tasks, const NraSweepTask* tasks,
+                                    const NraDevRead* reads, const NraDevRegion* regions, const uint8_t* pool,
+                                    const uint32_t* q2bit, const uint32_t* qnmask, NraScoreParams sp,
+                                    const int32_t* kmin, const int32_t* kmax, const uint32_t* coff,
+                                    int16_t* snap_h, int16_t* snap_e, int16_t* snap_e2, int32_t* arr_a,
+                                    int32_t* cand_score, uint8_t* cand_flag, int32_t* chain_buf, int chain_cap)
+{
+    return launch_sweep<1>(R, has_n, chain, st, n_tasks, tasks, reads, regions, pool, q2bit, qnmask, sp, kmin, kmax,
+                           coff, snap_h, snap_e, snap_e2, arr_a, cand_score, cand_flag, chain_buf, chain_cap);
 }
 #endif

@@ -111,7 +111,7 @@ def test_1d_many_regions_and_buckets(capi, oracle):
         for k in (1, 7, 20, 45, 90):
             s = synth.apply_errors(rng, L[-min(fl, len(L)):] + unit * k + R[:min(fl, len(R))], "ont_q20")
             reads.append(s); rr.append(g); kmin.append(max(0, k - 2)); kmax.append(k + 2)
-    # long reads: q ~ 700, 1300, 2100, 3072 (R = 11, 22, 40, 48)
+    # long reads: q ~ 700, 1300, 2100, 3072 (R = 11, 22, 40, 48; anything longer is chained)
     unit = regions[2][1]
     L, R = regions[2][0], regions[2][2]
     for q in (700, 1300, 2100, 3072):
@@ -132,7 +132,7 @@ def test_1d_scoring_variants(capi, oracle):
 def test_1d_errors(capi):
     L, R = "ACGT" * 20, "TTGCA" * 16
     with pytest.raises(capi.NraError) as e:
-        capi.round3_1d([(L, "CAG", R)], ["A" * 3073], [0], [1])
+        capi.round3_1d([(L, "CAG", R)], ["A" * 8001], [0], [1])
     assert e.value.code == -3
     with pytest.raises(capi.NraError) as e:
         capi.round3_1d([(L, "", R)], ["ACGT"], [0], [1])
@@ -406,3 +406,51 @@ def test_config3_joint_sample(capi, oracle):
     assert res["gpu"] == res["oracle"]
     k1 = np.array([res["gpu"][0][f"r{i}"] for i in range(6)]); k2 = np.array([res["gpu"][1][f"r{i}"] for i in range(6)])
     assert np.mean(np.abs(k1 - j["truth"][:, 0]) <= 1) >= 0.8 and np.mean(np.abs(k2 - j["truth"][:, 1]) <= 1) >= 0.8
+
+
+# ------------------------------------------------------------------ long reads: chained row blocks
+def test_1d_row_block_chaining_small_blocks(capi, oracle):
+    """The chaining mechanism (a read swept as consecutive row blocks in one wave, hand-off through a
+    scratch strip) exercised with 128-row blocks on ordinary reads: 2-8 blocks per read."""
+    for unit, seed, fl in (("TATTG", 201, 100), ("CAG", 202, 60), ("AT", 203, 30)):
+        d = synth.make_1d(14, unit, (6, 31), "ont", kwin=None, anchor=220, flank=fl, seed=seed)
+        o = oracle.round3_1d(d["regions"], d["reads"], d["kmin"], d["kmax"])
+        for flags in (capi.F_TEST_CHAIN, capi.F_TEST_CHAIN | capi.F_TIE_EXTENTS):
+            with capi.Batch.create_1d(d["regions"], d["reads"], d["kmin"], d["kmax"], flags=flags) as b:
+                b.run(); b.sync(); g = b.fetch()
+            keys = KEYS_1D if flags & capi.F_TIE_EXTENTS else ("best_score", "sum_k", "n_ties", "status", "cand_score")
+            for k in keys:
+                assert np.array_equal(g[k], o[k]), (unit, flags, k)
+    # adversarial reads (no flanks, ties on the junction) force the ambiguous-verdict extents DP through the chain too
+    rng = np.random.default_rng(9)
+    L, R, u = synth.rand_seq(rng, 150), synth.rand_seq(rng, 150), "TATTG"
+    reads = [L[-70:] + u * 9 + R[:70], L[-70:] + u * 9, u * 12 + R[:60], L[-70:] + u * 9 + R[:1], u * 30,
+             L[-70:] + u * 40 + R[:70]]
+    d = dict(regions=[(L, u, R)], reads=reads, kmin=np.zeros(6, np.int32), kmax=np.full(6, 45, np.int32))
+    o = oracle.round3_1d(d["regions"], d["reads"], d["kmin"], d["kmax"])
+    with capi.Batch.create_1d(d["regions"], d["reads"], d["kmin"], d["kmax"], flags=capi.F_TEST_CHAIN) as b:
+        b.run(); b.sync(); g = b.fetch(); st = b.stats()
+    for k in ("best_score", "sum_k", "n_ties", "status", "cand_score"):
+        assert np.array_equal(g[k], o[k]), k
+
+
+def test_1d_long_reads_over_one_register_block(capi, oracle):
+    """Reads of 3.3-7.9 kb (beyond the 3072 rows a wave holds in registers): 1536-row chained blocks."""
+    rng = np.random.default_rng(31)
+    L, R, u = synth.rand_seq(rng, 120), synth.rand_seq(rng, 120), "GGCCCC"
+    reads, kmin, kmax = [], [], []
+    for k in (530, 800, 1290):                      # cores of 3.3, 4.9, 7.9 kb
+        reads.append(synth.apply_errors(rng, L[-60:] + u * k + R[:60], "hifi"))
+        kmin.append(k - 2); kmax.append(k + 2)
+    reads.append(synth.apply_errors(rng, L[-60:] + u * 20 + R[:60], "hifi")); kmin.append(18); kmax.append(23)
+    g = capi.round3_1d([(L, u, R)], reads, kmin, kmax)
+    o = oracle.round3_1d([(L, u, R)], reads, kmin, kmax)
+    for k in KEYS_1D:
+        assert np.array_equal(g[k], o[k]), k
+    assert (g["status"] == 0).all()
+    with pytest.raises(capi.NraError) as e:
+        capi.round3_1d([(L, u, R)], ["A" * 8001], [0], [1])
+    assert e.value.code == -3
+    with pytest.raises(capi.NraError) as e:
+        capi.round3_1d([(L, u, R)], reads[:1], kmin[:1], kmax[:1], flags=capi.F_BRUTE_FORCE)
+    assert e.value.code == -3
