@@ -104,6 +104,8 @@ struct Bucket {
     size_t queue_cap = 0;      // capacity of this bucket's queue region
     int n_sweep = 0;           // junction-decomposition tasks (pairs of reads)
     size_t sweep_off = 0;
+    int n_jbwd = 0, n_jfwd = 0; // 2D decomposition tasks
+    size_t jbwd_off = 0, jfwd_off = 0;
     int64_t cells_pair = 0;    // executed cells per run, pk16
     int64_t cells_queue = 0;   // executed cells per run, prebuilt payload queue
     int64_t cells_sweep = 0;   // executed cells per run, both sweeps
@@ -156,6 +158,8 @@ struct nra_batch {
     DevBuf<uint8_t> cand_flag;                 // flank verdict per candidate
     bool brute = false;                        // K independent alignments instead of the sweeps
     DevBuf<int32_t> chain_sweep, chain_payload; // scratch strips of the chained row blocks
+    DevBuf<NraJointTask> jbwd_tasks, jfwd_tasks; // 2D junction decomposition: per read / per (read, k1) run
+    DevBuf<int32_t> jsnap, jread_a;             // R side of the junction (3 x int32 per base), A per read
     int chain_cap = 0;
     DevBuf<NraTask> queue_tasks;
     DevBuf<int32_t> queue_count;   // per bucket: prebuilt queue length (constant)
@@ -722,6 +726,11 @@ int nra_batch2d_create(int device, const nra_joint_region_t* reg, int32_t n_read
     d.p1_off = pool_append(pool, reg->left, reg->left_len, reg->unit1, reg->unit1_len, k1max, has_n);
     d.p2_off = pool_append(pool, reg->mid, reg->mid_len, reg->unit2, reg->unit2_len, k2max, has_n);
     d.p3_off = pool_append(pool, reg->right, reg->right_len, nullptr, 0, 0, has_n);
+    {
+        std::string rr(reg->right, reg->right + reg->right_len);
+        std::reverse(rr.begin(), rr.end());
+        d.pr_off = pool_append(pool, rr.data(), reg->right_len, nullptr, 0, 0, has_n);
+    }
     d.l1 = reg->left_len; d.m1 = reg->unit1_len; d.l2 = reg->mid_len; d.m2 = reg->unit2_len; d.l3 = reg->right_len;
     pool.push_back(0);
     b->has_n = has_n ? 1 : 0;
@@ -735,28 +744,55 @@ int nra_batch2d_create(int device, const nra_joint_region_t* reg, int32_t n_read
     std::vector<NraPairTask> pair_tasks;
     std::vector<NraTask> queue_tasks;
     std::vector<int32_t> queue_count;
+    std::vector<NraJointTask> jbwd, jfwd;
+    // junction decomposition needs a base left of the window and two bases of R
+    b->brute = (flags & NRA_F_BRUTE_FORCE) != 0 || reg->left_len < 1 || reg->right_len < 2;
     int64_t alg_cells = 0;
     for (int bi = kNumR - 1; bi >= 0; --bi) {
         if (by_bucket[bi].empty()) continue;
         Bucket bk; bk.R = kRList[bi];
         bk.pair_off = pair_tasks.size();
         bk.queue_off = queue_tasks.size();
+        bk.jbwd_off = jbwd.size(); bk.jfwd_off = jfwd.size();
         for (int32_t r : by_bucket[bi]) {
+            if (!b->brute) {
+                // one reverse sweep over R per read; one forward sweep per run of cells with the
+                // same k1 and k2 in arithmetic progression (how the grid rounds list them)
+                jbwd.push_back(NraJointTask{r, 0, 0, 1, 1, 0});
+                bk.cells_sweep += sweep_cells(bk.R, d.l3);
+                for (uint32_t c = first[r]; c < first[r] + cnt[r];) {
+                    NraJointTask t{r, cell_k1[c], cell_k2[c], 1, 1, (int32_t)c};
+                    uint32_t e = c + 1;
+                    if (e < first[r] + cnt[r] && cell_k1[e] == t.k1 && cell_k2[e] > t.k2lo) {
+                        t.k2step = cell_k2[e] - t.k2lo;
+                        while (e < first[r] + cnt[r] && cell_k1[e] == t.k1 &&
+                               cell_k2[e] == t.k2lo + t.k2step * (int32_t)(e - c)) ++e;
+                    }
+                    t.n2 = (int32_t)(e - c);
+                    jfwd.push_back(t);
+                    bk.cells_sweep += sweep_cells(bk.R, d.l1 + d.m1 * t.k1 + d.l2 + d.m2 * (t.k2lo + t.k2step * (t.n2 - 1)));
+                    c = e;
+                }
+            }
             // strand probe against the read's first listed cell: half A = template, half B = its revcomp
             NraPairTask t{};
             t.read = r; t.k1a = t.k1b = cell_k1[first[r]]; t.k2a = t.k2b = cell_k2[first[r]];
-            t.out_a = 2 * r; t.out_b = 2 * r + 1; t.flags = 1;
+            t.out_a = 2 * r; t.out_b = 2 * r + 1; t.flags = 3;     // B = reverse complement; raw scores
             pair_tasks.push_back(t);
             bk.cells_pair += 2 * sweep_cells(bk.R, d.l1 + d.m1 * t.k1a + d.l2 + d.m2 * t.k2a + d.l3);
             for (uint32_t c = first[r]; c < first[r] + cnt[r]; ++c) {
-                queue_tasks.push_back(NraTask{r, cell_k1[c], cell_k2[c], (int32_t)c});
                 const int tl = d.l1 + d.m1 * cell_k1[c] + d.l2 + d.m2 * cell_k2[c] + d.l3;
                 alg_cells += (int64_t)pr.reads[r].qlen * tl;
-                bk.cells_queue += sweep_cells(bk.R, tl);
+                if (b->brute) {
+                    queue_tasks.push_back(NraTask{r, cell_k1[c], cell_k2[c], (int32_t)c});
+                    bk.cells_queue += sweep_cells(bk.R, tl);
+                }
             }
         }
         bk.n_pair = (int)(pair_tasks.size() - bk.pair_off);
         bk.n_queue = (int)(queue_tasks.size() - bk.queue_off);
+        bk.n_jbwd = (int)(jbwd.size() - bk.jbwd_off);
+        bk.n_jfwd = (int)(jfwd.size() - bk.jfwd_off);
         bk.queue_cap = (size_t)bk.n_queue;
         queue_count.push_back(bk.n_queue);
         b->buckets.push_back(bk);
@@ -772,6 +808,12 @@ int nra_batch2d_create(int device, const nra_joint_region_t* reg, int32_t n_read
     HIP_TRY(b->pair_tasks.upload(pair_tasks));
     HIP_TRY(b->queue_tasks.upload(queue_tasks));
     HIP_TRY(b->queue_count.upload(queue_count));
+    if (!b->brute) {
+        HIP_TRY(b->jbwd_tasks.upload(jbwd));
+        HIP_TRY(b->jfwd_tasks.upload(jfwd));
+        HIP_TRY(b->jsnap.alloc(pr.q2bit.size() * 16 * 3));
+        HIP_TRY(b->jread_a.alloc((size_t)n_reads));
+    }
     HIP_TRY(b->probe_score.alloc(2 * (size_t)n_reads));
     {
         std::vector<int32_t> v(cell_k1, cell_k1 + n_cells); HIP_TRY(b->cell_k1.upload(v));
@@ -792,13 +834,13 @@ int nra_batch2d_create(int device, const nra_joint_region_t* reg, int32_t n_read
     HIP_TRY(b->sum_k.alloc((size_t)n_reads));
     HIP_TRY(b->sum_k2.alloc((size_t)n_reads));
     HIP_TRY(b->status.alloc((size_t)n_reads));
-    rc = make_events(b, 2 + 4 * (int)nb + 2);
+    rc = make_events(b, 2 + 6 * (int)nb + 2);
     if (rc) return rc;
 
     b->stats.n_alignments = n_cells;
     b->stats.algorithmic_cells = alg_cells;
     int64_t ex = 0;
-    for (const Bucket& bk : b->buckets) ex += bk.cells_pair + bk.cells_queue;
+    for (const Bucket& bk : b->buckets) ex += bk.cells_pair + bk.cells_queue + bk.cells_sweep;
     b->stats.executed_cells = ex;
     b->stats.algorithmic_bytes = (int64_t)pr.q2bit.size() * 4 + (int64_t)pool.size() + n_cells * 8 + (int64_t)n_reads * 25;
     *out = guard.release();
@@ -830,16 +872,37 @@ static int run_2d(nra_batch* b)
     LAUNCH_TRY(nra_launch_pick_strand(st, b->n_reads, b->probe_score.p,
                                       b->have_strand_in ? b->strand_in.p : nullptr, b->strand_out.p, b->reads.p));
     HIP_TRY(hipEventRecord(b->phase_ev[0], st));
-    for (size_t i = 0; i < nb; ++i) {
-        const Bucket& bk = b->buckets[i];
-        HIP_TRY(hipEventRecord(b->ev[ev++], st));
-        LAUNCH_TRY(nra_launch_payload_window(bk.R, b->has_n, st, std::min(bk.n_queue, max_waves),
-                                          b->queue_tasks.p + bk.queue_off, b->queue_count.p + i,
-                                          b->reads.p, b->regions.p, b->pool.p,
-                                          b->q2bit.p, b->qnmask.p, b->sp, b->cand_score.p,
-                                          b->cand_tstart.p, nullptr));
-        HIP_TRY(hipEventRecord(b->ev[ev++], st));
-        b->n_score_ev++;
+    if (b->brute) {
+        for (size_t i = 0; i < nb; ++i) {
+            const Bucket& bk = b->buckets[i];
+            HIP_TRY(hipEventRecord(b->ev[ev++], st));
+            LAUNCH_TRY(nra_launch_payload_window(bk.R, b->has_n, st, std::min(bk.n_queue, max_waves),
+                                              b->queue_tasks.p + bk.queue_off, b->queue_count.p + i,
+                                              b->reads.p, b->regions.p, b->pool.p,
+                                              b->q2bit.p, b->qnmask.p, b->sp, b->cand_score.p,
+                                              b->cand_tstart.p, nullptr));
+            HIP_TRY(hipEventRecord(b->ev[ev++], st));
+            b->n_score_ev++;
+        }
+    } else {
+        // junction decomposition: reverse sweeps over R (one per read), then one forward sweep per
+        // (read, k1) run of cells
+        for (int dir = 0; dir < 2; ++dir) {
+            for (size_t i = 0; i < nb; ++i) {
+                const Bucket& bk = b->buckets[i];
+                HIP_TRY(hipEventRecord(b->ev[ev++], st));
+                if (dir == 0)
+                    LAUNCH_TRY(nra_launch_joint_bwd(bk.R, b->has_n, st, bk.n_jbwd, b->jbwd_tasks.p + bk.jbwd_off,
+                                                    b->reads.p, b->regions.p, b->pool.p, b->q2bit.p, b->qnmask.p,
+                                                    b->sp, b->jsnap.p, b->jread_a.p));
+                else
+                    LAUNCH_TRY(nra_launch_joint_fwd(bk.R, b->has_n, st, bk.n_jfwd, b->jfwd_tasks.p + bk.jfwd_off,
+                                                    b->reads.p, b->regions.p, b->pool.p, b->q2bit.p, b->qnmask.p,
+                                                    b->sp, b->jsnap.p, b->jread_a.p, b->cand_score.p, b->cand_tstart.p));
+                HIP_TRY(hipEventRecord(b->ev[ev++], st));
+                b->n_score_ev++;
+            }
+        }
     }
     HIP_TRY(hipEventRecord(b->phase_ev[1], st));
     LAUNCH_TRY(nra_launch_select_2d(st, b->n_reads, b->cell_first.p, b->cell_cnt.p, b->cell_k1.p, b->cell_k2.p,

@@ -37,7 +37,8 @@ struct NraPairTask {
     int32_t read;
     int32_t k1a, k2a, k1b, k2b;
     int32_t out_a, out_b;  // index into the per-candidate score array; out_b < 0: no B half
-    int32_t flags;         // bit 0: half B is the reverse complement of the template (strand probe)
+    int32_t flags;         // bit 0: half B is the reverse complement of the template (strand probe);
+                           // bit 1: store raw scores, no min_dp_score threshold
 };
 
 // Two reads of one region swept together (int16 halves A / B) by the junction-decomposition
@@ -45,6 +46,16 @@ struct NraPairTask {
 struct NraSweepTask {
     int32_t read_a, read_b;   // read_b < 0: no second read
     int32_t kmin, kmax;
+};
+
+// One (read, k1) row of the 2D grid for the joint sweeps: the read's cells with this k1 are
+// k2 = k2lo + n*k2step, n < n2, and sit at out + n in the cell arrays.  (The reverse sweep
+// over R uses one task per read with n2 = 1.)
+struct NraJointTask {
+    int32_t read;
+    int32_t k1;
+    int32_t k2lo, k2step, n2;
+    int32_t out;
 };
 
 // One candidate scored with a payload (extents / window kernels).
@@ -116,6 +127,16 @@ int nra_launch_sweep_fwd(int R, int has_n, int chain, hipStream_t st, int n_task
                          const int32_t* kmin, const int32_t* kmax, const uint32_t* coff,
                          int16_t* snap_h, int16_t* snap_e, int16_t* snap_e2, int32_t* arr_a,
                          int32_t* cand_score, uint8_t* cand_flag, int32_t* chain_buf, int chain_cap);
+
+// 2D junction decomposition (nra_joint.hip)
+int nra_launch_joint_bwd(int R, int has_n, hipStream_t st, int n_tasks, const NraJointTask* tasks,
+                         const NraDevRead* reads, const NraDevRegion* regions, const uint8_t* pool,
+                         const uint32_t* q2bit, const uint32_t* qnmask, NraScoreParams sp,
+                         int32_t* snap, int32_t* read_a);
+int nra_launch_joint_fwd(int R, int has_n, hipStream_t st, int n_tasks, const NraJointTask* tasks,
+                         const NraDevRead* reads, const NraDevRegion* regions, const uint8_t* pool,
+                         const uint32_t* q2bit, const uint32_t* qnmask, NraScoreParams sp,
+                         int32_t* snap, int32_t* read_a, int32_t* cell_score, int32_t* cell_wscore);
 
 // 1D selectors (one wave per read).  append_mode: 0 none, 1 ambiguous ties only, 2 every tie
 int nra_launch_select_best_1d(hipStream_t st, int n_reads, const int32_t* kmin, const int32_t* kmax,

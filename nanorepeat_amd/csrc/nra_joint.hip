@@ -1,0 +1,285 @@
+// nra_joint.hip -- junction decomposition of the 2D (joint) grid (gfx950).
+//
+// For one read and one k1, the templates L + u1^k1 + mid + u2^k2 + R over k2 share
+// L + u1^k1 + mid + u2^k2 as a prefix and R as a suffix, exactly like the 1D bank
+// (nra_sweep.hip), so one forward sweep per (read, k1) and one reverse sweep over rev(R)
+// per read replace one full DP per (read, k1, k2) cell.
+//
+// The 2D selector needs the reference's CIGAR-window score of the co-optimal alignment
+// (tk.py:435-500), so cells are int32 = (score << 16) | (window + 0x8000) and every max is
+// the oracle's lexicographic (score, window) max.  Both parts are additive along a path, so
+// the pair decomposes at the junction like the score alone:
+//
+//   reverse sweep (DIR 0): reversed read vs rev(R); window payload of the R side: the
+//     window reaches wr = min(10, |R|) bases into R (nanoRepeat_joint.py:447-448).  A
+//     deletion run charges -4 on its first overlapped base and -2 on the others
+//     (tk.py:480-485); read backwards that is -4 on the first base met (or on R[wr-1] when the
+//     run comes in from outside the window) and -2 after.  At the column of R[0] every row
+//     stores H, E_in, E2_in; the running maximum is A = the best alignment inside R.
+//   forward sweep (DIR 1): read vs L + u1^k1 + mid + u2^k2hi, window open from a = max(0,|L|-10)
+//     on.  At every requested k2 boundary each row combines with the R side:
+//        max(H, fresh) + Hb,   E_in + Eb_in + (q, +2),   E2_in + E2b_in + (q2, +2)
+//     -- a gap spanning the junction gets one open refunded, and +2 of window score, because
+//     both sides charged a "first overlapped base" --  and V = max(S, B, A) is the cell's
+//     (score, window score).
+//
+// Preconditions checked on the host (else the cell goes to the brute-force kernel):
+// |L| >= 1, |R| >= 2, the k2 values of a (read, k1) form an arithmetic progression.
+#include "nra_device.h"
+
+#ifndef NRA_PART
+#define NRA_PART 0
+#endif
+#define NRA_HAS_PART(n) (NRA_PART == 0 || NRA_PART == (n))
+
+#define JNEG (-(1 << 29))
+#define JBIAS 0x8000
+#define JFLAG_BOUNDARY 0x100
+#define JFLAG_SNAPSHOT 0x200
+
+// base of the strand-oriented read at oriented index idx (0..qlen-1)
+template <bool HAS_N>
+__device__ __forceinline__ int oriented_code(const NraDevRead& rd, const uint32_t* q2bit,
+                                             const uint32_t* qnmask, int idx)
+{
+    if (idx < 0 || idx >= rd.qlen) return NRA_PAD_Q;
+    uint32_t b = rd.qoff + (uint32_t)(rd.rc ? (rd.qlen - 1 - idx) : idx);
+    int c = (q2bit[b >> 4] >> ((b & 15u) * 2u)) & 3u;
+    if (rd.rc) c = 3 - c;
+    if (HAS_N) {
+        if ((qnmask[b >> 5] >> (b & 31u)) & 1u) c = NRA_CODE_N;
+    }
+    return c;
+}
+
+template <int R, bool HAS_N, int DIR>
+__global__ __launch_bounds__(WAVE) void k_joint_sweep(int n_tasks, const NraJointTask* __restrict__ tasks,
+                                                      const NraDevRead* __restrict__ reads,
+                                                      const NraDevRegion* __restrict__ regions,
+                                                      const uint8_t* __restrict__ pool,
+                                                      const uint32_t* __restrict__ q2bit,
+                                                      const uint32_t* __restrict__ qnmask,
+                                                      NraScoreParams sp,
+                                                      int32_t* __restrict__ snap,      // 3 x int32 per read base
+                                                      int32_t* __restrict__ read_a,    // A per read (packed)
+                                                      int32_t* __restrict__ cell_score,
+                                                      int32_t* __restrict__ cell_wscore)
+{
+    const int task = blockIdx.x;
+    if (task >= n_tasks) return;
+    const int lane = threadIdx.x;
+    const NraJointTask tk = tasks[task];
+    const NraDevRead rd = reads[tk.read];
+    const NraDevRegion rg = regions[rd.region];
+    const int Q = rd.qlen;
+    const int lenR = rg.l3;
+    const int wr = imin(10, lenR);                      // window bases inside R
+
+    // template of this sweep
+    const int len1 = DIR ? rg.l1 + rg.m1 * tk.k1 : lenR;                       // piece 1
+    const int len2 = DIR ? rg.l2 + rg.m2 * (tk.k2lo + tk.k2step * (tk.n2 - 1)) : 0;
+    const uint8_t* __restrict__ p1 = pool + (DIR ? rg.p1_off : rg.pr_off);
+    const uint8_t* __restrict__ p2 = pool + rg.p2_off;
+    const int ncols = len1 + len2;
+    const int jfirst = DIR ? len1 + rg.l2 + rg.m2 * tk.k2lo - 1 : 0;            // first boundary column
+    const int jstep = DIR ? rg.m2 * tk.k2step : 1;
+    const int wa = imax(0, rg.l1 - 10);                                        // window start (forward)
+
+    int qc[R];
+#pragma unroll
+    for (int i = 0; i < R; ++i) {
+        const int r = lane * R + i;
+        qc[i] = oriented_code<HAS_N>(rd, q2bit, qnmask, DIR ? r : (r < Q ? Q - 1 - r : -1));
+    }
+
+    const int sA = sp.match << 16, sB = -(sp.mismatch << 16), sN = -(sp.ambi << 16);
+    const int o1 = -(sp.open1 << 16), x1 = -(sp.ext1 << 16);
+    const int o2 = -(sp.open2 << 16), x2 = -(sp.ext2 << 16);
+    const int fresh = JBIAS;
+
+    // forward sweep: the R side, row r pairs with reverse-sweep row Q-2-r.  The stored values carry
+    // one JBIAS each; the combine adds two packed words, so one bias is taken out here, and the
+    // gap-spanning terms get the refunds (one gap open, +2 window).
+    int Hbo[DIR ? R : 1], Ebo[DIR ? R : 1], E2bo[DIR ? R : 1];
+    if (DIR) {
+        const int q1 = (sp.open1 - sp.ext1) << 16, q2 = (sp.open2 - sp.ext2) << 16;
+#pragma unroll
+        for (int i = 0; i < R; ++i) {
+            const int r = lane * R + i;
+            const int a = Q - 2 - r;
+            if (a >= 0) {
+                const int32_t* s3 = snap + ((size_t)rd.qoff + a) * 3;
+                Hbo[i] = s3[0] - JBIAS;
+                Ebo[i] = s3[1] - JBIAS + q1 + 2;
+                E2bo[i] = s3[2] - JBIAS + q2 + 2;
+            } else { Hbo[i] = JNEG; Ebo[i] = JNEG; E2bo[i] = JNEG; }
+        }
+    }
+
+    int Hprev[R], E[R], E2[R];          // after a step: H(i,j), and E_in / E2_in of column j
+#pragma unroll
+    for (int i = 0; i < R; ++i) { Hprev[i] = JNEG; E[i] = JNEG; E2[i] = JNEG; }
+    int Hbot = JNEG, Fout = JNEG, F2out = JNEG, Hup_prev = JNEG;
+    int M = fresh;                      // running lexicographic max of this lane's cells ((0, 0) to start)
+    int accS = JNEG, accB = JNEG;
+    int tt = NRA_PAD_T;
+    int j = -lane;
+    int ncur = 0;                       // boundary counter, meaningful in lane 63 only
+
+    const int nchunks = (ncols + 63 + 63) >> 6;
+    for (int c = 0; c < nchunks; ++c) {
+        const int col = c * 64 + lane;
+        int feed = NRA_PAD_T;
+        if (col < ncols) {
+            feed = col < len1 ? p1[col] : p2[col - len1];
+            if (DIR) {
+                if (col >= jfirst && (col - jfirst) % jstep == 0 && (col - jfirst) / jstep < tk.n2) feed |= JFLAG_BOUNDARY;
+            } else if (col == lenR - 1) feed |= JFLAG_SNAPSHOT | JFLAG_BOUNDARY;
+        }
+#pragma unroll 1   // unrolling the step loop twice takes minutes to compile at R >= 20
+        for (int s = 0; s < 64; ++s) {
+            int F = dpp_shr1(JNEG, Fout);
+            int F2 = dpp_shr1(JNEG, F2out);
+            tt = dpp_shr1(feed, tt);
+            feed = dpp_rol1(feed);
+            const int accS_in = dpp_shr1(JNEG, accS);
+            const int accB_in = dpp_shr1(JNEG, accB);
+            const int tcode = tt & 0xff;
+
+            // window payload increments of THIS column (tk.py:464-485; mirrored for the reverse sweep)
+            int pe, pn, eo, ex, fo, fx;
+            if (DIR) {
+                const bool inw = j >= wa;                                    // every column from wa on
+                pe = inw ? 2 : 0; pn = inw ? -4 : 0;
+                eo = inw ? -4 : 0; ex = inw ? (j == wa ? -4 : -2) : 0;        // deletion onto base j
+                const bool fin = j + 1 > wa;                                 // insertion at ref_pos = j+1
+                fo = fin ? -4 : 0; fx = fin ? -2 : 0;
+            } else {
+                const int p = lenR - 1 - j;                                  // forward position inside R
+                const bool inw = p < wr && p >= 0;
+                pe = inw ? 2 : 0; pn = inw ? -4 : 0;
+                eo = inw ? -4 : 0; ex = inw ? (p == wr - 1 ? -4 : -2) : 0;   // read backwards: first base met
+                const bool fin = p < wr - 1 && p >= 0;                       // insertion before R[p]
+                fo = fin ? -4 : 0; fx = fin ? -2 : 0;
+            }
+            const int s_eq = sA + pe, s_ne = sB + pn, n_eq = sN + pe, n_ne = sN + pn;
+            const int eo1 = o1 + eo, ex1 = x1 + ex, eo2 = o2 + eo, ex2 = x2 + ex;
+            const int fo1 = o1 + fo, fx1 = x1 + fx, fo2 = o2 + fo, fx2 = x2 + fx;
+#define NRA_SUBST(i, out)                                                                          \
+            {                                                                                      \
+                const bool eq_ = qc[i] == tcode;                                                   \
+                out = eq_ ? s_eq : s_ne;                                                           \
+                if (HAS_N) {                                                                       \
+                    if ((qc[i] | tcode) & 4) out = eq_ ? n_eq : n_ne;                              \
+                }                                                                                  \
+            }
+            int sc;
+            NRA_SUBST(0, sc);
+            int d = imax(Hup_prev, fresh) + sc;
+            Hup_prev = dpp_shr1(JNEG, Hbot);
+            int h = JNEG;
+            const bool at_boundary = (tt & JFLAG_BOUNDARY) != 0;
+#pragma unroll
+            for (int i = 0; i < R; ++i) {
+                int d_next = d;
+                if (i + 1 < R) {
+                    NRA_SUBST(i + 1, sc);
+                    d_next = imax(Hprev[i], fresh) + sc;
+                }
+                // E(i,j) from column j-1, lazily: E_in stays in the register for the combine
+                const int ein = imax(E[i] + ex1, Hprev[i] + eo1);
+                const int e2in = imax(E2[i] + ex2, Hprev[i] + eo2);
+                h = imax(imax(d, ein), F);
+                h = imax(imax(h, e2in), F2);
+                M = imax(M, h);
+                Hprev[i] = h;
+                E[i] = ein;
+                E2[i] = e2in;
+                F = imax(F + fx1, h + fo1);
+                F2 = imax(F2 + fx2, h + fo2);
+                d = d_next;
+            }
+#undef NRA_SUBST
+            int tS = JNEG;
+            if (DIR) {
+                if (__builtin_amdgcn_ballot_w64(at_boundary) != 0) {
+#pragma unroll
+                    for (int i = 0; i < R; ++i) {
+                        const int t1 = imax(Hprev[i], fresh) + Hbo[i];
+                        const int t2 = E[i] + Ebo[i];
+                        const int t3 = E2[i] + E2bo[i];
+                        tS = imax(imax(tS, t1), imax(t2, t3));
+                    }
+                }
+            } else if (tt & JFLAG_SNAPSHOT) {
+#pragma unroll
+                for (int i = 0; i < R; ++i) {
+                    const int a = lane * R + i;
+                    if (a < Q) {
+                        int32_t* s3 = snap + ((size_t)rd.qoff + a) * 3;
+                        s3[0] = Hprev[i]; s3[1] = E[i]; s3[2] = E2[i];
+                    }
+                }
+            }
+            Hbot = h; Fout = F; F2out = F2;
+            accS = imax(accS_in, tS);
+            accB = imax(accB_in, M);
+
+            if (lane == 63 && at_boundary) {
+                if (DIR == 0) {
+                    read_a[tk.read] = accB;                  // best alignment inside R (packed)
+                } else {
+                    const int n = ncur++;
+                    const int A = read_a[tk.read];
+                    const int V = imax(imax(accS, accB), A);
+                    const int scv = V >> 16;
+                    const int lo = sp.min_score > 1 ? sp.min_score : 1;
+                    const int idx = tk.out + n;
+                    if (scv >= lo) { cell_score[idx] = scv; cell_wscore[idx] = (V & 0xffff) - JBIAS; }
+                    else { cell_score[idx] = -1; cell_wscore[idx] = 0; }
+                }
+            }
+            ++j;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------
+template <int DIR>
+static int launch_joint(int R, int has_n, hipStream_t st, int n_tasks, const NraJointTask* tasks,
+                        const NraDevRead* reads, const NraDevRegion* regions, const uint8_t* pool,
+                        const uint32_t* q2bit, const uint32_t* qnmask, NraScoreParams sp,
+                        int32_t* snap, int32_t* read_a, int32_t* cell_score, int32_t* cell_wscore)
+{
+    if (n_tasks <= 0) return 0;
+#define CASE(r)                                                                                     \
+    case r:                                                                                         \
+        if (has_n) k_joint_sweep<r, true, DIR><<<n_tasks, WAVE, 0, st>>>(n_tasks, tasks, reads, regions, pool, q2bit, qnmask, sp, snap, read_a, cell_score, cell_wscore); \
+        else k_joint_sweep<r, false, DIR><<<n_tasks, WAVE, 0, st>>>(n_tasks, tasks, reads, regions, pool, q2bit, qnmask, sp, snap, read_a, cell_score, cell_wscore);       \
+        break;
+    switch (R) {
+        NRA_R_LIST(CASE)
+    default: return (int)hipErrorInvalidValue;
+    }
+#undef CASE
+    return (int)hipGetLastError();
+}
+
+#if NRA_HAS_PART(7)
+extern "C" int nra_launch_joint_bwd(int R, int has_n, hipStream_t st, int n_tasks, const NraJointTask* tasks,
+                                    const NraDevRead* reads, const NraDevRegion* regions, const uint8_t* pool,
+                                    const uint32_t* q2bit, const uint32_t* qnmask, NraScoreParams sp,
+                                    int32_t* snap, int32_t* read_a)
+{
+    return launch_joint<0>(R, has_n, st, n_tasks, tasks, reads, regions, pool, q2bit, qnmask, sp, snap, read_a, nullptr, nullptr);
+}
+#endif
+#if NRA_HAS_PART(8)
+extern "C" int nra_launch_joint_fwd(int R, int has_n, hipStream_t st, int n_tasks, const NraJointTask* tasks,
+                                    const NraDevRead* reads, const NraDevRegion* regions, const uint8_t* pool,
+                                    const uint32_t* q2bit, const uint32_t* qnmask, NraScoreParams sp,
+                                    int32_t* snap, int32_t* read_a, int32_t* cell_score, int32_t* cell_wscore)
+{
+    return launch_joint<1>(R, has_n, st, n_tasks, tasks, reads, regions, pool, q2bit, qnmask, sp, snap, read_a, cell_score, cell_wscore);
+}
+#endif

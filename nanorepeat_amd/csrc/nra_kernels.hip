@@ -146,7 +146,8 @@ __global__ __launch_bounds__(WAVE) void k_score_pk16(int n_tasks, const NraPairT
     for (int off = 32; off > 0; off >>= 1) m = as_i(pmax(as_s(m), as_s(__shfl_xor(m, off, WAVE))));
     if (lane == 0) {
         const int sa = (m & 0xffff) - KB, sb = ((m >> 16) & 0xffff) - KB;
-        const int lo = sp.min_score > 1 ? sp.min_score : 1;
+        // flags bit 1: raw scores (the strand probe compares them even below min_dp_score)
+        const int lo = (tk.flags & 2) ? 0 : (sp.min_score > 1 ? sp.min_score : 1);
         out_score[tk.out_a] = sa >= lo ? sa : -1;
         if (has_b) out_score[tk.out_b] = sb >= lo ? sb : -1;
     }

@@ -454,3 +454,43 @@ def test_1d_long_reads_over_one_register_block(capi, oracle):
     with pytest.raises(capi.NraError) as e:
         capi.round3_1d([(L, u, R)], reads[:1], kmin[:1], kmax[:1], flags=capi.F_BRUTE_FORCE)
     assert e.value.code == -3
+
+
+# ------------------------------------------------------------------ 2D junction decomposition
+def test_2d_decomposition_matches_oracle_and_brute_force(capi, oracle):
+    """The (read, k1)-row sweeps give the oracle's per-cell (score, window score) and per-read
+    selection, like the brute-force per-cell kernel, for grid-ordered and arbitrary cell lists."""
+    for seed, alleles, anchor in ((61, ((6, 4), (11, 3)), 300), (62, ((17, 10), (30, 7)), 1000), (63, ((3, 9), (8, 2)), 40)):
+        j = synth.make_joint(8, alleles=alleles, read_len=500 if anchor < 1000 else 800, read_sd=30, anchor=anchor, seed=seed)
+        cr, k1, k2 = _cells(j, step=2)
+        o = oracle.joint_2d(j["region"], j["reads"], cr, k1, k2)
+        for flags in (0, capi.F_BRUTE_FORCE):
+            g = capi.joint_2d(j["region"], j["reads"], cr, k1, k2, flags=flags)
+            for k in KEYS_2D:
+                assert np.array_equal(g[k], o[k]), (seed, flags, k, np.nonzero(g[k] != o[k])[0][:8], g[k][:10], o[k][:10])
+    # cells of a read in arbitrary order (runs of length 1, descending k2, repeated cells)
+    j = synth.make_joint(5, alleles=((6, 4), (11, 3)), read_len=450, read_sd=20, anchor=200, seed=64)
+    rng = np.random.default_rng(6)
+    cr, k1, k2 = [], [], []
+    for r in range(5):
+        cells = [(int(a), int(b)) for a in range(2, 14, 3) for b in range(0, 8, 2)]
+        rng.shuffle(cells)
+        cells += cells[:3]
+        for a, b in cells:
+            cr.append(r); k1.append(a); k2.append(b)
+    o = oracle.joint_2d(j["region"], j["reads"], cr, k1, k2)
+    g = capi.joint_2d(j["region"], j["reads"], cr, k1, k2)
+    for k in KEYS_2D:
+        assert np.array_equal(g[k], o[k]), k
+    # N bases, very short flanks (|R| = 2 is the smallest the decomposition takes; |R| = 1 falls back)
+    left, u1, mid, u2, right = j["region"]
+    for Lx, Rx in ((left[-12:], right[:2]), (left[-3:], right[:11]), (left[-1:], right[:1])):
+        reads = [Lx + u1 * 7 + mid + u2 * 5 + Rx, synth.revcomp(Lx + u1 * 9 + mid + u2 * 3 + Rx),
+                 "ACGTNNACGT" + u1 * 5 + "N" + mid + u2 * 4 + Rx]
+        cr2 = [r for r in range(3) for _ in range(20)]
+        a2 = [a for _ in range(3) for a in range(3, 13, 2) for _ in range(4)]
+        b2 = [b for _ in range(3) for _ in range(5) for b in range(1, 9, 2)]
+        o = oracle.joint_2d((Lx, u1, mid, u2, Rx), reads, cr2, a2, b2, sc=oracle.default_scoring(min_dp_score=20))
+        g = capi.joint_2d((Lx, u1, mid, u2, Rx), reads, cr2, a2, b2, sc=capi.default_scoring(min_dp_score=20))
+        for k in KEYS_2D:
+            assert np.array_equal(g[k], o[k]), (len(Lx), len(Rx), k, g[k][:10], o[k][:10])
