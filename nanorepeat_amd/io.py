@@ -1,0 +1,111 @@
+"""Input ingestion for the rows around the path: repeat-region BED, reference
+FASTA, region FASTQ, and flank extraction.  Mirrors repeat_region.py:195-204, tk.py:68-75,
+130-158 and nanoRepeat_bam.py:76-137 with the reference's names; errors raise instead of
+calling sys.exit().  BAM input needs pysam, which is absent offline: reads enter as FASTQ/FASTA
+or as a {name: sequence} dict."""
+import gzip
+
+from .round3 import RepeatRegion
+
+MIN_ANCHOR_LEN = 10
+
+
+def gzopen(in_file, mode="rt"):
+    """tk.gzopen (tk.py:68-75): transparent .gz."""
+    if str(in_file).endswith(".gz"):
+        return gzip.open(in_file, mode)
+    return open(in_file, mode)
+
+
+def read_repeat_region_file(repeat_region_file, no_details=False):
+    """repeat_region.py:195-204: one RepeatRegion per line (also the last line without a newline,
+    and CRLF files like the reference's example_data/HTT_repeat_region.bed)."""
+    with open(repeat_region_file, "r") as f:
+        lines = list(f)
+    return [RepeatRegion(line, no_details) for line in lines]
+
+
+def fasta_file2dict(fasta_file):
+    """tk.fasta_file2dict (tk.py:130-158): name = first word of the header, sequence upper-cased."""
+    fasta_dict = dict()
+    curr_name, chunks = "", []
+    with gzopen(fasta_file) as fp:
+        for line in fp:
+            line = line.strip()
+            if not line:
+                continue
+            if line[0] == ">":
+                if chunks and curr_name:
+                    if curr_name in fasta_dict:
+                        raise ValueError(f"duplicate sequence name in {fasta_file}: {curr_name}")
+                    fasta_dict[curr_name] = "".join(chunks)
+                curr_name, chunks = line[1:].split()[0], []
+                continue
+            chunks.append(line.upper())
+    if chunks and curr_name:
+        fasta_dict[curr_name] = "".join(chunks)
+    return fasta_dict
+
+
+def read_fastq(fastq_file):
+    """{read_name: sequence} in file order (4-line records; name = first word of the header)."""
+    reads = dict()
+    with gzopen(fastq_file) as fp:
+        while True:
+            l1, l2, l3, l4 = fp.readline(), fp.readline(), fp.readline(), fp.readline()
+            if not l1 or not l2 or not l3 or not l4:
+                break
+            reads[l1.strip()[1:].split()[0]] = l2.strip()
+    return reads
+
+
+def extract_ref_sequence(ref_fasta_dict, repeat_region, anchor_len=1000):
+    """nanoRepeat_bam.py:76-137: flanks of at most anchor_len bases on either side (clamped to the
+    chromosome), with the chr-prefix fallback and the reference's bounds checks."""
+    repeat_region.anchor_len = max(anchor_len, MIN_ANCHOR_LEN)
+    chr_name = repeat_region.chrom
+    if chr_name not in ref_fasta_dict:
+        chr_name = chr_name[3:] if chr_name[0:3] == "chr" else "chr" + chr_name
+    if chr_name not in ref_fasta_dict:
+        raise KeyError(f"chromosome {repeat_region.chrom} of the repeat region bed file is not in the reference fasta file")
+    chr_seq = ref_fasta_dict[chr_name]
+    chr_len = len(chr_seq)
+    if repeat_region.start_pos > chr_len:
+        raise ValueError(f"the repeat start position is larger than chromosome length: {repeat_region.start_pos}")
+    if repeat_region.start_pos < 0:
+        raise ValueError("the repeat start position < 0")
+    if repeat_region.end_pos > chr_len + 1:
+        raise ValueError(f"the repeat end position is larger than chromosome length: {repeat_region.end_pos}")
+    if repeat_region.end_pos < repeat_region.start_pos:
+        raise ValueError("end position is smaller than start position")
+    start_pos = max(0, repeat_region.start_pos - repeat_region.anchor_len)
+    end_pos = min(chr_len, repeat_region.end_pos + repeat_region.anchor_len)
+    repeat_region.left_anchor_seq = chr_seq[start_pos:repeat_region.start_pos]
+    repeat_region.left_anchor_len = len(repeat_region.left_anchor_seq)
+    repeat_region.right_anchor_seq = chr_seq[repeat_region.end_pos:end_pos]
+    repeat_region.right_anchor_len = len(repeat_region.right_anchor_seq)
+    repeat_region.mid_ref_seq = chr_seq[repeat_region.start_pos:repeat_region.end_pos]
+    if repeat_region.left_anchor_len == 0 and repeat_region.right_anchor_len == 0:
+        raise ValueError("there is no flanking sequence around the repeat region")
+    if repeat_region.left_anchor_len < MIN_ANCHOR_LEN and repeat_region.right_anchor_len < MIN_ANCHOR_LEN:
+        raise ValueError(f"both left and right flanking sequences are less than {MIN_ANCHOR_LEN} bp")
+
+
+def edit_distance(a, b):
+    """Levenshtein distance (the reference imports the Levenshtein package, absent offline)."""
+    prev = list(range(len(b) + 1))
+    for i, ca in enumerate(a, 1):
+        cur = [i]
+        for j, cb in enumerate(b, 1):
+            cur.append(min(prev[j] + 1, cur[j - 1] + 1, prev[j - 1] + (ca != cb)))
+        prev = cur
+    return prev[-1]
+
+
+def check_repeat_motif_in_ref(repeat_region):
+    """nanoRepeat_bam.py:139-154: the reference locus must look like the motif (edit distance of
+    the pure repeat to the reference slice at most a quarter of the shorter one)."""
+    mid, unit = repeat_region.mid_ref_seq, repeat_region.repeat_unit_seq
+    pure = unit * int(len(mid) / len(unit))
+    repeat_region.ref_has_issue = edit_distance(pure, mid) * 4 > min(len(pure), len(mid))
+    return not repeat_region.ref_has_issue

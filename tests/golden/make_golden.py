@@ -569,15 +569,49 @@ def gen_upstream(tmp):
     return fx
 
 
+# --------------------------------------------------------------------------- ingestion (8f-3)
+def gen_io(tmp):
+    fx = {}
+    bed_text = open("/root/reference/example_data/HTT_repeat_region.bed", "rb").read().decode()
+    bed = os.path.join(tmp, "r.bed"); open(bed, "wb").write(bed_text.encode())
+    regs = ref_rr.read_repeat_region_file(bed, False)
+    fx["bed"] = {"text": bed_text, "regions": [[r.chrom, r.start_pos, r.end_pos, r.repeat_unit_seq, r.to_unique_id()] for r in regs]}
+    rng = random.Random(5)
+    fa = os.path.join(tmp, "ref.fa")
+    seqs = {"chr4": rand_seq(3000, rng), "7": rand_seq(500, rng), "chrM extra words": rand_seq(90, rng).lower()}
+    with open(fa, "w") as f:
+        for n, s in seqs.items():
+            f.write(f">{n}\n")
+            for i in range(0, len(s), 70):
+                f.write(s[i:i + 70] + "\n")
+            f.write("\n")
+    d = tk.fasta_file2dict(fa)
+    fx["fasta"] = {"text": open(fa).read(), "names": list(d), "lens": [len(v) for v in d.values()],
+                   "sha1": [hashlib.sha1(v.encode()).hexdigest() for v in d.values()]}
+    cases = []
+    for chrom, st, en, anchor in [("chr4", 1200, 1260, 1000), ("4", 1200, 1260, 1000), ("chr4", 300, 360, 1000),
+                                  ("chr4", 2900, 2960, 1000), ("chr7", 100, 130, 50), ("7", 0, 30, 50),
+                                  ("chr4", 1200, 1260, 5), ("chr4", 2990, 3001, 1000)]:
+        rr = ref_rr.RepeatRegion(f"{chrom}\t{st}\t{en}\tCAG")
+        rr.anchor_len = anchor
+        ref_bam.extract_ref_sequence(d, rr)
+        cases.append({"chrom": chrom, "start": st, "end": en, "anchor_len": anchor,
+                      "left": rr.left_anchor_seq, "right": rr.right_anchor_seq, "mid": rr.mid_ref_seq,
+                      "anchor_len_after": rr.anchor_len})
+    fx["flanks"] = cases
+    return fx
+
+
 def main():
     tmp = tempfile.mkdtemp(prefix="nr_golden_")
     try:
         one = gen_1d(tmp)
         two = gen_2d(tmp)
         up = gen_upstream(tmp)
+        io_fx = gen_io(tmp)
     finally:
         shutil.rmtree(tmp, ignore_errors=True)
-    for name, fx in (("ref_1d.json", one), ("ref_2d.json", two), ("ref_upstream.json", up)):
+    for name, fx in (("ref_1d.json", one), ("ref_2d.json", two), ("ref_upstream.json", up), ("ref_io.json", io_fx)):
         with open(os.path.join(HERE, name), "w") as f:
             json.dump(fx, f, indent=1, sort_keys=True)
             f.write("\n")

@@ -1,0 +1,117 @@
+"""Ingestion helpers against fixtures from the reference's Python, and the
+region pipeline (steps 1-3) from files."""
+import json
+import hashlib
+import os
+
+import numpy as np
+import pytest
+
+from nanorepeat_amd import io as IO, pipeline, round3 as R3, synth
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+@pytest.fixture(scope="module")
+def golden():
+    return json.load(open(os.path.join(GOLDEN, "ref_io.json")))
+
+
+def test_bed_reader_matches_reference(golden, tmp_path):
+    p = tmp_path / "r.bed"
+    p.write_bytes(golden["bed"]["text"].encode())            # CRLF, no trailing newline
+    regs = IO.read_repeat_region_file(str(p))
+    got = [[r.chrom, r.start_pos, r.end_pos, r.repeat_unit_seq, r.to_unique_id()] for r in regs]
+    assert got == golden["bed"]["regions"]
+    with pytest.raises(ValueError):
+        R3.RepeatRegion("chr1\t5\t9")
+
+
+def test_fasta_reader_and_flanks_match_reference(golden, tmp_path):
+    p = tmp_path / "ref.fa"
+    p.write_text(golden["fasta"]["text"])
+    d = IO.fasta_file2dict(str(p))
+    assert list(d) == golden["fasta"]["names"]
+    assert [len(v) for v in d.values()] == golden["fasta"]["lens"]
+    assert [hashlib.sha1(v.encode()).hexdigest() for v in d.values()] == golden["fasta"]["sha1"]
+    import gzip
+    gz = tmp_path / "ref.fa.gz"
+    with gzip.open(gz, "wt") as f:
+        f.write(golden["fasta"]["text"])
+    assert IO.fasta_file2dict(str(gz)) == d
+    for c in golden["flanks"]:
+        rr = R3.RepeatRegion(f"{c['chrom']}\t{c['start']}\t{c['end']}\tCAG")
+        IO.extract_ref_sequence(d, rr, c["anchor_len"])
+        assert (rr.left_anchor_seq, rr.right_anchor_seq, rr.mid_ref_seq) == (c["left"], c["right"], c["mid"])
+        assert rr.anchor_len == c["anchor_len_after"]
+    with pytest.raises(KeyError):
+        IO.extract_ref_sequence(d, R3.RepeatRegion("chr9\t1\t5\tCAG"))
+    with pytest.raises(ValueError):
+        IO.extract_ref_sequence(d, R3.RepeatRegion("chr4\t3500\t3600\tCAG"))
+
+
+def test_motif_check_and_edit_distance():
+    assert IO.edit_distance("kitten", "sitting") == 3 and IO.edit_distance("", "abc") == 3
+    rr = R3.RepeatRegion("c\t0\t12\tCAG"); rr.mid_ref_seq = "CAGCAGCAACAG"
+    assert IO.check_repeat_motif_in_ref(rr)
+    rr.mid_ref_seq = "ACGTTGCATGCA"
+    assert not IO.check_repeat_motif_in_ref(rr) and rr.ref_has_issue
+
+
+def _make_files(tmp_path, n_regions=3, reads_per_region=8):
+    rng = np.random.default_rng(77)
+    chrom = synth.rand_seq(rng, 600)
+    bed, truth, fastqs = [], [], []
+    for g in range(n_regions):
+        unit = ["TATTG", "CAG", "AAGGG"][g % 3]
+        k_ref = 6 + g
+        start = len(chrom)
+        chrom += unit * k_ref + synth.rand_seq(rng, 700)
+        bed.append(f"chrS\t{start}\t{start + len(unit) * k_ref}\t{unit}")
+    (tmp_path / "ref.fa").write_text(">chrS test\n" + "\n".join(chrom[i:i + 60] for i in range(0, len(chrom), 60)) + "\n")
+    (tmp_path / "regions.bed").write_text("\r\n".join(bed))
+    for g, line in enumerate(bed):
+        _, st, en, unit = line.split("\t"); st, en = int(st), int(en)
+        alleles = (7 + g, 19 + 2 * g)
+        lines, kt = [], {}
+        for i in range(reads_per_region):
+            k = alleles[i % 2]
+            s = chrom[st - 450:st] + unit * k + chrom[en:en + 450]
+            s = synth.apply_errors(rng, s, "ont_q20")
+            if i % 3 == 0:
+                s = synth.revcomp(s)
+            lines.append(f"@g{g}r{i}\n{s}\n+\n{'I' * len(s)}\n"); kt[f"g{g}r{i}"] = k
+        (tmp_path / f"region{g}.fastq").write_text("".join(lines))
+        truth.append(kt)
+    return truth
+
+
+def _run_pipeline(tmp_path, **kw):
+    ref = IO.fasta_file2dict(str(tmp_path / "ref.fa"))
+    regions = IO.read_repeat_region_file(str(tmp_path / "regions.bed"))
+    reads = []
+    for g, rr in enumerate(regions):
+        IO.extract_ref_sequence(ref, rr, anchor_len=400)
+        assert IO.check_repeat_motif_in_ref(rr)
+        reads.append(IO.read_fastq(str(tmp_path / f"region{g}.fastq")))
+    texts = pipeline.quantify_regions(regions, reads, "ont_q20", **kw)
+    return regions, texts
+
+
+def test_pipeline_from_files_with_oracle(oracle, tmp_path):
+    truth = _make_files(tmp_path)
+    regions, texts = _run_pipeline(tmp_path, aligner=oracle.align_pairs, scorer=oracle.round3_1d)
+    for rr, kt, text in zip(regions, truth, texts):
+        assert len(rr.read_dict) == len(kt)
+        sizes = {l.split("\t")[0]: float(l.split("\t")[1]) for l in text.strip().split("\n")[2:]}
+        assert set(sizes) == set(kt)
+        assert np.mean([abs(sizes[n] - kt[n]) <= 1 for n in kt]) >= 0.85
+        assert text.startswith(f"##Repeat_Region={rr.to_unique_id()}\n#Read_Name\tRepeat_Size\n")
+
+
+@pytest.mark.gpu
+def test_pipeline_from_files_gpu_equals_oracle(capi, oracle, tmp_path):
+    _make_files(tmp_path)
+    _, t_gpu = _run_pipeline(tmp_path)
+    _, t_cpu = _run_pipeline(tmp_path, aligner=oracle.align_pairs, scorer=oracle.round3_1d)
+    assert t_gpu == t_cpu
