@@ -195,6 +195,20 @@ int nra_align_pairs(int device,
                     const nra_scoring_t* sc, int32_t flags,
                     int32_t* score, int32_t* tstart, int32_t* tend);
 
+/* ---- alignment paths in the reference's wire format: the same pairs as
+ *      nra_align_pairs, plus the query extents and a minimap2-style --eqx CIGAR ("12=1X3I4D")
+ *      of the co-optimal path the oracle's traceback picks (paf.py:32-79 carries it as cg:Z).
+ * cigar: caller buffer of cigar_cap bytes; pair i's NUL-terminated string starts at
+ * cigar + cigar_off[i] (cigar_off has n_pairs + 1 entries; empty string when no record).
+ * The trace needs qlen * tlen bytes of device memory per pair (8 GiB per call at most). */
+int nra_align_pairs_cigar(int device,
+                          int32_t n_seqs, const char* seqs, const int64_t* seq_off,
+                          int64_t n_pairs, const int32_t* pair_query, const int32_t* pair_target,
+                          const nra_scoring_t* sc, int32_t flags,
+                          int32_t* score, int32_t* tstart, int32_t* tend,
+                          int32_t* qstart, int32_t* qend,
+                          char* cigar, int64_t cigar_cap, int64_t* cigar_off);
+
 /* ---- device-resident batches (what bench.py times): create = encode + H2D,
  *      run = kernels only (asynchronous on the batch's own stream), fetch = D2H ------- */
 int  nra_batch1d_create(int device,

@@ -20,7 +20,7 @@ F_TEST_CHAIN = 8      # testing only: every read in chained 128-row blocks
 
 # every symbol include/nanorepeat_amd.h declares
 EXPORTS = ("nra_abi_version", "nra_version", "nra_last_error", "nra_device_count",
-           "nra_default_scoring", "nra_round3_1d", "nra_joint_2d", "nra_align_pairs", "nra_batch1d_create",
+           "nra_default_scoring", "nra_round3_1d", "nra_joint_2d", "nra_align_pairs", "nra_align_pairs_cigar", "nra_batch1d_create",
            "nra_batch2d_create", "nra_batch_run", "nra_batch_sync", "nra_batch_stats",
            "nra_batch1d_fetch", "nra_batch2d_fetch", "nra_batch_destroy")
 
@@ -92,6 +92,10 @@ def load():
     lib.nra_align_pairs.restype = C.c_int
     lib.nra_align_pairs.argtypes = [C.c_int, C.c_int32, C.c_char_p, pi64, C.c_int64, pi32, pi32,
                                     C.POINTER(Scoring), C.c_int32, pi32, pi32, pi32]
+    lib.nra_align_pairs_cigar.restype = C.c_int
+    lib.nra_align_pairs_cigar.argtypes = [C.c_int, C.c_int32, C.c_char_p, pi64, C.c_int64, pi32, pi32,
+                                          C.POINTER(Scoring), C.c_int32, pi32, pi32, pi32, pi32, pi32,
+                                          C.c_char_p, C.c_int64, pi64]
     lib.nra_batch1d_create.restype = C.c_int
     lib.nra_batch1d_create.argtypes = [C.c_int, C.POINTER(Region), C.c_int32, C.c_int32, C.c_char_p,
                                        pi64, pi32, pi32, pi32, C.POINTER(Scoring), C.c_int32,
@@ -238,6 +242,28 @@ def align_pairs(seqs, pair_query, pair_target, sc=None, flags=0, device=0):
     _check(lib.nra_align_pairs(device, len(seqs), data, _ptr(off, C.c_int64), n, _ptr(pq, C.c_int32),
                                _ptr(pt, C.c_int32), C.byref(sc), flags, _ptr(out["score"], C.c_int32),
                                _ptr(out["tstart"], C.c_int32), _ptr(out["tend"], C.c_int32)))
+    return out
+
+
+def align_pairs_cigar(seqs, pair_query, pair_target, sc=None, flags=0, device=0):
+    """nra_align_pairs_cigar: like align_pairs, plus qstart/qend and the --eqx CIGAR of each pair."""
+    lib = load()
+    sc = sc or default_scoring()
+    data, off = pack_reads(seqs)
+    pq = np.ascontiguousarray(pair_query, np.int32)
+    pt = np.ascontiguousarray(pair_target, np.int32)
+    n = len(pq)
+    out = {k: np.zeros(n, np.int32) for k in ("score", "tstart", "tend", "qstart", "qend")}
+    lens = np.diff(off)
+    cap = int(sum(12 * (int(lens[q]) + int(lens[t])) + 16 for q, t in zip(pq, pt))) + 16
+    buf = C.create_string_buffer(cap)
+    coff = np.zeros(n + 1, np.int64)
+    _check(lib.nra_align_pairs_cigar(device, len(seqs), data, _ptr(off, C.c_int64), n, _ptr(pq, C.c_int32),
+                                     _ptr(pt, C.c_int32), C.byref(sc), flags,
+                                     *[_ptr(out[k], C.c_int32) for k in ("score", "tstart", "tend", "qstart", "qend")],
+                                     buf, cap, _ptr(coff, C.c_int64)))
+    raw = buf.raw
+    out["cigar"] = [raw[coff[i]:coff[i + 1] - 1].decode() for i in range(n)]
     return out
 
 

@@ -953,79 +953,96 @@ int nra_joint_2d(int device, const nra_joint_region_t* region, int32_t n_reads, 
 }
 
 // ---- generic pairs --------------------------------------------------------------------
-int nra_align_pairs(int device, int32_t n_seqs, const char* seqs, const int64_t* seq_off, int64_t n_pairs,
-                    const int32_t* pair_query, const int32_t* pair_target, const nra_scoring_t* sc,
-                    int32_t flags, int32_t* score, int32_t* tstart, int32_t* tend)
+namespace {
+
+struct PairSetup {
+    std::vector<uint8_t> pool;
+    std::vector<NraDevRegion> dregs;
+    std::vector<NraDevRead> dreads;
+    std::vector<uint32_t> q2bit, nmask;
+    std::vector<int32_t> as_query, as_target;   // sequence -> read / region index
+    bool has_n = false;
+};
+
+int prepare_pairs(int device, int32_t n_seqs, const char* seqs, const int64_t* seq_off, int64_t n_pairs,
+                  const int32_t* pair_query, const int32_t* pair_target, const nra_scoring_t* sc, PairSetup& ps)
 {
-    (void)flags;
     if (n_seqs < 0 || n_pairs < 0) return fail(NRA_E_ARG, "negative count");
     if (n_seqs > 0 && (!seqs || !seq_off)) return fail(NRA_E_ARG, "NULL sequence array");
-    if (n_pairs > 0 && (!pair_query || !pair_target || !score || !tstart || !tend)) return fail(NRA_E_ARG, "NULL pair array");
+    if (n_pairs > 0 && (!pair_query || !pair_target)) return fail(NRA_E_ARG, "NULL pair array");
     if (n_pairs > 0x7ff00000ll) return fail(NRA_E_RANGE, "too many pairs");
     if (!scoring_ok(sc)) return fail(NRA_E_ARG, "scoring parameters out of range");
-    if (n_pairs == 0) return NRA_OK;
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
         return fail(NRA_E_DEVICE, "no HIP device: nanorepeat_amd has no CPU path");
     if (device < 0 || device >= ndev) return fail(NRA_E_ARG, "device index out of range");
     HIP_TRY(hipSetDevice(device));
 
-    // which sequences are queries (2-bit pool, <= 3072 bases) / targets (byte pool, <= 65000)
-    std::vector<int32_t> as_query((size_t)n_seqs, -1), as_target((size_t)n_seqs, -1);
+    // which sequences are queries (2-bit pool, one register block) / targets (byte pool, <= 65000)
+    ps.as_query.assign((size_t)n_seqs, -1); ps.as_target.assign((size_t)n_seqs, -1);
     for (int64_t i = 0; i < n_pairs; ++i) {
         const int32_t q = pair_query[i], t = pair_target[i];
         if (q < 0 || q >= n_seqs || t < 0 || t >= n_seqs) return fail(NRA_E_ARG, "pair index out of range");
-        as_query[q] = 0; as_target[t] = 0;
+        ps.as_query[q] = 0; ps.as_target[t] = 0;
     }
-    std::vector<uint8_t> pool;
-    std::vector<NraDevRegion> dregs;
-    std::vector<NraDevRead> dreads;
-    std::vector<uint32_t> q2bit, nmask;
-    bool has_n = false;
     uint64_t base = 0;
     for (int32_t s = 0; s < n_seqs; ++s) {
         const int64_t len = seq_off[s + 1] - seq_off[s];
         if (len < 0) return fail(NRA_E_ARG, "seq_off must be non-decreasing");
-        if (as_target[s] == 0) {
+        if (ps.as_target[s] == 0) {
             if (len > NRA_MAX_TLEN) return fail(NRA_E_RANGE, "target longer than " + std::to_string(NRA_MAX_TLEN));
             NraDevRegion d{};
-            d.p1_off = pool_append(pool, seqs + seq_off[s], (int32_t)len, nullptr, 0, 0, has_n);
-            d.p2_off = d.p3_off = d.pr_off = (uint32_t)pool.size();
+            d.p1_off = pool_append(ps.pool, seqs + seq_off[s], (int32_t)len, nullptr, 0, 0, ps.has_n);
+            d.p2_off = d.p3_off = d.pr_off = (uint32_t)ps.pool.size();
             d.l1 = (int32_t)len; d.m1 = 0; d.l2 = 0; d.m2 = 0; d.l3 = 0;
-            as_target[s] = (int32_t)dregs.size();
-            dregs.push_back(d);
-            if (pool.size() > 0xfff00000ull) return fail(NRA_E_RANGE, "target pool exceeds 4 GB");
+            ps.as_target[s] = (int32_t)ps.dregs.size();
+            ps.dregs.push_back(d);
+            if (ps.pool.size() > 0xfff00000ull) return fail(NRA_E_RANGE, "target pool exceeds 4 GB");
         }
-        if (as_query[s] == 0) {
+        if (ps.as_query[s] == 0) {
             if (len > NRA_MAX_QLEN_1BLOCK) return fail(NRA_E_RANGE, "query longer than " + std::to_string(NRA_MAX_QLEN_1BLOCK));
             NraDevRead r{};
             r.qoff = (uint32_t)base; r.qlen = (int32_t)len; r.region = 0; r.rc = 0;
-            as_query[s] = (int32_t)dreads.size();
-            dreads.push_back(r);
+            ps.as_query[s] = (int32_t)ps.dreads.size();
+            ps.dreads.push_back(r);
             base += ((uint64_t)len + 31) / 32 * 32;
             if (base > 0xfff00000ull) return fail(NRA_E_RANGE, "query pool exceeds 4G bases");
         }
     }
-    pool.push_back(0);
-    q2bit.assign((size_t)(base / 16) + 1, 0);
-    nmask.assign((size_t)(base / 32) + 1, 0);
+    ps.pool.push_back(0);
+    ps.q2bit.assign((size_t)(base / 16) + 1, 0);
+    ps.nmask.assign((size_t)(base / 32) + 1, 0);
     for (int32_t s = 0; s < n_seqs; ++s) {
-        if (as_query[s] < 0) continue;
-        const NraDevRead& r = dreads[as_query[s]];
+        if (ps.as_query[s] < 0) continue;
+        const NraDevRead& r = ps.dreads[ps.as_query[s]];
         const char* p = seqs + seq_off[s];
         for (int32_t i = 0; i < r.qlen; ++i) {
             uint8_t c = encode_base(p[i]);
             const uint32_t b = r.qoff + (uint32_t)i;
-            if (c >= 4) { nmask[b >> 5] |= 1u << (b & 31); has_n = true; c = 0; }
-            q2bit[b >> 4] |= (uint32_t)c << ((b & 15) * 2);
+            if (c >= 4) { ps.nmask[b >> 5] |= 1u << (b & 31); ps.has_n = true; c = 0; }
+            ps.q2bit[b >> 4] |= (uint32_t)c << ((b & 15) * 2);
         }
     }
+    return NRA_OK;
+}
+
+}  // namespace
+
+int nra_align_pairs(int device, int32_t n_seqs, const char* seqs, const int64_t* seq_off, int64_t n_pairs,
+                    const int32_t* pair_query, const int32_t* pair_target, const nra_scoring_t* sc,
+                    int32_t flags, int32_t* score, int32_t* tstart, int32_t* tend)
+{
+    (void)flags;
+    if (n_pairs > 0 && (!score || !tstart || !tend)) return fail(NRA_E_ARG, "NULL output array");
+    PairSetup ps;
+    int rc = prepare_pairs(device, n_seqs, seqs, seq_off, n_pairs, pair_query, pair_target, sc, ps);
+    if (rc || n_pairs == 0) return rc;
     // tasks by rows-per-lane bucket of the query
     std::vector<std::vector<NraTask>> by_bucket((size_t)kNumR);
     for (int64_t i = 0; i < n_pairs; ++i) {
-        const int32_t qi = as_query[pair_query[i]];
-        if (dreads[qi].qlen == 0) continue;
-        by_bucket[rows_for_qlen(dreads[qi].qlen)].push_back(NraTask{qi, as_target[pair_target[i]], -1, (int32_t)i});
+        const int32_t qi = ps.as_query[pair_query[i]];
+        if (ps.dreads[qi].qlen == 0) continue;
+        by_bucket[rows_for_qlen(ps.dreads[qi].qlen)].push_back(NraTask{qi, ps.as_target[pair_target[i]], -1, (int32_t)i});
     }
     std::vector<NraTask> tasks;
     std::vector<int32_t> counts;
@@ -1038,8 +1055,8 @@ int nra_align_pairs(int device, int32_t n_seqs, const char* seqs, const int64_t*
     }
     DevBuf<uint8_t> d_pool; DevBuf<uint32_t> d_q2, d_nm; DevBuf<NraDevRegion> d_regs; DevBuf<NraDevRead> d_reads;
     DevBuf<NraTask> d_tasks; DevBuf<int32_t> d_counts, d_score, d_ts, d_te;
-    HIP_TRY(d_pool.upload(pool)); HIP_TRY(d_q2.upload(q2bit)); HIP_TRY(d_nm.upload(nmask));
-    HIP_TRY(d_regs.upload(dregs)); HIP_TRY(d_reads.upload(dreads)); HIP_TRY(d_tasks.upload(tasks));
+    HIP_TRY(d_pool.upload(ps.pool)); HIP_TRY(d_q2.upload(ps.q2bit)); HIP_TRY(d_nm.upload(ps.nmask));
+    HIP_TRY(d_regs.upload(ps.dregs)); HIP_TRY(d_reads.upload(ps.dreads)); HIP_TRY(d_tasks.upload(tasks));
     HIP_TRY(d_counts.upload(counts));
     HIP_TRY(d_score.alloc((size_t)n_pairs)); HIP_TRY(d_ts.alloc((size_t)n_pairs)); HIP_TRY(d_te.alloc((size_t)n_pairs));
     HIP_TRY(hipMemset(d_score.p, 0xff, (size_t)n_pairs * 4));
@@ -1047,7 +1064,7 @@ int nra_align_pairs(int device, int32_t n_seqs, const char* seqs, const int64_t*
     HIP_TRY(hipMemset(d_te.p, 0xff, (size_t)n_pairs * 4));
     const NraScoreParams sp = to_params(*sc);
     for (size_t i = 0; i < launches.size(); ++i) {
-        LAUNCH_TRY(nra_launch_payload_origin(launches[i].first, has_n ? 1 : 0, nullptr, std::min(counts[i], 256 * 16),
+        LAUNCH_TRY(nra_launch_payload_origin(launches[i].first, ps.has_n ? 1 : 0, nullptr, std::min(counts[i], 256 * 16),
                                              d_tasks.p + launches[i].second, d_counts.p + i, d_reads.p, d_regs.p,
                                              d_pool.p, d_q2.p, d_nm.p, sp, d_score.p, d_ts.p, d_te.p, nullptr, 0));
     }
@@ -1055,6 +1072,102 @@ int nra_align_pairs(int device, int32_t n_seqs, const char* seqs, const int64_t*
     HIP_TRY(hipMemcpy(score, d_score.p, (size_t)n_pairs * 4, hipMemcpyDeviceToHost));
     HIP_TRY(hipMemcpy(tstart, d_ts.p, (size_t)n_pairs * 4, hipMemcpyDeviceToHost));
     HIP_TRY(hipMemcpy(tend, d_te.p, (size_t)n_pairs * 4, hipMemcpyDeviceToHost));
+    return NRA_OK;
+}
+
+int nra_align_pairs_cigar(int device, int32_t n_seqs, const char* seqs, const int64_t* seq_off, int64_t n_pairs,
+                          const int32_t* pair_query, const int32_t* pair_target, const nra_scoring_t* sc,
+                          int32_t flags, int32_t* score, int32_t* tstart, int32_t* tend, int32_t* qstart,
+                          int32_t* qend, char* cigar, int64_t cigar_cap, int64_t* cigar_off)
+{
+    (void)flags;
+    if (n_pairs > 0 && (!score || !tstart || !tend || !qstart || !qend || !cigar || !cigar_off || cigar_cap < 1))
+        return fail(NRA_E_ARG, "NULL output array");
+    PairSetup ps;
+    int rc = prepare_pairs(device, n_seqs, seqs, seq_off, n_pairs, pair_query, pair_target, sc, ps);
+    if (rc) return rc;
+    if (cigar_off) cigar_off[0] = 0;
+    if (n_pairs == 0) return NRA_OK;
+
+    // one launch per rows-per-lane bucket; tasks keep their pair index through `order`
+    std::vector<std::vector<int64_t>> by_bucket((size_t)kNumR);
+    for (int64_t i = 0; i < n_pairs; ++i) {
+        const int32_t qi = ps.as_query[pair_query[i]];
+        if (ps.dreads[qi].qlen == 0 || ps.dregs[ps.as_target[pair_target[i]]].l1 == 0) continue;
+        by_bucket[rows_for_qlen(ps.dreads[qi].qlen)].push_back(i);
+    }
+    std::vector<NraTraceTask> tasks;
+    std::vector<int64_t> order;
+    std::vector<std::pair<int, size_t>> launches;
+    std::vector<int> counts;
+    uint64_t trace_bytes = 0, ops_bytes = 0;
+    for (int bi = kNumR - 1; bi >= 0; --bi) {
+        if (by_bucket[bi].empty()) continue;
+        launches.push_back({kRList[bi], tasks.size()});
+        counts.push_back((int)by_bucket[bi].size());
+        for (int64_t i : by_bucket[bi]) {
+            NraTraceTask t{};
+            t.read = ps.as_query[pair_query[i]];
+            t.region = ps.as_target[pair_target[i]];
+            const uint64_t ql = (uint64_t)ps.dreads[t.read].qlen, tl = (uint64_t)ps.dregs[t.region].l1;
+            t.ops_cap = (int32_t)(ql + tl);
+            t.trace_off = trace_bytes; t.ops_off = ops_bytes;
+            trace_bytes += ql * tl; ops_bytes += ql + tl;
+            tasks.push_back(t); order.push_back(i);
+        }
+    }
+    if (trace_bytes > (8ull << 30)) return fail(NRA_E_RANGE, "trace needs more than 8 GiB: split the call");
+    const size_t nt = tasks.size();
+    DevBuf<uint8_t> d_pool, d_trace, d_ops; DevBuf<uint32_t> d_q2, d_nm; DevBuf<NraDevRegion> d_regs;
+    DevBuf<NraDevRead> d_reads; DevBuf<NraTraceTask> d_tasks; DevBuf<int32_t> d_fill, d_back;
+    HIP_TRY(d_pool.upload(ps.pool)); HIP_TRY(d_q2.upload(ps.q2bit)); HIP_TRY(d_nm.upload(ps.nmask));
+    HIP_TRY(d_regs.upload(ps.dregs)); HIP_TRY(d_reads.upload(ps.dreads)); HIP_TRY(d_tasks.upload(tasks));
+    HIP_TRY(d_trace.alloc((size_t)trace_bytes)); HIP_TRY(d_ops.alloc((size_t)ops_bytes));
+    HIP_TRY(d_fill.alloc(nt * 5)); HIP_TRY(d_back.alloc(nt * 3));
+    const NraScoreParams sp = to_params(*sc);
+    for (size_t i = 0; i < launches.size(); ++i) {
+        const size_t off = launches[i].second;
+        LAUNCH_TRY(nra_launch_trace_fill(launches[i].first, ps.has_n ? 1 : 0, nullptr, counts[i], d_tasks.p + off,
+                                         d_reads.p, d_regs.p, d_pool.p, d_q2.p, d_nm.p, sp, d_trace.p, d_fill.p + off * 5));
+        LAUNCH_TRY(nra_launch_trace_back(nullptr, counts[i], d_tasks.p + off, d_reads.p, d_regs.p, d_trace.p,
+                                         d_fill.p + off * 5, d_ops.p, d_back.p + off * 3));
+    }
+    HIP_TRY(hipDeviceSynchronize());
+    std::vector<int32_t> fill(nt * 5), back(nt * 3);
+    std::vector<uint8_t> ops((size_t)ops_bytes);
+    if (nt) {
+        HIP_TRY(hipMemcpy(fill.data(), d_fill.p, nt * 5 * 4, hipMemcpyDeviceToHost));
+        HIP_TRY(hipMemcpy(back.data(), d_back.p, nt * 3 * 4, hipMemcpyDeviceToHost));
+        HIP_TRY(hipMemcpy(ops.data(), d_ops.p, (size_t)ops_bytes, hipMemcpyDeviceToHost));
+    }
+    // per pair: extents + run-length encoded CIGAR
+    std::vector<std::string> cg((size_t)n_pairs);
+    for (int64_t i = 0; i < n_pairs; ++i) { score[i] = -1; tstart[i] = -1; tend[i] = -1; qstart[i] = -1; qend[i] = -1; }
+    for (size_t t = 0; t < nt; ++t) {
+        const int64_t i = order[t];
+        const int32_t* f = &fill[t * 5];
+        if (f[0] < 0) continue;
+        score[i] = f[0]; tstart[i] = back[t * 3 + 2]; tend[i] = f[2]; qstart[i] = back[t * 3 + 1]; qend[i] = f[3] + 1;
+        const int n = back[t * 3];
+        const uint8_t* op = ops.data() + tasks[t].ops_off + tasks[t].ops_cap - n;
+        std::string& out = cg[i];
+        for (int k = 0; k < n;) {
+            int e = k;
+            while (e < n && op[e] == op[k]) ++e;
+            out += std::to_string(e - k);
+            out += (char)op[k];
+            k = e;
+        }
+    }
+    int64_t pos = 0;
+    for (int64_t i = 0; i < n_pairs; ++i) {
+        cigar_off[i] = pos;
+        if (pos + (int64_t)cg[i].size() + 1 > cigar_cap)
+            return fail(NRA_E_ARG, "cigar buffer too small");
+        memcpy(cigar + pos, cg[i].c_str(), cg[i].size() + 1);
+        pos += (int64_t)cg[i].size() + 1;
+    }
+    cigar_off[n_pairs] = pos;
     return NRA_OK;
 }
 

@@ -58,6 +58,16 @@ struct NraJointTask {
     int32_t out;
 };
 
+// One (query, target) pair whose path is wanted (nra_trace.hip).
+struct NraTraceTask {
+    int32_t read;        // query (2-bit pool)
+    int32_t region;      // target = piece 1 of this region
+    int32_t ops_cap;     // qlen + tlen
+    int32_t pad;
+    uint64_t trace_off;  // qlen * tlen bytes, row-major
+    uint64_t ops_off;
+};
+
 // One candidate scored with a payload (extents / window kernels).
 struct NraTask {
     int32_t read;
@@ -137,6 +147,15 @@ int nra_launch_joint_fwd(int R, int has_n, hipStream_t st, int n_tasks, const Nr
                          const NraDevRead* reads, const NraDevRegion* regions, const uint8_t* pool,
                          const uint32_t* q2bit, const uint32_t* qnmask, NraScoreParams sp,
                          int32_t* snap, int32_t* read_a, int32_t* cell_score, int32_t* cell_wscore);
+
+// alignment paths (nra_trace.hip)
+int nra_launch_trace_fill(int R, int has_n, hipStream_t st, int n_tasks, const NraTraceTask* tasks,
+                          const NraDevRead* reads, const NraDevRegion* regions, const uint8_t* pool,
+                          const uint32_t* q2bit, const uint32_t* qnmask, NraScoreParams sp,
+                          uint8_t* trace, int32_t* out);
+int nra_launch_trace_back(hipStream_t st, int n_tasks, const NraTraceTask* tasks, const NraDevRead* reads,
+                          const NraDevRegion* regions, const uint8_t* trace, const int32_t* fill_out,
+                          uint8_t* ops, int32_t* out);
 
 // 1D selectors (one wave per read).  append_mode: 0 none, 1 ambiguous ties only, 2 every tie
 int nra_launch_select_best_1d(hipStream_t st, int n_reads, const int32_t* kmin, const int32_t* kmax,
