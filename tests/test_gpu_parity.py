@@ -494,3 +494,18 @@ def test_2d_decomposition_matches_oracle_and_brute_force(capi, oracle):
         g = capi.joint_2d((Lx, u1, mid, u2, Rx), reads, cr2, a2, b2, sc=capi.default_scoring(min_dp_score=20))
         for k in KEYS_2D:
             assert np.array_equal(g[k], o[k]), (len(Lx), len(Rx), k, g[k][:10], o[k][:10])
+
+
+@pytest.mark.gpu
+def test_differential_fuzz_small():
+    """60 rounds of tools/gpu_fuzz.py (random regions, scoring, N bases, missing flanks, junction
+    indels; all 1D modes and both 2D modes against the oracle).  profiles/r01e_fuzz.txt holds a
+    3000-round run."""
+    import importlib.util, os
+    spec = importlib.util.spec_from_file_location(
+        "gpu_fuzz", os.path.join(os.path.dirname(__file__), "..", "tools", "gpu_fuzz.py"))
+    fz = importlib.util.module_from_spec(spec); spec.loader.exec_module(fz)
+    rng = np.random.default_rng(20260104)
+    for _ in range(60):
+        assert fz.fuzz_1d(rng) is None
+        assert fz.fuzz_2d(rng) is None

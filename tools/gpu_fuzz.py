@@ -1,0 +1,118 @@
+"""Differential fuzzing of the HIP path against the CPU oracle: random regions, motifs, flank
+lengths, windows, scoring parameters, N bases and adversarial reads (missing flanks, junction
+indels, junk).  Usage: python tools/gpu_fuzz.py [n_rounds] [seed]"""
+import sys, time
+import numpy as np
+sys.path.insert(0, '.')
+from nanorepeat_amd import _capi as A, synth
+from oracle import oracle as O
+
+K1 = ("best_score", "sum_k", "n_ties", "status", "cand_score")
+K2 = ("read_strand", "cell_score", "cell_wscore", "best_wscore", "sum_k1", "sum_k2", "n_ties", "status")
+
+
+def rand_scoring(rng):
+    if rng.random() < 0.6:
+        return {}
+    a = int(rng.integers(1, 5)); b = int(rng.integers(1, 9))
+    o1 = int(rng.integers(0, 8)); e1 = int(rng.integers(1, 4))
+    o2 = int(rng.integers(o1, 40)); e2 = int(rng.integers(1, e1 + 1))
+    return dict(match=a, mismatch=b, gap_open1=o1, gap_ext1=e1, gap_open2=o2, gap_ext2=e2,
+                sc_ambi=int(rng.integers(0, 3)), min_dp_score=int(rng.choice([0, 10, 40, 80])))
+
+
+def mangle(rng, s):
+    r = rng.random()
+    if r < 0.15:
+        i = int(rng.integers(0, max(1, len(s)))); return s[:i] + "N" * int(rng.integers(1, 4)) + s[i + 1:]
+    if r < 0.25:
+        return s.lower()
+    return s
+
+
+def fuzz_1d(rng):
+    m = int(rng.integers(1, 8)); unit = synth.rand_unit(rng, m)
+    L = synth.rand_seq(rng, int(rng.choice([1, 2, 9, 40, 150, 400]))); R = synth.rand_seq(rng, int(rng.choice([1, 2, 11, 60, 150, 400])))
+    if rng.random() < 0.1:
+        L = mangle(rng, L)
+    n = int(rng.integers(1, 14)); reads, kmin, kmax = [], [], []
+    for _ in range(n):
+        k = int(rng.integers(0, 40)); fl, fr = int(rng.integers(0, len(L) + 1)), int(rng.integers(0, len(R) + 1))
+        kind = rng.random()
+        s = L[len(L) - fl:] + unit * k + R[:fr]
+        if kind < 0.15: s = unit * k + R[:fr]
+        elif kind < 0.3: s = L[len(L) - fl:] + unit * k
+        elif kind < 0.35: s = synth.rand_seq(rng, int(rng.integers(0, 200)))
+        elif kind < 0.45:
+            cut = len(L[len(L) - fl:]) + m * k; d = int(rng.integers(1, 30)); s = s[:max(0, cut - d)] + s[cut + int(rng.integers(0, 30)):]
+        s = synth.apply_errors(rng, s, [(0, 0, 0), "hifi", "ont_q20", "ont"][int(rng.integers(0, 4))])
+        reads.append(mangle(rng, s))
+        lo = max(0, k - int(rng.integers(0, 12))); hi = k + int(rng.integers(0, 12))
+        if rng.random() < 0.05: lo, hi = 5, 4
+        kmin.append(lo); kmax.append(hi)
+    sc = rand_scoring(rng)
+    o = O.round3_1d([(L, unit, R)], reads, kmin, kmax, sc=O.default_scoring(**sc))
+    for flags in (0, A.F_TIE_EXTENTS, A.F_BRUTE_FORCE, A.F_TEST_CHAIN):
+        if flags == A.F_TEST_CHAIN and (len(L) < 1 or len(R) < 1):
+            continue
+        try:
+            with A.Batch.create_1d([(L, unit, R)], reads, kmin, kmax, sc=A.default_scoring(**sc), flags=flags) as b:
+                b.run(); b.sync(); g = b.fetch()
+        except A.NraError:
+            if flags == A.F_TEST_CHAIN:      # scoring that needs the brute-force path cannot chain 128-base blocks
+                continue
+            raise
+        keys = K1 + (("cand_tstart", "cand_tend") if flags in (A.F_TIE_EXTENTS, A.F_BRUTE_FORCE) else ())
+        for k in keys:
+            if not np.array_equal(g[k], o[k]):
+                return dict(kind="1d", flags=flags, key=k, L=L, unit=unit, R=R, reads=reads, kmin=kmin, kmax=kmax, sc=sc,
+                            got=g[k].tolist(), want=o[k].tolist())
+    return None
+
+
+def fuzz_2d(rng):
+    u1 = synth.rand_unit(rng, int(rng.integers(1, 6))); u2 = synth.rand_unit(rng, int(rng.integers(1, 6)))
+    L = synth.rand_seq(rng, int(rng.choice([1, 3, 9, 10, 11, 60, 300]))); R = synth.rand_seq(rng, int(rng.choice([1, 2, 3, 9, 10, 11, 60, 300])))
+    mid = synth.rand_seq(rng, int(rng.choice([0, 1, 5, 13, 40])))
+    n = int(rng.integers(1, 7)); reads, cr, k1, k2 = [], [], [], []
+    for r in range(n):
+        a, b = int(rng.integers(0, 25)), int(rng.integers(0, 15))
+        fl, fr = int(rng.integers(0, len(L) + 1)), int(rng.integers(0, len(R) + 1))
+        s = synth.apply_errors(rng, L[len(L) - fl:] + u1 * a + mid + u2 * b + R[:fr], ["hifi", "ont"][int(rng.integers(0, 2))])
+        if rng.random() < 0.4: s = synth.revcomp(s)
+        reads.append(mangle(rng, s))
+        s1, s2 = int(rng.integers(1, 4)), int(rng.integers(1, 4))
+        for x in range(max(0, a - 4), a + 4, s1):
+            for y in range(max(0, b - 3), b + 3, s2):
+                cr.append(r); k1.append(x); k2.append(y)
+    sc = rand_scoring(rng)
+    try:
+        o = O.joint_2d((L, u1, mid, u2, R), reads, cr, k1, k2, sc=O.default_scoring(**sc))
+    except ValueError:
+        return None
+    for flags in (0, A.F_BRUTE_FORCE):
+        g = A.joint_2d((L, u1, mid, u2, R), reads, cr, k1, k2, sc=A.default_scoring(**sc), flags=flags)
+        for k in K2:
+            if not np.array_equal(g[k], o[k]):
+                return dict(kind="2d", flags=flags, key=k, region=(L, u1, mid, u2, R), reads=reads, cr=cr, k1=k1, k2=k2, sc=sc,
+                            got=g[k].tolist(), want=o[k].tolist())
+    return None
+
+
+if __name__ == "__main__":
+    rounds = int(sys.argv[1]) if len(sys.argv) > 1 else 100
+    seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
+    rng = np.random.default_rng(seed)
+    t0 = time.time(); bad = 0
+    for i in range(rounds):
+        for f in (fuzz_1d, fuzz_2d):
+            r = f(rng)
+            if r is not None:
+                bad += 1
+                print("MISMATCH", {k: (v if k not in ("got", "want") else v[:40]) for k, v in r.items()}, flush=True)
+                if bad >= 3:
+                    sys.exit(1)
+        if i % 20 == 19:
+            print(f"round {i + 1}/{rounds} ok, {time.time() - t0:.0f} s", flush=True)
+    print("fuzz done", rounds, "rounds, mismatches:", bad, flush=True)
+    sys.exit(1 if bad else 0)
