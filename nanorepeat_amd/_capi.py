@@ -267,6 +267,36 @@ def align_pairs_cigar(seqs, pair_query, pair_target, sc=None, flags=0, device=0)
     return out
 
 
+TRACE_CHUNK_BYTES = 6 << 30        # nra_align_pairs_cigar keeps one trace byte per DP cell, <= 8 GiB per call
+
+
+def align_pairs_cigar_chunked(seqs, pair_query, pair_target, sc=None, flags=0, device=0,
+                              chunk_bytes=TRACE_CHUNK_BYTES):
+    """align_pairs_cigar for any number of pairs: splits the list so that each call's trace
+    (query length x target length bytes per pair) stays below `chunk_bytes`, and sends each call
+    only the sequences it uses."""
+    n = len(pair_query)
+    out = {k: np.full(n, -1, np.int32) for k in ("score", "tstart", "tend", "qstart", "qend")}
+    out["cigar"] = [""] * n
+    lo = 0
+    while lo < n:
+        hi, used = lo, 0
+        while hi < n:
+            cost = len(seqs[pair_query[hi]]) * len(seqs[pair_target[hi]])
+            if hi > lo and used + cost > chunk_bytes:
+                break
+            used += cost; hi += 1
+        ids = sorted({int(x) for x in pair_query[lo:hi]} | {int(x) for x in pair_target[lo:hi]})
+        local = {g: i for i, g in enumerate(ids)}
+        part = align_pairs_cigar([seqs[g] for g in ids], [local[int(x)] for x in pair_query[lo:hi]],
+                                 [local[int(x)] for x in pair_target[lo:hi]], sc=sc, flags=flags, device=device)
+        for k in ("score", "tstart", "tend", "qstart", "qend"):
+            out[k][lo:hi] = part[k]
+        out["cigar"][lo:hi] = part["cigar"]
+        lo = hi
+    return out
+
+
 class Batch:
     """Device-resident batch: create = encode + H2D, run = kernels only, fetch = D2H."""
 

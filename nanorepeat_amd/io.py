@@ -59,6 +59,37 @@ def read_fastq(fastq_file):
     return reads
 
 
+def fastq_file_to_dict(in_fastq_file):
+    """nanoRepeat_joint.py:652-673: {read_name: the record's four lines as one string}."""
+    fastq_dict = dict()
+    with gzopen(in_fastq_file) as fp:
+        while True:
+            rec = [fp.readline() for _ in range(4)]
+            if not all(rec):
+                break
+            fastq_dict[rec[0].strip().split()[0][1:]] = "".join(rec)
+    return fastq_dict
+
+
+def read_one_chr_from_fasta_file(fasta_file, target_chr):
+    """tk.read_one_chr_from_fasta_file (tk.py:193-230): the first record with that exact name,
+    upper-cased; '' when absent."""
+    chunks, reading = [], False
+    with gzopen(fasta_file) as fp:
+        for line in fp:
+            line = line.strip()
+            if not line:
+                continue
+            if line[0] == ">":
+                if reading and chunks:
+                    break
+                reading = line[1:].split()[0] == target_chr
+                continue
+            if reading:
+                chunks.append(line.upper())
+    return "".join(chunks)
+
+
 def extract_ref_sequence(ref_fasta_dict, repeat_region, anchor_len=1000):
     """nanoRepeat_bam.py:76-137: flanks of at most anchor_len bases on either side (clamped to the
     chromosome), with the chr-prefix fallback and the reference's bounds checks."""

@@ -47,6 +47,8 @@ class Round1Estimation:
     def __init__(self):
         self.repeat1_count_range_dict = dict()
         self.repeat2_count_range_dict = dict()
+        self.potential_repeat_region_dict = dict()
+        self.bad_reads_set = set()
 
 
 class RepeatSize:
@@ -93,6 +95,143 @@ def build_template_for_two_repeats(left_anchor_seq, mid_anchor_seq, right_anchor
     return ("%d-%d" % (repeat_count1, repeat_count2),
             left_anchor_seq + repeat1.repeat_unit * repeat_count1 + mid_anchor_seq +
             repeat2.repeat_unit * repeat_count2 + right_anchor_seq)
+
+
+def calculate_repeat_size_from_exact_match(cigar, tstart, ref_repeat_start_pos, repeat_unit_size):
+    """tk.py:405-431: whole units inside every run of exact matches that lies in (or reaches
+    into) the repeat part of a template -- a deliberately low estimate of the repeat count."""
+    from .paf import cigar_ops
+    repeat_size = 0
+    pos = tstart
+    for op, n in cigar_ops(cigar):
+        if op == "=":
+            inside = n if pos >= ref_repeat_start_pos else pos + n - ref_repeat_start_pos
+            if inside > 0:
+                repeat_size += inside // repeat_unit_size
+            pos += n
+        elif op in "XD":
+            pos += n
+        elif op != "I":
+            raise ValueError(f"unsupported CIGAR operation: {op}")
+    return repeat_size
+
+
+def round1_estimation_for1read(read_paf_list, repeat1, repeat2, left_anchor_len, right_anchor_len,
+                               initial_estimation):
+    """nanoRepeat_joint.py:591-649.  A read is used when exactly one primary, mapq >= 30 record
+    per template spans that template's anchor/repeat boundary and the two are on opposite
+    strands (the right template is reverse-complemented).  Upper bound of a count: how far the
+    alignment reaches into the repeat, + 5; lower bound: min(max(0, e - 20), e // 2) with e the
+    exact-match estimate."""
+    spans = {"left_": [], "right": []}
+    bounds = {"left_": left_anchor_len, "right": right_anchor_len}
+    for paf in read_paf_list:
+        if paf.mapq < 30 or not paf.is_primary:
+            continue
+        key = paf.tname[0:5]
+        if key not in spans:
+            raise ValueError(f"unknown template: {paf.tname}")
+        if paf.tstart <= bounds[key] <= paf.tend:
+            spans[key].append(paf)
+    if len(spans["left_"]) != 1 or len(spans["right"]) != 1:
+        return
+    left_paf, right_paf = spans["left_"][0], spans["right"][0]
+    if left_paf.strand == right_paf.strand:
+        return
+    readname = left_paf.qname
+    for paf, bound, repeat, ranges in ((left_paf, left_anchor_len, repeat1, initial_estimation.repeat1_count_range_dict),
+                                       (right_paf, right_anchor_len, repeat2, initial_estimation.repeat2_count_range_dict)):
+        upper = int((paf.tend - bound) / repeat.repeat_unit_size) + 5
+        exact = calculate_repeat_size_from_exact_match(paf.cigar, paf.tstart, bound, repeat.repeat_unit_size)
+        ranges[readname] = (min(max(0, exact - 20), int(exact / 2.0)), upper)
+    if left_paf.strand == "+":
+        candidate = (left_paf.qstart, right_paf.qlen - right_paf.qstart)
+    else:
+        candidate = (right_paf.qstart, left_paf.qlen - left_paf.qstart)
+    if candidate[1] - candidate[0] <= 0:
+        initial_estimation.bad_reads_set.add(readname)
+    initial_estimation.potential_repeat_region_dict[readname] = candidate
+
+
+def round1_estimation_from_paf(paf_records, repeat1, repeat2, left_anchor_len, right_anchor_len):
+    """nanoRepeat_joint.py:561-589 on parsed records grouped by read name (the reference sorts the
+    PAF text by its first column and groups consecutive lines)."""
+    initial_estimation = Round1Estimation()
+    by_read = dict()
+    for paf in paf_records:
+        by_read.setdefault(paf.qname, []).append(paf)
+    for readname in sorted(by_read):
+        round1_estimation_for1read(by_read[readname], repeat1, repeat2, left_anchor_len, right_anchor_len,
+                                   initial_estimation)
+    for readname in initial_estimation.bad_reads_set:
+        initial_estimation.repeat1_count_range_dict.pop(readname, None)
+        initial_estimation.repeat2_count_range_dict.pop(readname, None)
+    return initial_estimation
+
+
+def round1_templates(repeat_chrom_seq, repeat1, repeat2, max_anchor_len):
+    """Names and sequences of the two round-1 templates (nanoRepeat_joint.py:515-538): the left
+    anchor followed by max_size units of repeat 1, and the reverse complement of max_size units
+    of repeat 2 followed by the right anchor."""
+    from .upstream import rev_comp
+    left_anchor_seq = repeat_chrom_seq[max(0, repeat1.start - max_anchor_len):repeat1.start]
+    right_anchor_seq = repeat_chrom_seq[repeat2.end:min(len(repeat_chrom_seq), repeat2.end + max_anchor_len)]
+    left = ("left_anchor_%d_%d_%s" % (len(left_anchor_seq), repeat1.max_size, repeat1.repeat_unit),
+            left_anchor_seq + repeat1.repeat_unit * repeat1.max_size)
+    right = ("right_anchor_%d_%d_%s_revc" % (len(right_anchor_seq), repeat2.max_size, repeat2.repeat_unit),
+             rev_comp(repeat2.repeat_unit * repeat2.max_size + right_anchor_seq))
+    return left, right, len(left_anchor_seq), len(right_anchor_seq)
+
+
+def initial_estimate_repeat_size(repeat_chrom_seq, fastq_dict, data_type, num_threads, repeat1, repeat2,
+                                 max_anchor_len, out_dir=None, device=0, scoring=None, aligner=None,
+                                 cigar_aligner=None, save_paf=False):
+    """Drop-in for nanoRepeat_joint.initial_estimate_repeat_size (nanoRepeat_joint.py:509-559); takes
+    the reads as the dict `fastq_file_to_dict` returns instead of a file name.  The two aligner
+    calls become: one score-only `nra_align_pairs` call that picks each read's strand per
+    template (the lower strand would be a secondary record, which :602 drops), then one
+    `nra_align_pairs_cigar` call for the chosen (read, template) pairs -- the CIGAR is needed for
+    the exact-match estimate.  Reads are DP queries here (<= 3072 bases).  mapq is taken as 60."""
+    from .paf import PAF, format_paf_line
+    from .upstream import rev_comp
+    assert repeat1.chrom == repeat2.chrom and repeat1.start < repeat2.start
+    aligner = aligner or _capi.align_pairs
+    cigar_aligner = cigar_aligner or _capi.align_pairs_cigar_chunked
+    left, right, left_anchor_len, right_anchor_len = round1_templates(repeat_chrom_seq, repeat1, repeat2, max_anchor_len)
+    names = list(fastq_dict)
+    seqs = [left[1], right[1]]
+    pq, pt = [], []
+    for i, n in enumerate(names):
+        s = _read_seq(fastq_dict[n])
+        seqs += [s, rev_comp(s)]
+        for t in (0, 1):
+            for o in (0, 1):
+                pq.append(2 + 2 * i + o); pt.append(t)
+    records = []
+    if names:
+        probe = aligner(seqs, np.array(pq, np.int32), np.array(pt, np.int32), sc=scoring, device=device)
+        cq, ct, who = [], [], []
+        for i, n in enumerate(names):
+            for t in (0, 1):
+                fwd, rev = int(probe["score"][4 * i + 2 * t]), int(probe["score"][4 * i + 2 * t + 1])
+                if max(fwd, rev) < 0:
+                    continue
+                o = 0 if fwd >= rev else 1
+                cq.append(2 + 2 * i + o); ct.append(t); who.append((n, t, "+-"[o]))
+        got = cigar_aligner(seqs, cq, ct, sc=scoring, device=device) if cq else None
+        for j, (n, t, strand) in enumerate(who):
+            if int(got["score"][j]) < 0:
+                continue
+            tname, tseq = (left, right)[t]
+            line = format_paf_line(n, len(seqs[cq[j]]), int(got["qstart"][j]), int(got["qend"][j]), strand, tname,
+                                   len(tseq), int(got["tstart"][j]), int(got["tend"][j]), int(got["score"][j]),
+                                   got["cigar"][j])
+            records.append(line)
+    if save_paf and out_dir:
+        with open(f"{out_dir}/round1.paf", "w") as f:
+            f.write("".join(r + "\n" for r in sorted(records, key=lambda r: r.split("\t")[0])))
+    pafs = [PAF(r.split("\t")) for r in records]
+    return round1_estimation_from_paf(pafs, repeat1, repeat2, left_anchor_len, right_anchor_len)
 
 
 def _read_seq(fastq_record):

@@ -35,6 +35,14 @@ class PAF:
             self.qstart, self.qend = self.qlen - self.qend, self.qlen - self.qstart
 
 
+def cigar_ops(cigar):
+    """[(op, length)] of a CIGAR string (tk.analysis_cigar_string, tk.py:379-401)."""
+    ops = [(op, int(n)) for n, op in re.findall(r"(\d+)([=XIDNSHPM])", cigar)]
+    if sum(len(str(n)) + 1 for _, n in ops) != len(cigar):
+        raise ValueError(f"unknown CIGAR operation in: {cigar[:40]}")
+    return ops
+
+
 def cigar_counts(cigar):
     """(matches, alignment block length) of an --eqx CIGAR."""
     n_match = sum(int(n) for n, op in re.findall(r"(\d+)([=XID])", cigar) if op == "=")

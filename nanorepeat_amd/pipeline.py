@@ -1,7 +1,8 @@
-"""Steps 1-3 of quantify1repeat_from_bam (nanoRepeat_bam.py:614-686) for one or many regions,
+"""Steps 1-4 of quantify1repeat_from_bam (nanoRepeat_bam.py:614-686) for one or many regions,
 from reads already extracted for the region: anchors -> core -> rounds 1-2 -> round 3 -> the
-`repeat_size.txt` text.  Step 4 (GMM phasing) and BAM extraction are outside this build."""
-from . import upstream, round3
+`repeat_size.txt` text -> GMM phasing -> one row of `NanoRepeat_output.tsv` per region.
+BAM extraction is outside this build."""
+from . import upstream, round3, phasing, joint, io as nr_io
 
 
 def quantify_regions(repeat_regions, reads_by_region, data_type="ont", fast_mode=False, num_cpu=1,
@@ -17,3 +18,60 @@ def quantify_regions(repeat_regions, reads_by_region, data_type="ont", fast_mode
                                               aligner=aligner)
     round3.round3_estimation_regions(data_type, fast_mode, repeat_regions, num_cpu, device, scoring, scorer)
     return [round3.output_repeat_size_1d(region) for region in repeat_regions]
+
+
+def phase_regions(repeat_regions, data_type="ont", ploidy=2, max_mutual_overlap=0.15, max_num_components=-1,
+                  remove_noisy_reads=False, seed=None, out_tsv_file=None):
+    """Step 4 for every region (nanoRepeat_bam.py:683-684) and the final table (:737-743); defaults
+    are the CLI's (nanoRepeat.py:121-129,159-160).  With a seed, region i uses seed + i."""
+    if max_num_components == -1:
+        max_num_components = ploidy + 20
+    error_rate = phasing.data_type_error_rate(data_type)
+    rows = []
+    for i, region in enumerate(repeat_regions):
+        phasing.split_allele_using_gmm_1d(region, ploidy, error_rate, max_mutual_overlap, max_num_components,
+                                          remove_noisy_reads, None if seed is None else seed + i)
+        rows.append(phasing.final_output_row(region))
+    if out_tsv_file:
+        with open(out_tsv_file, "w") as f:
+            f.write("".join(rows))
+    return rows
+
+
+def quantify_joint(in_fq, ref_fasta, repeat1_string, repeat2_string, out_prefix, data_type="ont", num_threads=1,
+                   ploidy=2, error_rate=0.1, max_mutual_overlap=0.1, remove_noisy_reads=False,
+                   max_num_components=-1, device=0, scoring=None, seed=None, **engines):
+    """The joint (2D) command from files to files (nanoRepeat_joint.py:160-232): round 1 ->
+    grid rounds 2/3 -> `<out_prefix>.repeat_size.txt` -> 2D GMM phasing -> `.phased_reads.txt`,
+    `.summary.txt`, `.alleleN.fastq`.  `engines` may carry aligner / cigar_aligner / scorer
+    stand-ins (tests).  Returns (RepeatSize, allele list or None)."""
+    if max_num_components == -1:
+        max_num_components = ploidy + 20
+    fastq_dict = nr_io.fastq_file_to_dict(in_fq)
+    if len(fastq_dict) < ploidy:
+        raise ValueError(f"not enough reads for analysis: ploidy {ploidy}, {len(fastq_dict)} reads in {in_fq}")
+    repeat1 = joint.Repeat().init_from_string(repeat1_string)
+    repeat2 = joint.Repeat().init_from_string(repeat2_string)
+    if repeat1.chrom != repeat2.chrom:
+        raise ValueError("joint quantification only works with two nearby repeats on one chromosome")
+    if repeat1.start > repeat2.start:
+        repeat1, repeat2 = repeat2, repeat1
+    repeat1.max_size += 10
+    repeat2.max_size += 10
+    if repeat1.end + 100 < repeat2.start:
+        raise ValueError("joint quantification only works with two nearby repeats (distance < 100 bp)")
+    repeat_chrom_seq = nr_io.read_one_chr_from_fasta_file(ref_fasta, repeat1.chrom)
+    if not repeat_chrom_seq:
+        raise ValueError(f"ref_fasta file {ref_fasta} has no sequence named {repeat1.chrom}")
+    initial_estimation = joint.initial_estimate_repeat_size(
+        repeat_chrom_seq, fastq_dict, data_type, num_threads, repeat1, repeat2, 1000, device=device, scoring=scoring,
+        aligner=engines.get("aligner"), cigar_aligner=engines.get("cigar_aligner"))
+    final_estimation = joint.fine_tune_read_count(initial_estimation, fastq_dict, repeat_chrom_seq, repeat1, repeat2,
+                                                  data_type, num_threads, None, device, scoring, engines.get("scorer"))
+    joint_counts, _ = joint.output_repeat_size_2d(in_fq, repeat1.repeat_id, repeat2.repeat_id, out_prefix,
+                                                  final_estimation.repeat1_count_dict,
+                                                  final_estimation.repeat2_count_dict)
+    alleles = phasing.split_alleles_using_gmm_2d(ploidy, error_rate, max_mutual_overlap, remove_noisy_reads,
+                                                 max_num_components, repeat1, repeat2, joint_counts, 0, in_fq,
+                                                 out_prefix, seed=seed)
+    return final_estimation, alleles

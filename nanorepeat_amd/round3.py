@@ -42,6 +42,10 @@ class RepeatRegion:
         self.no_details = no_details
         self.read_dict = dict()
         self.read_core_seq_dict = dict()
+        self.region_fq_file = None      # reads of the region (source of the per-allele FASTQ files)
+        self.results = None             # phasing.Result, filled by output_repeat_size_1d / step 4
+        self.final_output = None
+        self.index = None
         if line is not None:
             col_list = line.strip().split("\t")
             if len(col_list) < 4:
@@ -123,6 +127,8 @@ def output_repeat_size_1d(repeat_region):
         if repeat_size is not None:
             lines.append(f"{read_name}\t{repeat_size:.1f}\n")
     text = "".join(lines)
+    from . import phasing
+    phasing.record_repeat_sizes(repeat_region)
     if not repeat_region.no_details and repeat_region.out_prefix:
         with open(f"{repeat_region.out_prefix}.repeat_size.txt", "w") as f:
             f.write(text)

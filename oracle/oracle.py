@@ -215,6 +215,25 @@ def align_pairs(seqs, pair_query, pair_target, sc=None, flags=0, threads=None, *
     return out
 
 
+def align_pairs_cigar(seqs, pair_query, pair_target, sc=None, flags=0, **_ignored):
+    """Oracle twin of nra_align_pairs_cigar (one nro_align_cigar per pair; small inputs only)."""
+    scs = _scoring(sc)
+    lo = max(1, scs.min_dp_score)
+    n = len(pair_query)
+    out = {k: np.full(n, -1, np.int32) for k in ("score", "tstart", "tend", "qstart", "qend")}
+    out["cigar"] = [""] * n
+    for i, (a, b) in enumerate(zip(pair_query, pair_target)):
+        if not seqs[a] or not seqs[b]:
+            continue
+        r = align_cigar(seqs[a], seqs[b], sc=sc)
+        if r["score"] < lo:
+            continue
+        for k in ("score", "tstart", "tend", "qstart", "qend"):
+            out[k][i] = r[k]
+        out["cigar"][i] = r["cigar"]
+    return out
+
+
 def joint_2d(region, reads, cell_read, cell_k1, cell_k2, read_strand=None, sc=None, flags=0,
              threads=None, **_ignored):
     """Oracle twin of nra_joint_2d.  region = (left, unit1, mid, unit2, right)."""

@@ -3,7 +3,7 @@
 
 Run in the build container only (needs /root/reference):
 
-    PYTHONPATH=/root/reference/src python3 -B tests/golden/make_golden.py
+    PYTHONPATH=/root/reference/src python3 -B tests/golden/make_golden.py [1d 2d upstream io phasing joint_round1]
 
 The reference's drivers import pysam / pyminimap2 / Levenshtein, none of which exist
 offline; empty placeholder modules are registered for them so the pure
@@ -599,19 +599,170 @@ def gen_io(tmp):
                       "left": rr.left_anchor_seq, "right": rr.right_anchor_seq, "mid": rr.mid_ref_seq,
                       "anchor_len_after": rr.anchor_len})
     fx["flanks"] = cases
+    fx["one_chr"] = {n: hashlib.sha1(tk.read_one_chr_from_fasta_file(fa, n).encode()).hexdigest()
+                     for n in ("chr4", "7", "chrM", "nope")}
+    fq = os.path.join(tmp, "x.fastq")
+    fq_text = "@a first\nACGT\n+\nIIII\n@b\nGGNA\n+b\n!!!!\n@a again\nTT\n+\nII\n@trunc\nAC\n"
+    open(fq, "w").write(fq_text)
+    fx["fastq_dict"] = {"text": fq_text, "dict": ref_joint.fastq_file_to_dict(fq)}
+    return fx
+
+
+def _sizes(rng, spec, jitter):
+    """spec: [(mean, n)], sizes as the selectors emit them (x.0 / x.5 / x.33..)."""
+    out = []
+    for mean, n in spec:
+        for _ in range(n):
+            v = mean + rng.gauss(0, jitter * (1 + mean / 50.0))
+            out.append(max(0.0, round(v * 2) / 2.0))
+    return out
+
+
+def gen_phasing(tmp):
+    """Step 4 (split_alleles.py:82-534, nanoRepeat_bam.py:502-574, nanoRepeat_joint.py:675-747) run by
+    the reference itself with both of its random sources seeded; plots are switched off."""
+    fx = {"cases_1d": [], "cases_2d": []}
+    for mod in (ref_bam, ref_joint, ref_split):
+        for fn in ("plot_repeat_counts_1d", "plot_repeat_counts_2d", "scatter_plot_with_contour_2d"):
+            if hasattr(mod, fn):
+                setattr(mod, fn, lambda *a, **k: None)
+    rng = random.Random(77)
+    specs_1d = [
+        ("two_alleles", [(40, 50), (150, 45)], 1.0, dict(ploidy=2, error_rate=0.07, max_mutual_overlap=0.15, max_num_components=22, remove_noisy_reads=False), [400.0]),
+        ("one_allele", [(30, 60)], 0.6, dict(ploidy=2, error_rate=0.07, max_mutual_overlap=0.15, max_num_components=22, remove_noisy_reads=False), []),
+        ("noisy_third", [(20, 60), (75, 55), (130, 9)], 0.7, dict(ploidy=2, error_rate=0.07, max_mutual_overlap=0.15, max_num_components=22, remove_noisy_reads=True), []),
+        ("close_alleles", [(40, 40), (46, 40)], 0.5, dict(ploidy=2, error_rate=0.03, max_mutual_overlap=0.15, max_num_components=6, remove_noisy_reads=False), []),
+        ("haploid_cap", [(12, 30), (60, 30), (200, 30)], 0.8, dict(ploidy=1, error_rate=0.07, max_mutual_overlap=0.1, max_num_components=2, remove_noisy_reads=True), []),
+        ("two_reads", [(10, 1), (90, 1)], 0.0, dict(ploidy=2, error_rate=0.07, max_mutual_overlap=0.15, max_num_components=22, remove_noisy_reads=False), []),
+        ("one_read", [(10, 1)], 0.0, dict(ploidy=2, error_rate=0.07, max_mutual_overlap=0.15, max_num_components=22, remove_noisy_reads=False), []),
+    ]
+    for ci, (label, spec, jitter, par, extra) in enumerate(specs_1d):
+        sizes = _sizes(rng, spec, jitter) + extra
+        order = list(range(len(sizes))); rng.shuffle(order)
+        rr = ref_rr.RepeatRegion()
+        rr.chrom, rr.start_pos, rr.end_pos, rr.repeat_unit_seq = "chr4", 3074876, 3074933, "CAG"
+        rr.no_details = False
+        rr.out_prefix = os.path.join(tmp, f"ph1_{ci}")
+        rr.region_fq_file = os.path.join(tmp, f"ph1_{ci}.fastq")
+        reads = []
+        with open(rr.region_fq_file, "w") as f:
+            for j, oi in enumerate(order):
+                name = f"r{j:03d}"
+                rd = ref_rr.Read(); rd.read_name = name
+                rd.round3_repeat_size = sizes[oi] if not (j % 17 == 5 and len(sizes) > 10) else None
+                rr.read_dict[name] = rd
+                reads.append([name, rd.round3_repeat_size])
+                f.write(f"@{name} len=8\nACGTACGT\n+\nIIIIIIII\n")
+        seed = 1000 + ci
+        random.seed(seed); np.random.seed(seed)
+        ref_split.output_repeat_size_1d(rr)
+        ref_bam.split_allele_using_gmm_1d(rr, par["ploidy"], par["error_rate"], par["max_mutual_overlap"],
+                                          par["max_num_components"], par["remove_noisy_reads"])
+        rr.get_final_output()
+        files = {}
+        for fn in sorted(os.listdir(tmp)):
+            if fn.startswith(f"ph1_{ci}.") and fn != f"ph1_{ci}.fastq":
+                files[fn.replace(f"ph1_{ci}", "PREFIX")] = open(os.path.join(tmp, fn)).read()
+        fx["cases_1d"].append({"label": label, "reads": reads, "params": par, "seed": seed, "files": files,
+                               "final_output": rr.final_output,
+                               "num_alleles": len(rr.results.quantified_allele_list)})
+    specs_2d = [
+        ("htt_like", [((17, 10), 46), ((55, 7), 54)], dict(ploidy=2, error_rate=0.1, max_mutual_overlap=0.1, max_num_components=22, remove_noisy_reads=False)),
+        ("single", [((30, 12), 40)], dict(ploidy=2, error_rate=0.1, max_mutual_overlap=0.1, max_num_components=22, remove_noisy_reads=False)),
+        ("noisy_third", [((15, 5), 50), ((70, 20), 50), ((120, 40), 8)], dict(ploidy=2, error_rate=0.05, max_mutual_overlap=0.1, max_num_components=22, remove_noisy_reads=True)),
+        ("same_axis1", [((40, 5), 40), ((40, 25), 40)], dict(ploidy=2, error_rate=0.05, max_mutual_overlap=0.1, max_num_components=5, remove_noisy_reads=False)),
+        ("one_read", [((40, 5), 1)], dict(ploidy=1, error_rate=0.05, max_mutual_overlap=0.1, max_num_components=5, remove_noisy_reads=False)),
+    ]
+    r1 = make_repeat("chr4", 3074876, 3074933, "CAG", 200)
+    r2 = make_repeat("chr4", 3074946, 3074966, "CCG", 20)
+    for ci, (label, spec, par) in enumerate(specs_2d):
+        rows = []
+        for (m1, m2), n in spec:
+            a = _sizes(rng, [(m1, n)], 0.8); b = _sizes(rng, [(m2, n)], 0.4)
+            rows += list(zip(a, b))
+        rng.shuffle(rows)
+        fq = os.path.join(tmp, f"ph2_{ci}.fastq")
+        joint = {}
+        with open(fq, "w") as f:
+            for j, (a, b) in enumerate(rows):
+                name = f"q{j:03d}"
+                joint[name] = (a, b)
+                f.write(f"@{name}\nACGTACGTAC\n+\nIIIIIIIIII\n")
+        prefix = os.path.join(tmp, f"ph2_{ci}")
+        seed = 2000 + ci
+        random.seed(seed); np.random.seed(seed)
+        ref_joint.split_alleles_using_gmm_2d(par["ploidy"], par["error_rate"], par["max_mutual_overlap"],
+                                             par["remove_noisy_reads"], par["max_num_components"], r1, r2,
+                                             dict(joint), 0, fq, prefix)
+        files = {}
+        for fn in sorted(os.listdir(tmp)):
+            if fn.startswith(f"ph2_{ci}.") and fn != f"ph2_{ci}.fastq":
+                files[fn.replace(f"ph2_{ci}", "PREFIX")] = open(os.path.join(tmp, fn)).read().replace(fq, "IN.fastq")
+        fx["cases_2d"].append({"label": label, "reads": [[n, a, b] for n, (a, b) in joint.items()], "params": par,
+                               "seed": seed, "files": files})
+    return fx
+
+
+def gen_joint_round1(tmp):
+    """Joint round 1 (nanoRepeat_joint.py:509-649) run by the reference with the oracle-backed
+    aligner stand-in (best strand per template as the one primary record)."""
+    fx = {"cases": []}
+    rng = random.Random(31)
+    for ci, (u1, u2, k1ref, k2ref, flank, alleles) in enumerate([
+            ("CAG", "CCG", 19, 9, 300, [(17, 10), (55, 7)]),
+            ("TATTG", "AC", 6, 12, 220, [(8, 30), (25, 12)])]):
+        mid = "CAACAGCCGCCAC" if ci == 0 else ""
+        left, right = rand_seq(flank + 50, rng), rand_seq(flank + 80, rng)
+        chrom = left + u1 * k1ref + mid + u2 * k2ref + right
+        s1 = len(left); e1 = s1 + len(u1) * k1ref; s2 = e1 + len(mid); e2 = s2 + len(u2) * k2ref
+        r1 = make_repeat("chrJ", s1, e1, u1, 60); r2 = make_repeat("chrJ", s2, e2, u2, 40)
+        r1.max_size += 10; r2.max_size += 10
+        fq = os.path.join(tmp, f"j1_{ci}.fastq")
+        reads = []
+        with open(fq, "w") as f:
+            for i in range(16):
+                a, b = alleles[i % 2]
+                seq = left[-(150 + 5 * i):] + u1 * a + mid + u2 * b + right[:140 + 7 * i]
+                seq = mutate(seq, 0.025, 0.015, 0.03, rng) if i % 5 else seq
+                if i == 7:
+                    seq = seq[:len(seq) // 2]                  # no right anchor
+                if i == 11:
+                    seq = rand_seq(400, rng)                    # unrelated read
+                if i == 13:
+                    seq = left[-150:] + u1 * 70 + mid + u2 * b + right[:150]   # longer than the template's repeat
+                if i % 3 == 1:
+                    seq = revcomp(seq)
+                name = f"jr{i:02d}"
+                reads.append([name, seq])
+                f.write(f"@{name}\n{seq}\n+\n{'I' * len(seq)}\n")
+        out_dir = os.path.join(tmp, f"j1_{ci}.tmp"); os.makedirs(out_dir)
+        ref_joint.pymm2.main = Recorder(oracle_aligner(both_strands=True))
+        est = ref_joint.initial_estimate_repeat_size(chrom, fq, "ont", 1, r1, r2, flank, out_dir)
+        fx["cases"].append({
+            "chrom": chrom, "repeat1": f"chrJ:{s1}:{e1}:{u1}:60", "repeat2": f"chrJ:{s2}:{e2}:{u2}:40",
+            "max_anchor_len": flank, "reads": reads,
+            "round1_paf": open(os.path.join(out_dir, "round1.paf")).read(),
+            "repeat1_count_range": {k: list(v) for k, v in est.repeat1_count_range_dict.items()},
+            "repeat2_count_range": {k: list(v) for k, v in est.repeat2_count_range_dict.items()},
+            "potential_repeat_region": {k: list(v) for k, v in est.potential_repeat_region_dict.items()},
+            "bad_reads": sorted(est.bad_reads_set)})
     return fx
 
 
 def main():
+    which = set(sys.argv[1:]) or {"1d", "2d", "upstream", "io", "phasing", "joint_round1"}
+    gens = (("1d", "ref_1d.json", gen_1d), ("2d", "ref_2d.json", gen_2d), ("upstream", "ref_upstream.json", gen_upstream),
+            ("io", "ref_io.json", gen_io), ("phasing", "ref_phasing.json", gen_phasing),
+            ("joint_round1", "ref_joint_round1.json", gen_joint_round1))
     tmp = tempfile.mkdtemp(prefix="nr_golden_")
+    out = []
     try:
-        one = gen_1d(tmp)
-        two = gen_2d(tmp)
-        up = gen_upstream(tmp)
-        io_fx = gen_io(tmp)
+        for key, name, gen in gens:
+            if key in which:
+                out.append((name, gen(tmp)))
     finally:
         shutil.rmtree(tmp, ignore_errors=True)
-    for name, fx in (("ref_1d.json", one), ("ref_2d.json", two), ("ref_upstream.json", up), ("ref_io.json", io_fx)):
+    for name, fx in out:
         with open(os.path.join(HERE, name), "w") as f:
             json.dump(fx, f, indent=1, sort_keys=True)
             f.write("\n")

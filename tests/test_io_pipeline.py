@@ -115,3 +115,34 @@ def test_pipeline_from_files_gpu_equals_oracle(capi, oracle, tmp_path):
     _, t_gpu = _run_pipeline(tmp_path)
     _, t_cpu = _run_pipeline(tmp_path, aligner=oracle.align_pairs, scorer=oracle.round3_1d)
     assert t_gpu == t_cpu
+
+
+def test_pipeline_step4_phasing_and_final_table(oracle, tmp_path):
+    """Steps 1-4 from files: the two alleles of every region come out of the mixture and the
+    final table has the reference's row layout (repeat_region.py:186-191)."""
+    _make_files(tmp_path, n_regions=2, reads_per_region=24)
+    regions, _ = _run_pipeline(tmp_path, aligner=oracle.align_pairs, scorer=oracle.round3_1d)
+    for g, rr in enumerate(regions):
+        rr.out_prefix = str(tmp_path / f"out{g}")
+        rr.region_fq_file = str(tmp_path / f"region{g}.fastq")
+    rows = pipeline.phase_regions(regions, "ont_q20", seed=3, out_tsv_file=str(tmp_path / "x.NanoRepeat_output.tsv"))
+    assert (tmp_path / "x.NanoRepeat_output.tsv").read_text() == "".join(rows)
+    for g, (rr, row) in enumerate(zip(regions, rows)):
+        cols = row.rstrip("\n").split("\t")
+        assert cols[0] == "chrS" and cols[3] == rr.repeat_unit_seq and len(cols) == 9
+        assert int(cols[4]) == 2 and {int(cols[5]), int(cols[6])} == {7 + g, 19 + 2 * g}
+        assert cols[7].startswith("Allele_Repeat_Size;Allele_Num_Support_Reads|")
+        assert cols[8].count("|") == len(rr.read_dict)
+        assert (tmp_path / f"out{g}.summary.txt").read_text().count("Num_Alleles=2") == 1
+        n_fq = sum((tmp_path / f"out{g}.allele{a}.fastq").read_text().count("\n+\n") for a in (1, 2))
+        assert 0 < n_fq <= len(rr.read_dict)
+
+
+def test_joint_mode_readers_match_reference(golden, tmp_path):
+    import hashlib
+    fa = tmp_path / "ref.fa"; fa.write_text(golden["fasta"]["text"])
+    for name, sha in golden["one_chr"].items():
+        assert hashlib.sha1(IO.read_one_chr_from_fasta_file(str(fa), name).encode()).hexdigest() == sha, name
+    fq = tmp_path / "x.fastq"; fq.write_text(golden["fastq_dict"]["text"])
+    got = IO.fastq_file_to_dict(str(fq))
+    assert got == golden["fastq_dict"]["dict"] and list(got) == list(golden["fastq_dict"]["dict"])
