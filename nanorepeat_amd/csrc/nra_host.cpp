@@ -94,6 +94,15 @@ struct DevBuf {
     }
 };
 
+// 2D decomposition: reads of one bucket whose wave states fit the state buffer together; the
+// prefix sweeps of a group run, then its tail sweeps, then the next group reuses the buffer.
+struct JointGroup {
+    int R = 0;
+    int bucket = 0;
+    int n_pre = 0, n_tail = 0;
+    size_t pre_off = 0, tail_off = 0;
+};
+
 struct Bucket {
     int R = 0;
     bool chain = false;        // reads longer than one register block: chained row blocks
@@ -104,8 +113,8 @@ struct Bucket {
     size_t queue_cap = 0;      // capacity of this bucket's queue region
     int n_sweep = 0;           // junction-decomposition tasks (pairs of reads)
     size_t sweep_off = 0;
-    int n_jbwd = 0, n_jfwd = 0; // 2D decomposition tasks
-    size_t jbwd_off = 0, jfwd_off = 0;
+    int n_jbwd = 0;            // 2D decomposition: reverse sweeps (one per read)
+    size_t jbwd_off = 0;
     int64_t cells_pair = 0;    // executed cells per run, pk16
     int64_t cells_queue = 0;   // executed cells per run, prebuilt payload queue
     int64_t cells_sweep = 0;   // executed cells per run, both sweeps
@@ -158,8 +167,11 @@ struct nra_batch {
     DevBuf<uint8_t> cand_flag;                 // flank verdict per candidate
     bool brute = false;                        // K independent alignments instead of the sweeps
     DevBuf<int32_t> chain_sweep, chain_payload; // scratch strips of the chained row blocks
-    DevBuf<NraJointTask> jbwd_tasks, jfwd_tasks; // 2D junction decomposition: per read / per (read, k1) run
+    DevBuf<NraJointTask> jbwd_tasks, jpre_tasks, jtail_tasks; // 2D decomposition: per read / per read / per (read, k1) run
     DevBuf<int32_t> jsnap, jread_a;             // R side of the junction (3 x int32 per base), A per read
+    DevBuf<int32_t> jk1list, jstate;            // k1 values per read; wave states of the prefix sweeps
+    std::vector<JointGroup> jgroups;
+    bool all_strands_given = false;             // 2D: every read came with its strand, no probe needed
     int chain_cap = 0;
     DevBuf<NraTask> queue_tasks;
     DevBuf<int32_t> queue_count;   // per bucket: prebuilt queue length (constant)
@@ -179,7 +191,7 @@ struct nra_batch {
 
     std::vector<hipStream_t> bstreams;   // one per bucket: the sweep chains of different buckets overlap
     std::vector<hipEvent_t> bdone;       // bucket chain finished
-    hipEvent_t fork_ev = nullptr;
+    hipEvent_t fork_ev = nullptr, fork2_ev = nullptr;
     hipEvent_t phase_ev[2] = {nullptr, nullptr};   // scoring phase start / end (timing)
     std::vector<hipEvent_t> ev;    // [0]=run start, [1]=run end, then pairs per dominant launch
     int n_score_ev = 0, n_ext_ev = 0;
@@ -191,6 +203,7 @@ struct nra_batch {
         for (hipEvent_t e : ev) (void)hipEventDestroy(e);
         for (hipEvent_t e : bdone) (void)hipEventDestroy(e);
         if (fork_ev) (void)hipEventDestroy(fork_ev);
+        if (fork2_ev) (void)hipEventDestroy(fork2_ev);
         for (hipEvent_t e : phase_ev) if (e) (void)hipEventDestroy(e);
         for (hipStream_t q : bstreams) (void)hipStreamDestroy(q);
         if (stream) (void)hipStreamDestroy(stream);
@@ -744,24 +757,54 @@ int nra_batch2d_create(int device, const nra_joint_region_t* reg, int32_t n_read
     std::vector<NraPairTask> pair_tasks;
     std::vector<NraTask> queue_tasks;
     std::vector<int32_t> queue_count;
-    std::vector<NraJointTask> jbwd, jfwd;
+    std::vector<NraJointTask> jbwd, jpre, jtail;
+    std::vector<int32_t> k1list;
     // junction decomposition needs a base left of the window and two bases of R
     b->brute = (flags & NRA_F_BRUTE_FORCE) != 0 || reg->left_len < 1 || reg->right_len < 2;
+    // wave states of one group of reads (NRA_F_TEST_CHAIN: one read per group, to exercise the reuse)
+    // The buckets run concurrently, each in its own part of the state buffer.
+    size_t n_nonempty = 0;
+    for (const auto& v : by_bucket) n_nonempty += v.empty() ? 0 : 1;
+    const uint64_t state_cap = (flags & NRA_F_TEST_CHAIN) ? 1 : (uint64_t)NRA_JOINT_STATE_CAP_INTS / std::max<size_t>(n_nonempty, 1);
+    uint64_t state_base = 0;
+    b->all_strands_given = read_strand != nullptr && n_reads > 0;
+    if (read_strand)
+        for (int32_t r = 0; r < n_reads; ++r) if (cnt[r] > 0 && read_strand[r] == 0) b->all_strands_given = false;
     int64_t alg_cells = 0;
     for (int bi = kNumR - 1; bi >= 0; --bi) {
         if (by_bucket[bi].empty()) continue;
         Bucket bk; bk.R = kRList[bi];
         bk.pair_off = pair_tasks.size();
         bk.queue_off = queue_tasks.size();
-        bk.jbwd_off = jbwd.size(); bk.jfwd_off = jfwd.size();
+        bk.jbwd_off = jbwd.size();
+        const uint64_t slot = (uint64_t)(3 * bk.R + 7) * 64;
+        JointGroup g; g.R = bk.R; g.bucket = (int)b->buckets.size(); g.pre_off = jpre.size(); g.tail_off = jtail.size();
+        uint64_t used = 0, state_max = 0;
+        const size_t bucket_pre0 = jpre.size(), bucket_tail0 = jtail.size();
         for (int32_t r : by_bucket[bi]) {
             if (!b->brute) {
-                // one reverse sweep over R per read; one forward sweep per run of cells with the
-                // same k1 and k2 in arithmetic progression (how the grid rounds list them)
-                jbwd.push_back(NraJointTask{r, 0, 0, 1, 1, 0});
+                // one reverse sweep over R per read; one prefix sweep over L + u1^k1max per read that
+                // leaves the wave state at each of the read's k1 values; one tail sweep per run of cells
+                // with the same k1 and k2 in arithmetic progression (how the grid rounds list them)
+                NraJointTask tb{}; tb.read = r; tb.k2step = 1; tb.n2 = 1;
+                jbwd.push_back(tb);
                 bk.cells_sweep += sweep_cells(bk.R, d.l3);
+                std::vector<int32_t> ks(cell_k1 + first[r], cell_k1 + first[r] + cnt[r]);
+                std::sort(ks.begin(), ks.end());
+                ks.erase(std::unique(ks.begin(), ks.end()), ks.end());
+                if (used > 0 && used + slot * ks.size() > state_cap) {      // close the group
+                    g.n_pre = (int)(jpre.size() - g.pre_off); g.n_tail = (int)(jtail.size() - g.tail_off);
+                    b->jgroups.push_back(g);
+                    g.pre_off = jpre.size(); g.tail_off = jtail.size();
+                    used = 0;
+                }
+                NraJointTask tp{}; tp.read = r; tp.k1_off = (int32_t)k1list.size(); tp.nk1 = (int32_t)ks.size();
+                tp.state = used; tp.k2step = 1;
+                jpre.push_back(tp);
+                bk.cells_sweep += (int64_t)64 * bk.R * (d.l1 + d.m1 * ks.back() - 1);
                 for (uint32_t c = first[r]; c < first[r] + cnt[r];) {
-                    NraJointTask t{r, cell_k1[c], cell_k2[c], 1, 1, (int32_t)c};
+                    NraJointTask t{}; t.read = r; t.k1 = cell_k1[c]; t.k2lo = cell_k2[c]; t.k2step = 1; t.n2 = 1;
+                    t.out = (int32_t)c;
                     uint32_t e = c + 1;
                     if (e < first[r] + cnt[r] && cell_k1[e] == t.k1 && cell_k2[e] > t.k2lo) {
                         t.k2step = cell_k2[e] - t.k2lo;
@@ -769,17 +812,22 @@ int nra_batch2d_create(int device, const nra_joint_region_t* reg, int32_t n_read
                                cell_k2[e] == t.k2lo + t.k2step * (int32_t)(e - c)) ++e;
                     }
                     t.n2 = (int32_t)(e - c);
-                    jfwd.push_back(t);
-                    bk.cells_sweep += sweep_cells(bk.R, d.l1 + d.m1 * t.k1 + d.l2 + d.m2 * (t.k2lo + t.k2step * (t.n2 - 1)));
+                    t.state = used + slot * (uint64_t)(std::lower_bound(ks.begin(), ks.end(), t.k1) - ks.begin());
+                    jtail.push_back(t);
+                    bk.cells_sweep += sweep_cells(bk.R, 1 + d.l2 + d.m2 * (t.k2lo + t.k2step * (t.n2 - 1)));
                     c = e;
                 }
+                k1list.insert(k1list.end(), ks.begin(), ks.end());
+                used += slot * ks.size();
+                state_max = std::max(state_max, used);
             }
             // strand probe against the read's first listed cell: half A = template, half B = its revcomp
             NraPairTask t{};
             t.read = r; t.k1a = t.k1b = cell_k1[first[r]]; t.k2a = t.k2b = cell_k2[first[r]];
             t.out_a = 2 * r; t.out_b = 2 * r + 1; t.flags = 3;     // B = reverse complement; raw scores
             pair_tasks.push_back(t);
-            bk.cells_pair += 2 * sweep_cells(bk.R, d.l1 + d.m1 * t.k1a + d.l2 + d.m2 * t.k2a + d.l3);
+            if (!b->all_strands_given)
+                bk.cells_pair += 2 * sweep_cells(bk.R, d.l1 + d.m1 * t.k1a + d.l2 + d.m2 * t.k2a + d.l3);
             for (uint32_t c = first[r]; c < first[r] + cnt[r]; ++c) {
                 const int tl = d.l1 + d.m1 * cell_k1[c] + d.l2 + d.m2 * cell_k2[c] + d.l3;
                 alg_cells += (int64_t)pr.reads[r].qlen * tl;
@@ -789,10 +837,16 @@ int nra_batch2d_create(int device, const nra_joint_region_t* reg, int32_t n_read
                 }
             }
         }
+        if (!b->brute) {
+            g.n_pre = (int)(jpre.size() - g.pre_off); g.n_tail = (int)(jtail.size() - g.tail_off);
+            if (g.n_pre > 0) b->jgroups.push_back(g);
+            for (size_t i = bucket_pre0; i < jpre.size(); ++i) jpre[i].state += state_base;
+            for (size_t i = bucket_tail0; i < jtail.size(); ++i) jtail[i].state += state_base;
+            state_base += state_max;
+        }
         bk.n_pair = (int)(pair_tasks.size() - bk.pair_off);
         bk.n_queue = (int)(queue_tasks.size() - bk.queue_off);
         bk.n_jbwd = (int)(jbwd.size() - bk.jbwd_off);
-        bk.n_jfwd = (int)(jfwd.size() - bk.jfwd_off);
         bk.queue_cap = (size_t)bk.n_queue;
         queue_count.push_back(bk.n_queue);
         b->buckets.push_back(bk);
@@ -810,7 +864,10 @@ int nra_batch2d_create(int device, const nra_joint_region_t* reg, int32_t n_read
     HIP_TRY(b->queue_count.upload(queue_count));
     if (!b->brute) {
         HIP_TRY(b->jbwd_tasks.upload(jbwd));
-        HIP_TRY(b->jfwd_tasks.upload(jfwd));
+        HIP_TRY(b->jpre_tasks.upload(jpre));
+        HIP_TRY(b->jtail_tasks.upload(jtail));
+        HIP_TRY(b->jk1list.upload(k1list));
+        HIP_TRY(b->jstate.alloc((size_t)state_base));
         HIP_TRY(b->jsnap.alloc(pr.q2bit.size() * 16 * 3));
         HIP_TRY(b->jread_a.alloc((size_t)n_reads));
     }
@@ -834,8 +891,14 @@ int nra_batch2d_create(int device, const nra_joint_region_t* reg, int32_t n_read
     HIP_TRY(b->sum_k.alloc((size_t)n_reads));
     HIP_TRY(b->sum_k2.alloc((size_t)n_reads));
     HIP_TRY(b->status.alloc((size_t)n_reads));
-    rc = make_events(b, 2 + 6 * (int)nb + 2);
+    rc = make_events(b, 2 + 6 * (int)nb + 4 * (int)b->jgroups.size() + 2);
     if (rc) return rc;
+    // two streams per bucket: the buckets' chains overlap, and so do a bucket's reverse and prefix sweeps
+    b->bstreams.resize(2 * nb); b->bdone.resize(3 * nb);
+    for (size_t i = 0; i < 2 * nb; ++i) HIP_TRY(hipStreamCreateWithFlags(&b->bstreams[i], hipStreamNonBlocking));
+    for (size_t i = 0; i < 3 * nb; ++i) HIP_TRY(hipEventCreateWithFlags(&b->bdone[i], hipEventDisableTiming));
+    HIP_TRY(hipEventCreateWithFlags(&b->fork_ev, hipEventDisableTiming));
+    HIP_TRY(hipEventCreateWithFlags(&b->fork2_ev, hipEventDisableTiming));
 
     b->stats.n_alignments = n_cells;
     b->stats.algorithmic_cells = alg_cells;
@@ -860,14 +923,21 @@ static int run_2d(nra_batch* b)
     int ev = 2;
     b->n_score_ev = 0; b->n_ext_ev = 0;
     const int max_waves = 256 * 16;
-    for (size_t i = 0; i < nb; ++i) {
-        const Bucket& bk = b->buckets[i];
-        HIP_TRY(hipEventRecord(b->ev[ev++], st));
-        LAUNCH_TRY(nra_launch_score_pk16(bk.R, b->has_n, st, bk.n_pair, b->pair_tasks.p + bk.pair_off,
-                                         b->reads.p, b->regions.p, b->pool.p, b->q2bit.p, b->qnmask.p,
-                                         b->sp, b->probe_score.p));
-        HIP_TRY(hipEventRecord(b->ev[ev++], st));
-        b->n_ext_ev++;
+    if (!b->all_strands_given) {
+        HIP_TRY(hipEventRecord(b->fork_ev, st));
+        for (size_t i = 0; i < nb; ++i) {
+            const Bucket& bk = b->buckets[i];
+            hipStream_t q = b->bstreams[2 * i];
+            HIP_TRY(hipStreamWaitEvent(q, b->fork_ev, 0));
+            HIP_TRY(hipEventRecord(b->ev[ev++], q));
+            LAUNCH_TRY(nra_launch_score_pk16(bk.R, b->has_n, q, bk.n_pair, b->pair_tasks.p + bk.pair_off,
+                                             b->reads.p, b->regions.p, b->pool.p, b->q2bit.p, b->qnmask.p,
+                                             b->sp, b->probe_score.p));
+            HIP_TRY(hipEventRecord(b->ev[ev++], q));
+            b->n_ext_ev++;
+            HIP_TRY(hipEventRecord(b->bdone[3 * i + 2], q));
+            HIP_TRY(hipStreamWaitEvent(st, b->bdone[3 * i + 2], 0));
+        }
     }
     LAUNCH_TRY(nra_launch_pick_strand(st, b->n_reads, b->probe_score.p,
                                       b->have_strand_in ? b->strand_in.p : nullptr, b->strand_out.p, b->reads.p));
@@ -885,23 +955,44 @@ static int run_2d(nra_batch* b)
             b->n_score_ev++;
         }
     } else {
-        // junction decomposition: reverse sweeps over R (one per read), then one forward sweep per
-        // (read, k1) run of cells
-        for (int dir = 0; dir < 2; ++dir) {
-            for (size_t i = 0; i < nb; ++i) {
-                const Bucket& bk = b->buckets[i];
-                HIP_TRY(hipEventRecord(b->ev[ev++], st));
-                if (dir == 0)
-                    LAUNCH_TRY(nra_launch_joint_bwd(bk.R, b->has_n, st, bk.n_jbwd, b->jbwd_tasks.p + bk.jbwd_off,
-                                                    b->reads.p, b->regions.p, b->pool.p, b->q2bit.p, b->qnmask.p,
-                                                    b->sp, b->jsnap.p, b->jread_a.p));
-                else
-                    LAUNCH_TRY(nra_launch_joint_fwd(bk.R, b->has_n, st, bk.n_jfwd, b->jfwd_tasks.p + bk.jfwd_off,
-                                                    b->reads.p, b->regions.p, b->pool.p, b->q2bit.p, b->qnmask.p,
-                                                    b->sp, b->jsnap.p, b->jread_a.p, b->cand_score.p, b->cand_tstart.p));
-                HIP_TRY(hipEventRecord(b->ev[ev++], st));
+        // junction decomposition: reverse sweeps over R (one per read); then, group by group, the
+        // prefix sweeps (one per read) that leave the wave states and the tail sweeps (one per
+        // (read, k1) run of cells) that resume from them
+        HIP_TRY(hipEventRecord(b->fork2_ev, st));
+        for (size_t i = 0; i < nb; ++i) {
+            const Bucket& bk = b->buckets[i];
+            hipStream_t qa = b->bstreams[2 * i], qb = b->bstreams[2 * i + 1];
+            HIP_TRY(hipStreamWaitEvent(qa, b->fork2_ev, 0));
+            HIP_TRY(hipStreamWaitEvent(qb, b->fork2_ev, 0));
+            HIP_TRY(hipEventRecord(b->ev[ev++], qa));
+            LAUNCH_TRY(nra_launch_joint_bwd(bk.R, b->has_n, qa, bk.n_jbwd, b->jbwd_tasks.p + bk.jbwd_off,
+                                            b->reads.p, b->regions.p, b->pool.p, b->q2bit.p, b->qnmask.p,
+                                            b->sp, b->jsnap.p, b->jread_a.p));
+            HIP_TRY(hipEventRecord(b->ev[ev++], qa));
+            b->n_score_ev++;
+            HIP_TRY(hipEventRecord(b->bdone[3 * i], qa));
+            HIP_TRY(hipStreamWaitEvent(st, b->bdone[3 * i], 0));
+            bool first = true;
+            for (const JointGroup& g : b->jgroups) {
+                if (g.bucket != (int)i) continue;
+                HIP_TRY(hipEventRecord(b->ev[ev++], qb));
+                LAUNCH_TRY(nra_launch_joint_prefix(g.R, b->has_n, qb, g.n_pre, b->jpre_tasks.p + g.pre_off,
+                                                   b->reads.p, b->regions.p, b->pool.p, b->q2bit.p, b->qnmask.p,
+                                                   b->sp, b->jk1list.p, b->jstate.p));
+                HIP_TRY(hipEventRecord(b->ev[ev++], qb));
+                b->n_score_ev++;
+                if (first) HIP_TRY(hipStreamWaitEvent(qb, b->bdone[3 * i], 0));     // the tails read the R side
+                first = false;
+                HIP_TRY(hipEventRecord(b->ev[ev++], qb));
+                LAUNCH_TRY(nra_launch_joint_tail(g.R, b->has_n, qb, g.n_tail, b->jtail_tasks.p + g.tail_off,
+                                                 b->reads.p, b->regions.p, b->pool.p, b->q2bit.p, b->qnmask.p,
+                                                 b->sp, b->jstate.p, b->jsnap.p, b->jread_a.p, b->cand_score.p,
+                                                 b->cand_tstart.p));
+                HIP_TRY(hipEventRecord(b->ev[ev++], qb));
                 b->n_score_ev++;
             }
+            HIP_TRY(hipEventRecord(b->bdone[3 * i + 1], qb));
+            HIP_TRY(hipStreamWaitEvent(st, b->bdone[3 * i + 1], 0));
         }
     }
     HIP_TRY(hipEventRecord(b->phase_ev[1], st));

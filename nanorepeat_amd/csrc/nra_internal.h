@@ -48,14 +48,20 @@ struct NraSweepTask {
     int32_t kmin, kmax;
 };
 
-// One (read, k1) row of the 2D grid for the joint sweeps: the read's cells with this k1 are
-// k2 = k2lo + n*k2step, n < n2, and sit at out + n in the cell arrays.  (The reverse sweep
-// over R uses one task per read with n2 = 1.)
+// Tasks of the joint sweeps (nra_joint.hip).
+//   tail sweep: one (read, k1) row of the 2D grid -- the read's cells with this k1 are
+//     k2 = k2lo + n*k2step, n < n2, and sit at out + n in the cell arrays; `state` = where the
+//     prefix sweep left the wave state for this (read, k1) (index into the int32 state buffer);
+//   prefix sweep: one per read; its nk1 distinct k1 values, ascending, start at k1list[k1_off];
+//     state of the i-th goes to state + i * (3R+7) * 64;
+//   reverse sweep over R: one per read, only `read` is used.
 struct NraJointTask {
     int32_t read;
     int32_t k1;
     int32_t k2lo, k2step, n2;
     int32_t out;
+    int32_t k1_off, nk1;
+    uint64_t state;
 };
 
 // One (query, target) pair whose path is wanted (nra_trace.hip).
@@ -95,6 +101,8 @@ struct NraScoreParams {
 #define NRA_CHAIN_R 24
 #define NRA_CHAIN_R_TEST 2                     // tiny row blocks, for the tests (NRA_F_TEST_CHAIN)
 #define NRA_MAX_QLEN 8000
+// wave states of one group of 2D prefix sweeps: at most this many int32 (16 GiB)
+#define NRA_JOINT_STATE_CAP_INTS (4ull << 30)
 #define NRA_MAX_TLEN 65000     // payload (tstart) is 16 bits; + 64 pipeline columns
 
 #ifdef __cplusplus
@@ -143,10 +151,15 @@ int nra_launch_joint_bwd(int R, int has_n, hipStream_t st, int n_tasks, const Nr
                          const NraDevRead* reads, const NraDevRegion* regions, const uint8_t* pool,
                          const uint32_t* q2bit, const uint32_t* qnmask, NraScoreParams sp,
                          int32_t* snap, int32_t* read_a);
-int nra_launch_joint_fwd(int R, int has_n, hipStream_t st, int n_tasks, const NraJointTask* tasks,
-                         const NraDevRead* reads, const NraDevRegion* regions, const uint8_t* pool,
-                         const uint32_t* q2bit, const uint32_t* qnmask, NraScoreParams sp,
-                         int32_t* snap, int32_t* read_a, int32_t* cell_score, int32_t* cell_wscore);
+int nra_launch_joint_prefix(int R, int has_n, hipStream_t st, int n_tasks, const NraJointTask* tasks,
+                            const NraDevRead* reads, const NraDevRegion* regions, const uint8_t* pool,
+                            const uint32_t* q2bit, const uint32_t* qnmask, NraScoreParams sp,
+                            const int32_t* k1list, int32_t* state);
+int nra_launch_joint_tail(int R, int has_n, hipStream_t st, int n_tasks, const NraJointTask* tasks,
+                          const NraDevRead* reads, const NraDevRegion* regions, const uint8_t* pool,
+                          const uint32_t* q2bit, const uint32_t* qnmask, NraScoreParams sp,
+                          int32_t* state, int32_t* snap, int32_t* read_a, int32_t* cell_score,
+                          int32_t* cell_wscore);
 
 // alignment paths (nra_trace.hip)
 int nra_launch_trace_fill(int R, int has_n, hipStream_t st, int n_tasks, const NraTraceTask* tasks,

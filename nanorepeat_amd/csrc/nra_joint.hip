@@ -16,12 +16,22 @@
 //     (tk.py:480-485); read backwards that is -4 on the first base met (or on R[wr-1] when the
 //     run comes in from outside the window) and -2 after.  At the column of R[0] every row
 //     stores H, E_in, E2_in; the running maximum is A = the best alignment inside R.
-//   forward sweep (DIR 1): read vs L + u1^k1 + mid + u2^k2hi, window open from a = max(0,|L|-10)
+//   forward sweep: read vs L + u1^k1 + mid + u2^k2hi, window open from a = max(0,|L|-10)
 //     on.  At every requested k2 boundary each row combines with the R side:
 //        max(H, fresh) + Hb,   E_in + Eb_in + (q, +2),   E2_in + E2b_in + (q2, +2)
 //     -- a gap spanning the junction gets one open refunded, and +2 of window score, because
 //     both sides charged a "first overlapped base" --  and V = max(S, B, A) is the cell's
 //     (score, window score).
+//
+// The forward sweeps of one read share L + u1^k1 across its k1 values too.  A systolic wave is a
+// deterministic machine: its whole state is 3R+7 registers per lane.  So the forward sweep is cut
+// in two:
+//   prefix sweep (DIR 1), one per read: read vs L + u1^k1max; at step t = |L| + m1*k1 - 1, for
+//     every k1 of the read's cells, all lanes store their registers (lane 0 is about to take the
+//     LAST column of L + u1^k1; lane l is l columns behind, still inside the shared prefix);
+//   tail sweep (DIR 2), one per (read, k1) run of cells: loads that state and carries on with
+//     that last column followed by mid + u2^k2hi -- bit for bit the uninterrupted sweep over
+//     L + u1^k1 + mid + u2^k2hi, for 1 + |mid| + m2*k2hi + 63 steps instead of all of them.
 //
 // Preconditions checked on the host (else the cell goes to the brute-force kernel):
 // |L| >= 1, |R| >= 2, the k2 values of a (read, k1) form an arithmetic progression.
@@ -60,6 +70,8 @@ __global__ __launch_bounds__(WAVE) void k_joint_sweep(int n_tasks, const NraJoin
                                                       const uint32_t* __restrict__ q2bit,
                                                       const uint32_t* __restrict__ qnmask,
                                                       NraScoreParams sp,
+                                                      const int32_t* __restrict__ k1list,  // DIR 1: the read's k1 values, ascending
+                                                      int32_t* __restrict__ state,     // wave states: (3R+7) x 64 per (read, k1)
                                                       int32_t* __restrict__ snap,      // 3 x int32 per read base
                                                       int32_t* __restrict__ read_a,    // A per read (packed)
                                                       int32_t* __restrict__ cell_score,
@@ -75,15 +87,21 @@ __global__ __launch_bounds__(WAVE) void k_joint_sweep(int n_tasks, const NraJoin
     const int lenR = rg.l3;
     const int wr = imin(10, lenR);                      // window bases inside R
 
-    // template of this sweep
-    const int len1 = DIR ? rg.l1 + rg.m1 * tk.k1 : lenR;                       // piece 1
-    const int len2 = DIR ? rg.l2 + rg.m2 * (tk.k2lo + tk.k2step * (tk.n2 - 1)) : 0;
+    // template of this sweep, in the sweep's own column numbers v = 0, 1, ...:
+    //   DIR 0: rev(R);  DIR 1: L + u1^k1max up to the last state dump;
+    //   DIR 2: v = 0 is column t0 = |L| + m1*k1 - 1 of piece 1, then mid + u2^k2hi.
     const uint8_t* __restrict__ p1 = pool + (DIR ? rg.p1_off : rg.pr_off);
     const uint8_t* __restrict__ p2 = pool + rg.p2_off;
-    const int ncols = len1 + len2;
-    const int jfirst = DIR ? len1 + rg.l2 + rg.m2 * tk.k2lo - 1 : 0;            // first boundary column
-    const int jstep = DIR ? rg.m2 * tk.k2step : 1;
+    const int t0 = DIR == 2 ? rg.l1 + rg.m1 * tk.k1 - 1 : 0;                   // real column of v = 0
+    int si = 0;                                                                // DIR 1: next dump
+    int next_t = DIR == 1 ? rg.l1 + rg.m1 * k1list[tk.k1_off] - 1 : -1;
+    const int t_last = DIR == 1 ? rg.l1 + rg.m1 * k1list[tk.k1_off + tk.nk1 - 1] - 1 : 0;
+    const int ncols = DIR == 0 ? lenR : DIR == 1 ? t_last
+                                                 : 1 + rg.l2 + rg.m2 * (tk.k2lo + tk.k2step * (tk.n2 - 1));
+    const int vfirst = rg.l2 + rg.m2 * tk.k2lo;                                // DIR 2: first boundary
+    const int vstep = rg.m2 * tk.k2step;
     const int wa = imax(0, rg.l1 - 10);                                        // window start (forward)
+    constexpr int NSTATE = 3 * R + 7;
 
     int qc[R];
 #pragma unroll
@@ -100,8 +118,8 @@ __global__ __launch_bounds__(WAVE) void k_joint_sweep(int n_tasks, const NraJoin
     // forward sweep: the R side, row r pairs with reverse-sweep row Q-2-r.  The stored values carry
     // one JBIAS each; the combine adds two packed words, so one bias is taken out here, and the
     // gap-spanning terms get the refunds (one gap open, +2 window).
-    int Hbo[DIR ? R : 1], Ebo[DIR ? R : 1], E2bo[DIR ? R : 1];
-    if (DIR) {
+    int Hbo[DIR == 2 ? R : 1], Ebo[DIR == 2 ? R : 1], E2bo[DIR == 2 ? R : 1];
+    if (DIR == 2) {
         const int q1 = (sp.open1 - sp.ext1) << 16, q2 = (sp.open2 - sp.ext2) << 16;
 #pragma unroll
         for (int i = 0; i < R; ++i) {
@@ -123,21 +141,51 @@ __global__ __launch_bounds__(WAVE) void k_joint_sweep(int n_tasks, const NraJoin
     int M = fresh;                      // running lexicographic max of this lane's cells ((0, 0) to start)
     int accS = JNEG, accB = JNEG;
     int tt = NRA_PAD_T;
-    int j = -lane;
+    int j = t0 - lane;                  // real template column of this lane's next cell
     int ncur = 0;                       // boundary counter, meaningful in lane 63 only
 
-    const int nchunks = (ncols + 63 + 63) >> 6;
+    if (DIR == 2) {
+        // resume: the registers of every lane as the prefix sweep left them before step t0
+        const int32_t* __restrict__ sv = state + tk.state + lane;
+#pragma unroll
+        for (int i = 0; i < R; ++i) {
+            Hprev[i] = sv[(size_t)i * 64]; E[i] = sv[(size_t)(R + i) * 64]; E2[i] = sv[(size_t)(2 * R + i) * 64];
+        }
+        Hbot = sv[(size_t)(3 * R) * 64]; Fout = sv[(size_t)(3 * R + 1) * 64]; F2out = sv[(size_t)(3 * R + 2) * 64];
+        Hup_prev = sv[(size_t)(3 * R + 3) * 64]; M = sv[(size_t)(3 * R + 4) * 64];
+        accB = sv[(size_t)(3 * R + 5) * 64]; tt = sv[(size_t)(3 * R + 6) * 64];
+    }
+
+    // DIR 0 / 2 drain the pipeline (ncols + 63 steps); DIR 1 leaves at its last dump (step t_last)
+    const int nchunks = DIR == 1 ? (ncols >> 6) + 1 : (ncols + 63 + 63) >> 6;
     for (int c = 0; c < nchunks; ++c) {
         const int col = c * 64 + lane;
         int feed = NRA_PAD_T;
         if (col < ncols) {
-            feed = col < len1 ? p1[col] : p2[col - len1];
-            if (DIR) {
-                if (col >= jfirst && (col - jfirst) % jstep == 0 && (col - jfirst) / jstep < tk.n2) feed |= JFLAG_BOUNDARY;
-            } else if (col == lenR - 1) feed |= JFLAG_SNAPSHOT | JFLAG_BOUNDARY;
+            if (DIR == 2) {
+                feed = col == 0 ? p1[t0] : p2[col - 1];
+                if (col >= vfirst && (col - vfirst) % vstep == 0 && (col - vfirst) / vstep < tk.n2) feed |= JFLAG_BOUNDARY;
+            } else {
+                feed = p1[col];
+                if (DIR == 0 && col == lenR - 1) feed |= JFLAG_SNAPSHOT | JFLAG_BOUNDARY;
+            }
         }
 #pragma unroll 1   // unrolling the step loop twice takes minutes to compile at R >= 20
         for (int s = 0; s < 64; ++s) {
+            if (DIR == 1) {
+                if (c * 64 + s == next_t) {          // wave-uniform: dump the wave before this step
+                    int32_t* __restrict__ sv = state + tk.state + (size_t)si * (NSTATE * 64) + lane;
+#pragma unroll
+                    for (int i = 0; i < R; ++i) {
+                        sv[(size_t)i * 64] = Hprev[i]; sv[(size_t)(R + i) * 64] = E[i]; sv[(size_t)(2 * R + i) * 64] = E2[i];
+                    }
+                    sv[(size_t)(3 * R) * 64] = Hbot; sv[(size_t)(3 * R + 1) * 64] = Fout; sv[(size_t)(3 * R + 2) * 64] = F2out;
+                    sv[(size_t)(3 * R + 3) * 64] = Hup_prev; sv[(size_t)(3 * R + 4) * 64] = M;
+                    sv[(size_t)(3 * R + 5) * 64] = accB; sv[(size_t)(3 * R + 6) * 64] = tt;
+                    if (++si >= tk.nk1) return;
+                    next_t = rg.l1 + rg.m1 * k1list[tk.k1_off + si] - 1;
+                }
+            }
             int F = dpp_shr1(JNEG, Fout);
             int F2 = dpp_shr1(JNEG, F2out);
             tt = dpp_shr1(feed, tt);
@@ -201,7 +249,7 @@ __global__ __launch_bounds__(WAVE) void k_joint_sweep(int n_tasks, const NraJoin
             }
 #undef NRA_SUBST
             int tS = JNEG;
-            if (DIR) {
+            if (DIR == 2) {
                 if (__builtin_amdgcn_ballot_w64(at_boundary) != 0) {
 #pragma unroll
                     for (int i = 0; i < R; ++i) {
@@ -211,7 +259,7 @@ __global__ __launch_bounds__(WAVE) void k_joint_sweep(int n_tasks, const NraJoin
                         tS = imax(imax(tS, t1), imax(t2, t3));
                     }
                 }
-            } else if (tt & JFLAG_SNAPSHOT) {
+            } else if (DIR == 0 && (tt & JFLAG_SNAPSHOT)) {
 #pragma unroll
                 for (int i = 0; i < R; ++i) {
                     const int a = lane * R + i;
@@ -225,7 +273,7 @@ __global__ __launch_bounds__(WAVE) void k_joint_sweep(int n_tasks, const NraJoin
             accS = imax(accS_in, tS);
             accB = imax(accB_in, M);
 
-            if (lane == 63 && at_boundary) {
+            if (DIR != 1 && lane == 63 && at_boundary) {
                 if (DIR == 0) {
                     read_a[tk.read] = accB;                  // best alignment inside R (packed)
                 } else {
@@ -249,13 +297,14 @@ template <int DIR>
 static int launch_joint(int R, int has_n, hipStream_t st, int n_tasks, const NraJointTask* tasks,
                         const NraDevRead* reads, const NraDevRegion* regions, const uint8_t* pool,
                         const uint32_t* q2bit, const uint32_t* qnmask, NraScoreParams sp,
+                        const int32_t* k1list, int32_t* state,
                         int32_t* snap, int32_t* read_a, int32_t* cell_score, int32_t* cell_wscore)
 {
     if (n_tasks <= 0) return 0;
 #define CASE(r)                                                                                     \
     case r:                                                                                         \
-        if (has_n) k_joint_sweep<r, true, DIR><<<n_tasks, WAVE, 0, st>>>(n_tasks, tasks, reads, regions, pool, q2bit, qnmask, sp, snap, read_a, cell_score, cell_wscore); \
-        else k_joint_sweep<r, false, DIR><<<n_tasks, WAVE, 0, st>>>(n_tasks, tasks, reads, regions, pool, q2bit, qnmask, sp, snap, read_a, cell_score, cell_wscore);       \
+        if (has_n) k_joint_sweep<r, true, DIR><<<n_tasks, WAVE, 0, st>>>(n_tasks, tasks, reads, regions, pool, q2bit, qnmask, sp, k1list, state, snap, read_a, cell_score, cell_wscore); \
+        else k_joint_sweep<r, false, DIR><<<n_tasks, WAVE, 0, st>>>(n_tasks, tasks, reads, regions, pool, q2bit, qnmask, sp, k1list, state, snap, read_a, cell_score, cell_wscore);       \
         break;
     switch (R) {
         NRA_R_LIST(CASE)
@@ -271,15 +320,28 @@ extern "C" int nra_launch_joint_bwd(int R, int has_n, hipStream_t st, int n_task
                                     const uint32_t* q2bit, const uint32_t* qnmask, NraScoreParams sp,
                                     int32_t* snap, int32_t* read_a)
 {
-    return launch_joint<0>(R, has_n, st, n_tasks, tasks, reads, regions, pool, q2bit, qnmask, sp, snap, read_a, nullptr, nullptr);
+    return launch_joint<0>(R, has_n, st, n_tasks, tasks, reads, regions, pool, q2bit, qnmask, sp, nullptr, nullptr,
+                           snap, read_a, nullptr, nullptr);
 }
 #endif
 #if NRA_HAS_PART(8)
-extern "C" int nra_launch_joint_fwd(int R, int has_n, hipStream_t st, int n_tasks, const NraJointTask* tasks,
-                                    const NraDevRead* reads, const NraDevRegion* regions, const uint8_t* pool,
-                                    const uint32_t* q2bit, const uint32_t* qnmask, NraScoreParams sp,
-                                    int32_t* snap, int32_t* read_a, int32_t* cell_score, int32_t* cell_wscore)
+extern "C" int nra_launch_joint_prefix(int R, int has_n, hipStream_t st, int n_tasks, const NraJointTask* tasks,
+                                       const NraDevRead* reads, const NraDevRegion* regions, const uint8_t* pool,
+                                       const uint32_t* q2bit, const uint32_t* qnmask, NraScoreParams sp,
+                                       const int32_t* k1list, int32_t* state)
 {
-    return launch_joint<1>(R, has_n, st, n_tasks, tasks, reads, regions, pool, q2bit, qnmask, sp, snap, read_a, cell_score, cell_wscore);
+    return launch_joint<1>(R, has_n, st, n_tasks, tasks, reads, regions, pool, q2bit, qnmask, sp, k1list, state,
+                           nullptr, nullptr, nullptr, nullptr);
+}
+#endif
+#if NRA_HAS_PART(10)
+extern "C" int nra_launch_joint_tail(int R, int has_n, hipStream_t st, int n_tasks, const NraJointTask* tasks,
+                                     const NraDevRead* reads, const NraDevRegion* regions, const uint8_t* pool,
+                                     const uint32_t* q2bit, const uint32_t* qnmask, NraScoreParams sp,
+                                     int32_t* state, int32_t* snap, int32_t* read_a, int32_t* cell_score,
+                                     int32_t* cell_wscore)
+{
+    return launch_joint<2>(R, has_n, st, n_tasks, tasks, reads, regions, pool, q2bit, qnmask, sp, nullptr, state,
+                           snap, read_a, cell_score, cell_wscore);
 }
 #endif

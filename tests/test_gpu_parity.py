@@ -468,6 +468,11 @@ def test_2d_decomposition_matches_oracle_and_brute_force(capi, oracle):
             g = capi.joint_2d(j["region"], j["reads"], cr, k1, k2, flags=flags)
             for k in KEYS_2D:
                 assert np.array_equal(g[k], o[k]), (seed, flags, k, np.nonzero(g[k] != o[k])[0][:8], g[k][:10], o[k][:10])
+        # state buffer reused group by group (one read per group), and all strands given (no probe)
+        g2 = capi.joint_2d(j["region"], j["reads"], cr, k1, k2, flags=capi.F_TEST_CHAIN)
+        g3 = capi.joint_2d(j["region"], j["reads"], cr, k1, k2, read_strand=o["read_strand"].copy())
+        for k in KEYS_2D:
+            assert np.array_equal(g2[k], o[k]) and np.array_equal(g3[k], o[k]), (seed, k)
     # cells of a read in arbitrary order (runs of length 1, descending k2, repeated cells)
     j = synth.make_joint(5, alleles=((6, 4), (11, 3)), read_len=450, read_sd=20, anchor=200, seed=64)
     rng = np.random.default_rng(6)

@@ -90,7 +90,7 @@ def fuzz_2d(rng):
         o = O.joint_2d((L, u1, mid, u2, R), reads, cr, k1, k2, sc=O.default_scoring(**sc))
     except ValueError:
         return None
-    for flags in (0, A.F_BRUTE_FORCE):
+    for flags in (0, A.F_BRUTE_FORCE, A.F_TEST_CHAIN):
         g = A.joint_2d((L, u1, mid, u2, R), reads, cr, k1, k2, sc=A.default_scoring(**sc), flags=flags)
         for k in K2:
             if not np.array_equal(g[k], o[k]):
