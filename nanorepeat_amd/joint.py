@@ -49,6 +49,7 @@ class Round1Estimation:
         self.repeat2_count_range_dict = dict()
         self.potential_repeat_region_dict = dict()
         self.bad_reads_set = set()
+        self.read_strand_dict = dict()      # not in the reference: +1 / -1 from round 1, saves the strand probe
 
 
 class RepeatSize:
@@ -151,6 +152,7 @@ def round1_estimation_for1read(read_paf_list, repeat1, repeat2, left_anchor_len,
     if candidate[1] - candidate[0] <= 0:
         initial_estimation.bad_reads_set.add(readname)
     initial_estimation.potential_repeat_region_dict[readname] = candidate
+    initial_estimation.read_strand_dict[readname] = 1 if left_paf.strand == "+" else -1
 
 
 def round1_estimation_from_paf(paf_records, repeat1, repeat2, left_anchor_len, right_anchor_len):
@@ -191,7 +193,7 @@ def initial_estimate_repeat_size(repeat_chrom_seq, fastq_dict, data_type, num_th
     calls become: one score-only `nra_align_pairs` call that picks each read's strand per
     template (the lower strand would be a secondary record, which :602 drops), then one
     `nra_align_pairs_cigar` call for the chosen (read, template) pairs -- the CIGAR is needed for
-    the exact-match estimate.  Reads are DP queries here (<= 3072 bases).  mapq is taken as 60."""
+    the exact-match estimate.  mapq is taken as 60."""
     from .paf import PAF, format_paf_line
     from .upstream import rev_comp
     assert repeat1.chrom == repeat2.chrom and repeat1.start < repeat2.start
@@ -200,13 +202,23 @@ def initial_estimate_repeat_size(repeat_chrom_seq, fastq_dict, data_type, num_th
     left, right, left_anchor_len, right_anchor_len = round1_templates(repeat_chrom_seq, repeat1, repeat2, max_anchor_len)
     names = list(fastq_dict)
     seqs = [left[1], right[1]]
+    swap_ops = str.maketrans("ID", "DI")
+    # A read is the DP's query (rows) and the template its target, as in a PAF record -- unless the
+    # read is longer than the kernels hold in registers: then the template is the query and the
+    # read the target (same score; extents and CIGAR are swapped back below; only the choice among
+    # co-optimal paths can differ from the read-as-query alignment).
+    long_read = []
     pq, pt = [], []
     for i, n in enumerate(names):
         s = _read_seq(fastq_dict[n])
         seqs += [s, rev_comp(s)]
+        long_read.append(len(s) > MAX_READ_2D)
         for t in (0, 1):
             for o in (0, 1):
-                pq.append(2 + 2 * i + o); pt.append(t)
+                a, b = 2 + 2 * i + o, t
+                if long_read[i]:
+                    a, b = b, a
+                pq.append(a); pt.append(b)
     records = []
     if names:
         probe = aligner(seqs, np.array(pq, np.int32), np.array(pt, np.int32), sc=scoring, device=device)
@@ -217,16 +229,22 @@ def initial_estimate_repeat_size(repeat_chrom_seq, fastq_dict, data_type, num_th
                 if max(fwd, rev) < 0:
                     continue
                 o = 0 if fwd >= rev else 1
-                cq.append(2 + 2 * i + o); ct.append(t); who.append((n, t, "+-"[o]))
+                a, b = 2 + 2 * i + o, t
+                if long_read[i]:
+                    a, b = b, a
+                cq.append(a); ct.append(b); who.append((n, i, t, "+-"[o], 2 + 2 * i + o))
         got = cigar_aligner(seqs, cq, ct, sc=scoring, device=device) if cq else None
-        for j, (n, t, strand) in enumerate(who):
+        for j, (n, i, t, strand, read_idx) in enumerate(who):
             if int(got["score"][j]) < 0:
                 continue
             tname, tseq = (left, right)[t]
-            line = format_paf_line(n, len(seqs[cq[j]]), int(got["qstart"][j]), int(got["qend"][j]), strand, tname,
-                                   len(tseq), int(got["tstart"][j]), int(got["tend"][j]), int(got["score"][j]),
-                                   got["cigar"][j])
-            records.append(line)
+            qs, qe, ts, te = (int(got[k][j]) for k in ("qstart", "qend", "tstart", "tend"))
+            cigar = got["cigar"][j]
+            if long_read[i]:
+                qs, qe, ts, te = ts, te, qs, qe
+                cigar = cigar.translate(swap_ops)
+            records.append(format_paf_line(n, len(seqs[read_idx]), qs, qe, strand, tname, len(tseq), ts, te,
+                                           int(got["score"][j]), cigar))
     if save_paf and out_dir:
         with open(f"{out_dir}/round1.paf", "w") as f:
             f.write("".join(r + "\n" for r in sorted(records, key=lambda r: r.split("\t")[0])))
@@ -238,11 +256,32 @@ def _read_seq(fastq_record):
     return fastq_record.split("\n")[1].strip()
 
 
-def _score_cells(region, readnames, fastq_dict, cells_by_read, device, scoring, scorer, strands):
+MAX_READ_2D = 3072          # rows one wave holds in the joint kernels (NRA_MAX_QLEN_1BLOCK)
+TRIM_MARGIN = 50
+
+
+def cut_long_read(seq, candidate, limit=MAX_READ_2D, margin=TRIM_MARGIN):
+    """A read longer than the joint kernels take is cut to the part round 1 found to hold the
+    anchors and both repeats (`potential_repeat_region_dict`, nanoRepeat_joint.py:639-648 -- the
+    reference computes it and never uses it) plus a margin; if that is still too long, both
+    flanks lose the same number of bases.  Coordinates are on the read as given (either strand)."""
+    if len(seq) <= limit:
+        return seq
+    if candidate is None:
+        raise ValueError(f"read of {len(seq)} bases without a round-1 region: joint scoring takes <= {limit} bases")
+    lo, hi = max(0, candidate[0] - margin), min(len(seq), candidate[1] + margin)
+    if hi - lo > limit:
+        cut = hi - lo - limit
+        lo += cut // 2
+        hi -= cut - cut // 2
+    return seq[lo:hi]
+
+
+def _score_cells(region, readnames, fastq_dict, cells_by_read, device, scoring, scorer, strands, candidates=None):
     """One C-ABI call for every (read, k1, k2) cell; returns (RepeatSize, raw outputs)."""
     scorer = scorer or _capi.joint_2d
     names = [n for n in readnames if cells_by_read.get(n)]
-    reads = [_read_seq(fastq_dict[n]) for n in names]
+    reads = [cut_long_read(_read_seq(fastq_dict[n]), (candidates or {}).get(n)) for n in names]
     cell_read, k1, k2 = [], [], []
     for i, n in enumerate(names):
         for a, b in cells_by_read[n]:
@@ -287,7 +326,8 @@ def round2_estimation_of_repeat_size(initial_estimation, fastq_dict, repeat_chro
                 if min1 <= repeat_count1 < max1 and min2 <= repeat_count2 < max2:
                     cells.setdefault(readname, []).append((repeat_count1, repeat_count2))
     region = (left, repeat1.repeat_unit, mid, repeat2.repeat_unit, right)
-    est, _ = _score_cells(region, list(fastq_dict), fastq_dict, cells, device, scoring, scorer, strands)
+    est, _ = _score_cells(region, list(fastq_dict), fastq_dict, cells, device, scoring, scorer, strands,
+                          getattr(initial_estimation, "potential_repeat_region_dict", None))
     est.step_size1 = step_size1
     est.step_size2 = step_size2
     return est
@@ -331,7 +371,8 @@ def round3_estimation_of_repeat_size(initial_estimation, round2_estimation, fast
                 if repeat_count2 < r1min2 or repeat_count2 >= r1max2: continue
                 cells.setdefault(readname, []).append((repeat_count1, repeat_count2))
     region = (left, repeat1.repeat_unit, mid, repeat2.repeat_unit, right)
-    est, _ = _score_cells(region, list(fastq_dict), fastq_dict, cells, device, scoring, scorer, strands)
+    est, _ = _score_cells(region, list(fastq_dict), fastq_dict, cells, device, scoring, scorer, strands,
+                          getattr(initial_estimation, "potential_repeat_region_dict", None))
     est.step_size1 = 1
     est.step_size2 = 1
     return est
@@ -356,7 +397,8 @@ def fine_tune_read_count(initial_estimation, fastq_dict, repeat_chrom_seq, repea
         repeat2.round1_min_size = min(repeat2.round1_min_size, lo)
     repeat1.round1_max_size = min(repeat1.round1_max_size, repeat1.max_size)
     repeat2.round1_max_size = min(repeat2.round1_max_size, repeat2.max_size)
-    strands = {}
+    # a read's strand is known from round 1 when that was run here (the left template is forward)
+    strands = dict(getattr(initial_estimation, "read_strand_dict", {}))
     round2_estimation = round2_estimation_of_repeat_size(
         initial_estimation, fastq_dict, repeat_chrom_seq, repeat1, repeat2, data_type, num_threads,
         out_dir, device, scoring, scorer, strands)
