@@ -777,7 +777,7 @@ int nra_batch2d_create(int device, const nra_joint_region_t* reg, int32_t n_read
         bk.pair_off = pair_tasks.size();
         bk.queue_off = queue_tasks.size();
         bk.jbwd_off = jbwd.size();
-        const uint64_t slot = (uint64_t)(3 * bk.R + 7) * 64;
+        const uint64_t slot = (uint64_t)NRA_JOINT_NSTATE(bk.R) * 64;
         JointGroup g; g.R = bk.R; g.bucket = (int)b->buckets.size(); g.pre_off = jpre.size(); g.tail_off = jtail.size();
         uint64_t used = 0, state_max = 0;
         const size_t bucket_pre0 = jpre.size(), bucket_tail0 = jtail.size();

@@ -101,6 +101,9 @@ struct NraScoreParams {
 #define NRA_CHAIN_R 24
 #define NRA_CHAIN_R_TEST 2                     // tiny row blocks, for the tests (NRA_F_TEST_CHAIN)
 #define NRA_MAX_QLEN 8000
+// int32 values per lane in one dumped wave state of the 2D prefix sweep (3 per row + 7), shared by
+// the kernel and the host so that the two cannot disagree
+#define NRA_JOINT_NSTATE(R) (3 * (R) + 7)
 // wave states of one group of 2D prefix sweeps: at most this many int32 (16 GiB)
 #define NRA_JOINT_STATE_CAP_INTS (4ull << 30)
 #define NRA_MAX_TLEN 65000     // payload (tstart) is 16 bits; + 64 pipeline columns

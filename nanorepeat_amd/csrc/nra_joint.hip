@@ -62,8 +62,18 @@ __device__ __forceinline__ int oriented_code(const NraDevRead& rd, const uint32_
     return c;
 }
 
+// Waves per SIMD to aim for (512 VGPRs per lane and SIMD): a sweep keeps 4 registers per row (H,
+// E_in, E2_in, the read base) -- 7 in the tail sweep, which also holds the R side -- and ~45 more.
+// Without the hint the compiler spends every register its occupancy bracket has (R = 18: 239).
+constexpr int joint_waves(int R, int DIR)
+{
+    const int need = (DIR == 2 ? 7 : 4) * R + 70;
+    const int w = 512 / need;
+    return w < 1 ? 1 : (w > 8 ? 8 : w);
+}
+
 template <int R, bool HAS_N, int DIR>
-__global__ __launch_bounds__(WAVE) void k_joint_sweep(int n_tasks, const NraJointTask* __restrict__ tasks,
+__global__ __launch_bounds__(WAVE, joint_waves(R, DIR)) void k_joint_sweep(int n_tasks, const NraJointTask* __restrict__ tasks,
                                                       const NraDevRead* __restrict__ reads,
                                                       const NraDevRegion* __restrict__ regions,
                                                       const uint8_t* __restrict__ pool,
@@ -101,13 +111,16 @@ __global__ __launch_bounds__(WAVE) void k_joint_sweep(int n_tasks, const NraJoin
     const int vfirst = rg.l2 + rg.m2 * tk.k2lo;                                // DIR 2: first boundary
     const int vstep = rg.m2 * tk.k2step;
     const int wa = imax(0, rg.l1 - 10);                                        // window start (forward)
-    constexpr int NSTATE = 3 * R + 7;
+    constexpr int NSTATE = NRA_JOINT_NSTATE(R);
 
-    int qc[R];
+    // the lane's read bases, four per register (byte-select compares cost nothing extra)
+    uint32_t qcp[(R + 3) / 4];
+#pragma unroll
+    for (int i = 0; i < (R + 3) / 4; ++i) qcp[i] = 0;
 #pragma unroll
     for (int i = 0; i < R; ++i) {
         const int r = lane * R + i;
-        qc[i] = oriented_code<HAS_N>(rd, q2bit, qnmask, DIR ? r : (r < Q ? Q - 1 - r : -1));
+        qcp[i >> 2] |= (uint32_t)oriented_code<HAS_N>(rd, q2bit, qnmask, DIR ? r : (r < Q ? Q - 1 - r : -1)) << (8 * (i & 3));
     }
 
     const int sA = sp.match << 16, sB = -(sp.mismatch << 16), sN = -(sp.ambi << 16);
@@ -157,23 +170,28 @@ __global__ __launch_bounds__(WAVE) void k_joint_sweep(int n_tasks, const NraJoin
     }
 
     // DIR 0 / 2 drain the pipeline (ncols + 63 steps); DIR 1 leaves at its last dump (step t_last)
-    const int nchunks = DIR == 1 ? (ncols >> 6) + 1 : (ncols + 63 + 63) >> 6;
-    for (int c = 0; c < nchunks; ++c) {
-        const int col = c * 64 + lane;
-        int feed = NRA_PAD_T;
-        if (col < ncols) {
-            if (DIR == 2) {
-                feed = col == 0 ? p1[t0] : p2[col - 1];
-                if (col >= vfirst && (col - vfirst) % vstep == 0 && (col - vfirst) / vstep < tk.n2) feed |= JFLAG_BOUNDARY;
-            } else {
-                feed = p1[col];
-                if (DIR == 0 && col == lenR - 1) feed |= JFLAG_SNAPSHOT | JFLAG_BOUNDARY;
-            }
-        }
+    // One flat step loop (a chunk loop around a 64-step loop made the compiler keep two copies of
+    // the row registers).  Every 64 steps the lanes fetch the next 64 template columns.
+    const int nsteps = DIR == 1 ? ncols + 1 : ((ncols + 63 + 63) >> 6) << 6;
+    int feed = NRA_PAD_T;
 #pragma unroll 1   // unrolling the step loop twice takes minutes to compile at R >= 20
-        for (int s = 0; s < 64; ++s) {
+    for (int step = 0; step < nsteps; ++step) {
+        {
+            if ((step & 63) == 0) {
+                const int col = step + lane;
+                feed = NRA_PAD_T;
+                if (col < ncols) {
+                    if (DIR == 2) {
+                        feed = col == 0 ? p1[t0] : p2[col - 1];
+                        if (col >= vfirst && (col - vfirst) % vstep == 0 && (col - vfirst) / vstep < tk.n2) feed |= JFLAG_BOUNDARY;
+                    } else {
+                        feed = p1[col];
+                        if (DIR == 0 && col == lenR - 1) feed |= JFLAG_SNAPSHOT | JFLAG_BOUNDARY;
+                    }
+                }
+            }
             if (DIR == 1) {
-                if (c * 64 + s == next_t) {          // wave-uniform: dump the wave before this step
+                if (step == next_t) {                // wave-uniform: dump the wave before this step
                     int32_t* __restrict__ sv = state + tk.state + (size_t)si * (NSTATE * 64) + lane;
 #pragma unroll
                     for (int i = 0; i < R; ++i) {
@@ -182,7 +200,7 @@ __global__ __launch_bounds__(WAVE) void k_joint_sweep(int n_tasks, const NraJoin
                     sv[(size_t)(3 * R) * 64] = Hbot; sv[(size_t)(3 * R + 1) * 64] = Fout; sv[(size_t)(3 * R + 2) * 64] = F2out;
                     sv[(size_t)(3 * R + 3) * 64] = Hup_prev; sv[(size_t)(3 * R + 4) * 64] = M;
                     sv[(size_t)(3 * R + 5) * 64] = accB; sv[(size_t)(3 * R + 6) * 64] = tt;
-                    if (++si >= tk.nk1) return;
+                    if (++si >= tk.nk1) break;
                     next_t = rg.l1 + rg.m1 * k1list[tk.k1_off + si] - 1;
                 }
             }
@@ -215,10 +233,11 @@ __global__ __launch_bounds__(WAVE) void k_joint_sweep(int n_tasks, const NraJoin
             const int fo1 = o1 + fo, fx1 = x1 + fx, fo2 = o2 + fo, fx2 = x2 + fx;
 #define NRA_SUBST(i, out)                                                                          \
             {                                                                                      \
-                const bool eq_ = qc[i] == tcode;                                                   \
+                const int qc_ = (int)((qcp[(i) >> 2] >> (8 * ((i) & 3))) & 0xffu);                 \
+                const bool eq_ = qc_ == tcode;                                                     \
                 out = eq_ ? s_eq : s_ne;                                                           \
                 if (HAS_N) {                                                                       \
-                    if ((qc[i] | tcode) & 4) out = eq_ ? n_eq : n_ne;                              \
+                    if ((qc_ | tcode) & 4) out = eq_ ? n_eq : n_ne;                                \
                 }                                                                                  \
             }
             int sc;

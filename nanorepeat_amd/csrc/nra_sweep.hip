@@ -247,26 +247,32 @@ __global__ __launch_bounds__(WAVE) void k_sweep_pk16(int n_tasks, const NraSweep
     int ttA = tbl_mis4, ttB = tbl_mis4;                   // padding column: everything mismatches
     int kcur = tk.kmin;                                   // meaningful in lane 63 only
 
-    const int nchunks = (ncols + 127 + 63) >> 6;          // 128 cells deep
-    for (int c = 0; c < nchunks; ++c) {
-        const int col = c * 64 + lane;
-        int feed = tbl_mis4;
-        if (col < ncols) {
-            const int code = piece[col];
-            feed = code < 4 ? tbl_mis4 + ((s_match - s_mis) << (8 * code)) : tbl_ambi4;
-            if (col >= jfirst && (col - jfirst) % m == 0) feed |= FLAG_BOUNDARY;
-            if (DIR == 0 && col == flank - 1) feed |= FLAG_SNAPSHOT;
-        }
-        // what enters cell 0 at each column: constants for the first row block, else the strip
-        int inH = v_floor, inF = NEG1, inF2 = NEG1, inS = NEG2, inB = NEG1;
-        if (CHAIN) {
-            if (!first_blk && col < ncols) {
-                inH = cin[col]; inF = cin[chain_cap + col]; inF2 = cin[2 * chain_cap + col];
-                inS = cin[3 * chain_cap + col]; inB = cin[4 * chain_cap + col];
+    // One flat step loop (128 cells deep; a chunk loop around a 64-step loop costs registers: the
+    // compiler keeps the row arrays twice).  Every 64 steps the lanes fetch the next 64 columns.
+    const int nsteps = ((ncols + 127 + 63) >> 6) << 6;
+    int feed = tbl_mis4;
+    // what enters cell 0 at each column: constants for the first row block, else the strip
+    int inH = v_floor, inF = NEG1, inF2 = NEG1, inS = NEG2, inB = NEG1;
+#pragma unroll 1   // two steps per trip would turn the hand-offs into renames but cost ~14 registers
+    for (int step = 0; step < nsteps; ++step) {
+        {
+            if ((step & 63) == 0) {
+                const int col = step + lane;
+                feed = tbl_mis4;
+                if (col < ncols) {
+                    const int code = piece[col];
+                    feed = code < 4 ? tbl_mis4 + ((s_match - s_mis) << (8 * code)) : tbl_ambi4;
+                    if (col >= jfirst && (col - jfirst) % m == 0) feed |= FLAG_BOUNDARY;
+                    if (DIR == 0 && col == flank - 1) feed |= FLAG_SNAPSHOT;
+                }
+                if (CHAIN) {
+                    inH = v_floor; inF = NEG1; inF2 = NEG1; inS = NEG2; inB = NEG1;
+                    if (!first_blk && col < ncols) {
+                        inH = cin[col]; inF = cin[chain_cap + col]; inF2 = cin[2 * chain_cap + col];
+                        inS = cin[3 * chain_cap + col]; inB = cin[4 * chain_cap + col];
+                    }
+                }
             }
-        }
-#pragma unroll 2
-        for (int s = 0; s < 64; ++s) {
             // inputs of cell A: cell B of the lane above, as it stood after the previous step
             const int hupA = dpp_shr1(CHAIN ? inH : v_floor, HbotB);
             int FA = dpp_shr1(CHAIN ? inF : NEG1, FoutB);
@@ -318,7 +324,7 @@ __global__ __launch_bounds__(WAVE) void k_sweep_pk16(int n_tasks, const NraSweep
                     sweep_snapshot<RA, RB, R>(Hq, E, E2, row_base + lane * R, rda, rdb, has_b, o1, snap_h, snap_e, snap_e2);
             }
             if (CHAIN) {
-                const int col_out = c * 64 + s - 127;     // the column cell 127 has just finished
+                const int col_out = step - 127;           // the column cell 127 has just finished
                 if (lane == 63 && !last_blk && col_out >= 0 && col_out < ncols) {
                     cout[col_out] = HbotB; cout[chain_cap + col_out] = FoutB; cout[2 * chain_cap + col_out] = F2outB;
                     cout[3 * chain_cap + col_out] = accS_B; cout[4 * chain_cap + col_out] = accB_B;
