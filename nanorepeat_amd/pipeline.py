@@ -1,7 +1,7 @@
 """Steps 1-4 of quantify1repeat_from_bam (nanoRepeat_bam.py:614-686) for one or many regions,
 from reads already extracted for the region: anchors -> core -> rounds 1-2 -> round 3 -> the
 `repeat_size.txt` text -> GMM phasing -> one row of `NanoRepeat_output.tsv` per region.
-BAM extraction is outside this build."""
+`quantify_from_bam` and `quantify_joint` are the two commands from files to files."""
 from . import upstream, round3, phasing, joint, io as nr_io
 
 
@@ -75,3 +75,45 @@ def quantify_joint(in_fq, ref_fasta, repeat1_string, repeat2_string, out_prefix,
                                                  max_num_components, repeat1, repeat2, joint_counts, 0, in_fq,
                                                  out_prefix, seed=seed)
     return final_estimation, alleles
+
+
+def quantify_from_bam(in_bam_file, ref_fasta, repeat_region_bed, out_prefix, data_type="ont", anchor_len=1000,
+                      fast_mode=False, ploidy=2, max_mutual_overlap=0.15, max_num_components=-1,
+                      remove_noisy_reads=False, no_check_repeat_motif_in_ref=False, no_details=False,
+                      num_cpu=1, device=0, scoring=None, seed=None, **engines):
+    """The BAM command from files to files (nanoRepeat_bam.py:614-751): for every region of the BED
+    file, reads from the alignment file -> `<out_prefix>.details/<chr>/<region>.*` ->
+    `<out_prefix>.NanoRepeat_output.tsv`.  The reference forks up to 16 workers, one region each;
+    here steps 1-2 run region by region and step 3 for all regions in one GPU batch.  Regions
+    without reads, or whose reference sequence fails the motif check, get their row with 0
+    alleles like in the reference.  Returns the regions."""
+    import os
+    from . import bam as nr_bam
+    regions = nr_io.read_repeat_region_file(repeat_region_bed, no_details)
+    ref_fasta_dict = nr_io.fasta_file2dict(ref_fasta)
+    live, reads_of = [], []
+    for i, region in enumerate(regions):
+        region.index = i
+        chrom_dir = region.chrom if region.chrom[0:3].lower() == "chr" else "chr" + region.chrom
+        out_dir = f"{out_prefix}.details/{chrom_dir}"
+        os.makedirs(out_dir, exist_ok=True)
+        region.out_prefix = f"{out_dir}/{phasing.outfile_prefix(region)}"
+        region.region_fq_file = f"{region.out_prefix}.reads.fastq"
+        n = nr_bam.extract_fastq_from_bam(in_bam_file, region, anchor_len, region.region_fq_file, ref_fasta)
+        if n == 0:
+            continue
+        nr_io.extract_ref_sequence(ref_fasta_dict, region, anchor_len)
+        if not no_check_repeat_motif_in_ref and not nr_io.check_repeat_motif_in_ref(region):
+            continue
+        live.append(region)
+        reads_of.append(nr_io.read_fastq(region.region_fq_file))
+    quantify_regions(live, reads_of, data_type, fast_mode, num_cpu, device, scoring,
+                     engines.get("aligner"), engines.get("scorer"))
+    phase_regions(live, data_type, ploidy, max_mutual_overlap, max_num_components, remove_noisy_reads, seed)
+    with open(f"{out_prefix}.NanoRepeat_output.tsv", "w") as f:
+        for region in regions:
+            f.write(phasing.final_output_row(region))
+    if no_details:
+        import shutil
+        shutil.rmtree(f"{out_prefix}.details", ignore_errors=True)
+    return regions

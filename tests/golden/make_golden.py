@@ -601,6 +601,37 @@ def gen_io(tmp):
     fx["flanks"] = cases
     fx["one_chr"] = {n: hashlib.sha1(tk.read_one_chr_from_fasta_file(fa, n).encode()).hexdigest()
                      for n in ("chr4", "7", "chrM", "nope")}
+    # reads of a region from an alignment file (nanoRepeat_bam.py:576-600) with a stand-in for pysam
+    recs = [["r1", "ACGTACGTAC", [30] * 10, 900, 1400], ["r2", "GGGTTTAAAC", None, 1190, 1300],
+            ["r1", "TTTT", [1, 2, 3, 4], 1250, 1254], ["r3", "", None, 1200, 1201], ["r4", None, None, 1200, 1300],
+            ["r5", "CCCCC", [0, 41, 60, 93, 2], 1359, 1364], ["r6", "AAAAA", [9] * 5, 1360, 1365],
+            ["r7", "TTTTT", [9] * 5, 100, 1141], ["r8", "GGGGG", [9] * 5, 100, 1140]]
+    calls = []
+
+    class FakeRead:
+        def __init__(self, r):
+            self.query_name, self.query_sequence, self.query_qualities, self.pos, self.end = r
+
+    class FakeAlignmentFile:
+        def __init__(self, path, mode, reference_filename=None):
+            calls.append(["open", os.path.basename(path), mode, reference_filename])
+
+        def fetch(self, chrom, start, end):
+            calls.append(["fetch", chrom, start, end])
+            return [FakeRead(r) for r in recs if r[3] < end and r[4] > start]
+
+        def close(self):
+            calls.append(["close"])
+
+    ref_bam.pysam.AlignmentFile = FakeAlignmentFile
+    bam_cases = []
+    for chrom, st, en, flank in (("chr4", 1200, 1260, 100), ("chr4", 40, 60, 100), ("chr4", 1200, 1260, 0)):
+        rr = ref_rr.RepeatRegion(f"{chrom}\t{st}\t{en}\tCAG")
+        out_fq = os.path.join(tmp, "bam_out.fastq")
+        del calls[:]
+        ref_bam.extract_fastq_from_bam(types.SimpleNamespace(ref_fasta="ref.fa"), os.path.join(tmp, "in.bam"), rr, flank, out_fq)
+        bam_cases.append({"region": [chrom, st, en], "flank": flank, "calls": list(calls), "fastq": open(out_fq).read()})
+    fx["bam_extract"] = {"records": recs, "cases": bam_cases}
     fq = os.path.join(tmp, "x.fastq")
     fq_text = "@a first\nACGT\n+\nIIII\n@b\nGGNA\n+b\n!!!!\n@a again\nTT\n+\nII\n@trunc\nAC\n"
     open(fq, "w").write(fq_text)
