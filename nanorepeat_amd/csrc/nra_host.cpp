@@ -163,7 +163,8 @@ struct nra_batch {
     DevBuf<NraPairTask> pair_tasks;
     DevBuf<NraSweepTask> sweep_tasks;
     DevBuf<int16_t> snap_h, snap_e, snap_e2;   // R side of the junction, one entry per read base
-    DevBuf<int32_t> arr_a;                     // A_k per candidate
+    DevBuf<int32_t> arr_a;                     // A_k per candidate (chained reads only)
+    DevBuf<int32_t> read_a1d;                  // A per read: best alignment inside R (origin-bit scheme)
     DevBuf<uint8_t> cand_flag;                 // flank verdict per candidate
     bool brute = false;                        // K independent alignments instead of the sweeps
     DevBuf<int32_t> chain_sweep, chain_payload; // scratch strips of the chained row blocks
@@ -389,8 +390,9 @@ int nra_batch1d_create(int device, const nra_region_t* regions, int32_t n_region
     for (int32_t g = 0; g < n_regions; ++g)       // the junction needs a base on either side
         if (regions[g].left_len < 1 || regions[g].right_len < 1) brute = true;
     {   // the sweep kernels keep (substitution score + gap-open cost) in unsigned table bytes
+        // (doubled: the low bit of every state is the origin bit)
         const int o1 = sc->gap_open1 + sc->gap_ext1;
-        if (o1 < sc->mismatch || o1 < sc->sc_ambi || sc->match + o1 > 127) brute = true;
+        if (o1 < sc->mismatch || o1 < sc->sc_ambi || 2 * (sc->match + o1) > 127) brute = true;
     }
     b->brute = brute;
     std::vector<NraSweepTask> sweep_tasks;
@@ -485,7 +487,9 @@ int nra_batch1d_create(int device, const nra_region_t* regions, int32_t n_region
                 int qmax = pr.reads[t.read_a].qlen;
                 if (t.read_b >= 0) qmax = std::max(qmax, pr.reads[t.read_b].qlen);
                 const int nblk = bk.chain ? (qmax + 64 * bk.R - 1) / (64 * bk.R) : 1;
-                bk.cells_sweep += (int64_t)nblk * 2 * (sweep_cells(bk.R, d.l1 + d.m1 * t.kmax + 64) + sweep_cells(bk.R, d.l3 + d.m1 * t.kmax + 64));
+                // chained reads sweep rev(unit)^kmax for A_k; the others stop at the end of rev(R)
+                bk.cells_sweep += (int64_t)nblk * 2 * (sweep_cells(bk.R, d.l1 + d.m1 * t.kmax + 64) +
+                                                       sweep_cells(bk.R, d.l3 + (bk.chain ? d.m1 * t.kmax : 0) + 64));
                 sweep_tasks.push_back(t);
             }
             bk.n_sweep = (int)(sweep_tasks.size() - bk.sweep_off);
@@ -512,6 +516,7 @@ int nra_batch1d_create(int device, const nra_region_t* regions, int32_t n_region
         HIP_TRY(b->snap_e.alloc(nbases));
         HIP_TRY(b->snap_e2.alloc(nbases));
         HIP_TRY(b->arr_a.alloc((size_t)total));
+        HIP_TRY(b->read_a1d.alloc((size_t)n_reads));
     }
     HIP_TRY(b->cand_flag.alloc((size_t)total));
     for (const Bucket& bk : b->buckets) {
@@ -587,13 +592,13 @@ static int run_1d(nra_batch* b)
             LAUNCH_TRY(nra_launch_sweep_bwd(bk.R, b->has_n, bk.chain ? 1 : 0, q, bk.n_sweep, b->sweep_tasks.p + bk.sweep_off,
                                             b->reads.p, b->regions.p, b->pool.p, b->q2bit.p, b->qnmask.p, b->sp,
                                             b->kmin.p, b->kmax.p, b->coff.p, b->snap_h.p, b->snap_e.p,
-                                            b->snap_e2.p, b->arr_a.p, b->chain_sweep.p, b->chain_cap));
+                                            b->snap_e2.p, b->arr_a.p, b->read_a1d.p, b->chain_sweep.p, b->chain_cap));
             HIP_TRY(hipEventRecord(b->ev[ev++], q));
             HIP_TRY(hipEventRecord(b->ev[ev++], q));
             LAUNCH_TRY(nra_launch_sweep_fwd(bk.R, b->has_n, bk.chain ? 1 : 0, q, bk.n_sweep, b->sweep_tasks.p + bk.sweep_off,
                                             b->reads.p, b->regions.p, b->pool.p, b->q2bit.p, b->qnmask.p, b->sp,
                                             b->kmin.p, b->kmax.p, b->coff.p, b->snap_h.p, b->snap_e.p,
-                                            b->snap_e2.p, b->arr_a.p, b->cand_score.p, b->cand_flag.p,
+                                            b->snap_e2.p, b->arr_a.p, b->read_a1d.p, b->cand_score.p, b->cand_flag.p,
                                             b->chain_sweep.p, b->chain_cap));
             HIP_TRY(hipEventRecord(b->ev[ev++], q));
             b->n_score_ev += 2;

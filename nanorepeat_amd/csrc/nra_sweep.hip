@@ -28,6 +28,18 @@
 //   right flank (tend > |L|+m*k)    passes  if  B_k < Score;  fails if B_k == Score > S_k;
 //                                   B_k == S_k == Score is ambiguous -> explicit extents DP.
 //
+// Reads that fit one register block (<= 3072 bases, CHAIN = false) do not sweep rev(unit)^kmax at
+// all.  A_k is only needed to know whether an optimal alignment STARTS at a column >= |L|, and
+// that is one bit of payload: all scores are doubled and the low bit of a state says "the best
+// path into this state (largest bit among co-optimal ones) starts at column >= |L|".  An
+// alignment starting at column j enters through max(H(i-1,j-1), 0): the 0 becomes 0|1 for
+// j >= |L| (a flag travelling with the template column), every other operation adds even
+// numbers, and max() on 2*score+bit is the lexicographic max.  So the forward sweep alone
+// yields (Score, bit) of S_k and B_k, the reverse sweep shrinks to rev(R) -- it leaves the R
+// side of the junction and A = best score entirely inside R (bit 1) -- and
+//   left flank passes  iff  bit of max(S_k, B_k, 2A+1) is 0.
+// 4q+1 must fit the int16 half: chained reads (up to 8000 bases) keep the A_k sweep.
+//
 // The two int16 halves of every VGPR hold two READS of the same region (paired by length
 // on the host); the template base is shared.  Inner loop = k_score_pk16's, with E updated
 // lazily (E_in of the current column stays in the register, which the combine needs).
@@ -47,7 +59,8 @@
 #define NEGB 1024                     // biased "minus infinity" (value -7168): below any real state (>= -1100),
                                       // survives a subtraction of any gap constant, and two of them still fit
 #define FLAG_BOUNDARY 0x00000080      // bit 7 of table byte 0
-#define FLAG_SNAPSHOT 0x00008000      // bit 7 of table byte 1
+#define FLAG_SNAPSHOT 0x00008000      // bit 7 of table byte 1 (reverse sweep)
+#define FLAG_INREP    0x80008000      // bits 7 of table bytes 1 and 3 (forward sweep, origin bit): column >= |L|
 
 __device__ __forceinline__ int half_lo(int v) { return v & 0xffff; }
 __device__ __forceinline__ int half_hi(int v) { return (v >> 16) & 0xffff; }
@@ -156,10 +169,13 @@ __global__ __launch_bounds__(WAVE) void k_sweep_pk16(int n_tasks, const NraSweep
                                                      int16_t* __restrict__ snap_e,
                                                      int16_t* __restrict__ snap_e2,
                                                      int32_t* __restrict__ arr_a,
+                                                     int32_t* __restrict__ read_a,
                                                      int32_t* __restrict__ cand_score,
                                                      uint8_t* __restrict__ cand_flag,
                                                      int32_t* chain_buf, int chain_cap)
 {
+    constexpr bool BIT = !CHAIN;          // origin-bit scheme: doubled scores, short reverse sweep
+    constexpr int SC = BIT ? 2 : 1;
     const int task = blockIdx.x;
     if (task >= n_tasks) return;
     const int lane = threadIdx.x;
@@ -171,19 +187,21 @@ __global__ __launch_bounds__(WAVE) void k_sweep_pk16(int n_tasks, const NraSweep
     const int m = rg.m1;
     const int flank = DIR ? rg.l1 : rg.l3;
     const uint8_t* __restrict__ piece = pool + (DIR ? rg.p1_off : rg.pr_off);
-    const int ncols = flank + m * tk.kmax;
-    const int jfirst = flank + m * tk.kmin - 1;       // boundary column of k = kmin (>= 0: flank >= 1)
+    const int ncols = (BIT && DIR == 0) ? flank : flank + m * tk.kmax;
+    // boundary column of k = kmin (>= 0: flank >= 1); the short reverse sweep has one: R[0]
+    const int jfirst = (BIT && DIR == 0) ? flank - 1 : flank + m * tk.kmin - 1;
     const int kmin_a = kmin_arr[ra], kmax_a = kmax_arr[ra];
     const int kmin_b = kmin_arr[rb], kmax_b = kmax_arr[rb];
     const uint32_t coff_a = coff[ra], coff_b = coff[rb];
 
-    const int o1 = sp.open1, o2 = sp.open2;
+    const int o1 = SC * sp.open1, o2 = SC * sp.open2;
     const int P1 = 0x00010001;
-    const int v_floor = (BIAS - o1) * P1;                   // max(H,0) - o1
-    const int v_o1 = o1 * P1, v_e1 = sp.ext1 * P1, v_o2 = o2 * P1, v_e2 = sp.ext2 * P1;
+    const int v_floor = (BIAS - o1) * P1;                   // max(H,0) - o1 (even: the origin bit is free)
+    const int v_floor1 = BIT ? v_floor | P1 : v_floor;      // the same for a path that starts at a column >= |L|
+    const int v_o1 = o1 * P1, v_e1 = SC * sp.ext1 * P1, v_o2 = o2 * P1, v_e2 = SC * sp.ext2 * P1;
     const int NEG1 = NEGB * P1, NEG2 = 2 * NEGB * P1;       // biased once / twice
     // substitution scores + o1 (the diagonal is read from Hq = H - o1): all in [0, 127]
-    const int s_match = sp.match + o1, s_mis = o1 - sp.mismatch, s_ambi = o1 - sp.ambi;
+    const int s_match = SC * sp.match + o1, s_mis = o1 - SC * sp.mismatch, s_ambi = o1 - SC * sp.ambi;
     const int tbl_hi = s_mis | (s_ambi << 8);               // selector 4: padding row, 5: N in the read
     const int tbl_mis4 = s_mis * 0x01010101, tbl_ambi4 = s_ambi * 0x01010101;
 
@@ -210,7 +228,7 @@ __global__ __launch_bounds__(WAVE) void k_sweep_pk16(int n_tasks, const NraSweep
     // forward sweep: the R side of the junction, row r pairs with reverse-sweep row Q-2-r
     int Hbo[DIR ? R : 1], Ebo[DIR ? R : 1], E2bo[DIR ? R : 1];
     if (DIR) {
-        const int q1 = sp.open1 - sp.ext1, q2 = sp.open2 - sp.ext2;     // the refunded gap opens
+        const int q1 = SC * (sp.open1 - sp.ext1), q2 = SC * (sp.open2 - sp.ext2);     // the refunded gap opens
 #pragma unroll
         for (int i = 0; i < R; ++i) {
             const int r = row_base + lane * R + i;
@@ -264,6 +282,7 @@ __global__ __launch_bounds__(WAVE) void k_sweep_pk16(int n_tasks, const NraSweep
                     feed = code < 4 ? tbl_mis4 + ((s_match - s_mis) << (8 * code)) : tbl_ambi4;
                     if (col >= jfirst && (col - jfirst) % m == 0) feed |= FLAG_BOUNDARY;
                     if (DIR == 0 && col == flank - 1) feed |= FLAG_SNAPSHOT;
+                    if (BIT && DIR == 1 && col >= flank) feed |= FLAG_INREP;
                 }
                 if (CHAIN) {
                     inH = v_floor; inF = NEG1; inF2 = NEG1; inS = NEG2; inB = NEG1;
@@ -291,12 +310,15 @@ __global__ __launch_bounds__(WAVE) void k_sweep_pk16(int n_tasks, const NraSweep
             const int ttB_new = ttA;
             const int accS_Bin = accS_A, accB_Bin = accB_A;
 
+            // the empty alignment a path may start from at this column: score 0, origin bit from the flag
+            const int floorA = (BIT && DIR == 1) ? (int)((((unsigned)ttA_new >> 15) & (unsigned)P1) | (unsigned)v_floor) : v_floor;
+            const int floorB = (BIT && DIR == 1) ? (int)((((unsigned)ttB_new >> 15) & (unsigned)P1) | (unsigned)v_floor) : v_floor;
             sweep_cell<0, RA, R>(Hq, Hq2, E, E2, qc, HupA_prev, FA, F2A, MA, ttA_new & 0x7f7f7f7f, tbl_hi,
-                                 v_floor, v_e1, v_e2, v_o1, v_o2);
+                                 floorA, v_e1, v_e2, v_o1, v_o2);
             HupA_prev = hupA; HbotA = Hq[RA - 1]; FoutA = FA; F2outA = F2A;
             if (RB > 0) {
                 sweep_cell<RA, RB, R>(Hq, Hq2, E, E2, qc, HupB_prev, FB, F2B, MB, ttB_new & 0x7f7f7f7f, tbl_hi,
-                                      v_floor, v_e1, v_e2, v_o1, v_o2);
+                                      floorB, v_e1, v_e2, v_o1, v_o2);
                 HbotB = Hq[R - 1];
             } else {
                 HbotB = hupB;                             // empty cell: hand everything through
@@ -308,8 +330,9 @@ __global__ __launch_bounds__(WAVE) void k_sweep_pk16(int n_tasks, const NraSweep
             int tSA = NEG2, tSB = NEG2;
             if constexpr (DIR != 0) {
                 if (__builtin_amdgcn_ballot_w64(atA || atB) != 0) {
-                    tSA = sweep_combine<0, RA, R>(Hq, E, E2, Hbo, Ebo, E2bo, v_floor, tSA);
-                    tSB = sweep_combine<RA, RB, R>(Hq, E, E2, Hbo, Ebo, E2bo, v_floor, tSB);
+                    // a path that starts in R starts at a column >= |L|
+                    tSA = sweep_combine<0, RA, R>(Hq, E, E2, Hbo, Ebo, E2bo, v_floor1, tSA);
+                    tSB = sweep_combine<RA, RB, R>(Hq, E, E2, Hbo, Ebo, E2bo, v_floor1, tSB);
                 }
             }
             accS_A = pmaxi(accS_Ain, tSA);
@@ -335,19 +358,30 @@ __global__ __launch_bounds__(WAVE) void k_sweep_pk16(int n_tasks, const NraSweep
 #pragma unroll
                 for (int s2 = 0; s2 < 2; ++s2) {
                     const int lo_k = s2 ? kmin_b : kmin_a, hi_k = s2 ? kmax_b : kmax_a;
-                    if ((s2 == 0 || has_b) && k >= lo_k && k <= hi_k) {
+                    const int B = (s2 ? half_hi(accB_B) : half_lo(accB_B)) - BIAS;
+                    if (BIT && DIR == 0) {
+                        // the one boundary of the short reverse sweep: A = best alignment inside R (doubled)
+                        if (s2 == 0 || has_b) read_a[s2 ? rb : ra] = B;
+                    } else if ((s2 == 0 || has_b) && k >= lo_k && k <= hi_k) {
                         const uint32_t idx = (s2 ? coff_b : coff_a) + (uint32_t)(k - lo_k);
-                        const int B = (s2 ? half_hi(accB_B) : half_lo(accB_B)) - BIAS;
                         if (DIR == 0) {
                             arr_a[idx] = B;                       // running max of the reverse sweep = A_k
                         } else {
                             const int S = (s2 ? half_hi(accS_B) : half_lo(accS_B)) - 2 * BIAS;
-                            const int A = arr_a[idx];
-                            const int best = imax(imax(S, B), A);
                             const int lo = sp.min_score > 1 ? sp.min_score : 1;
-                            int flag = 1;
-                            if (A >= best) flag = 0;                          // an optimal alignment starts in unit^k+R
-                            else if (B >= best) flag = (S >= best) ? 2 : 0;   // one ends inside L+unit^k
+                            int best, flag = 1;
+                            if (BIT) {
+                                // packed 2*score + origin bit; an alignment inside R starts at a column >= |L|
+                                const int V = imax(imax(S, B), read_a[s2 ? rb : ra] + 1);
+                                best = V >> 1;
+                                if (V & 1) flag = 0;                                  // an optimal alignment starts at >= |L|
+                                else if ((B >> 1) >= best) flag = ((S >> 1) >= best) ? 2 : 0;
+                            } else {
+                                const int A = arr_a[idx];
+                                best = imax(imax(S, B), A);
+                                if (A >= best) flag = 0;                          // an optimal alignment starts in unit^k+R
+                                else if (B >= best) flag = (S >= best) ? 2 : 0;   // one ends inside L+unit^k
+                            }
                             cand_score[idx] = best >= lo ? best : -1;
                             cand_flag[idx] = (uint8_t)flag;
                         }
@@ -367,11 +401,11 @@ static int launch_sweep(int R, int has_n, int chain, hipStream_t st, int n_tasks
                         const NraDevRead* reads, const NraDevRegion* regions, const uint8_t* pool,
                         const uint32_t* q2bit, const uint32_t* qnmask, NraScoreParams sp,
                         const int32_t* kmin, const int32_t* kmax, const uint32_t* coff,
-                        int16_t* snap_h, int16_t* snap_e, int16_t* snap_e2, int32_t* arr_a,
+                        int16_t* snap_h, int16_t* snap_e, int16_t* snap_e2, int32_t* arr_a, int32_t* read_a,
                         int32_t* cand_score, uint8_t* cand_flag, int32_t* chain_buf, int chain_cap)
 {
     if (n_tasks <= 0) return 0;
-#define ARGS n_tasks, tasks, reads, regions, pool, q2bit, qnmask, sp, kmin, kmax, coff, snap_h, snap_e, snap_e2, arr_a, cand_score, cand_flag, chain_buf, chain_cap
+#define ARGS n_tasks, tasks, reads, regions, pool, q2bit, qnmask, sp, kmin, kmax, coff, snap_h, snap_e, snap_e2, arr_a, read_a, cand_score, cand_flag, chain_buf, chain_cap
     if (chain) {      // row-block chaining: only the instantiations long reads (and the tests) use
         if (R == NRA_CHAIN_R) {
             if (has_n) k_sweep_pk16<NRA_CHAIN_R, true, DIR, true><<<n_tasks, WAVE, 0, st>>>(ARGS);
@@ -402,10 +436,10 @@ extern "C" int nra_launch_sweep_bwd(int R, int has_n, int chain, hipStream_t st,
                                     const uint32_t* q2bit, const uint32_t* qnmask, NraScoreParams sp,
                                     const int32_t* kmin, const int32_t* kmax, const uint32_t* coff,
                                     int16_t* snap_h, int16_t* snap_e, int16_t* snap_e2, int32_t* arr_a,
-                                    int32_t* chain_buf, int chain_cap)
+                                    int32_t* read_a, int32_t* chain_buf, int chain_cap)
 {
     return launch_sweep<0>(R, has_n, chain, st, n_tasks, tasks, reads, regions, pool, q2bit, qnmask, sp, kmin, kmax,
-                           coff, snap_h, snap_e, snap_e2, arr_a, nullptr, nullptr, chain_buf, chain_cap);
+                           coff, snap_h, snap_e, snap_e2, arr_a, read_a, nullptr, nullptr, chain_buf, chain_cap);
 }
 #endif
 #if NRA_HAS_PART(6)
@@ -414,9 +448,10 @@ extern "C" int nra_launch_sweep_fwd(int R, int has_n, int chain, hipStream_t st,
                                     const uint32_t* q2bit, const uint32_t* qnmask, NraScoreParams sp,
                                     const int32_t* kmin, const int32_t* kmax, const uint32_t* coff,
                                     int16_t* snap_h, int16_t* snap_e, int16_t* snap_e2, int32_t* arr_a,
-                                    int32_t* cand_score, uint8_t* cand_flag, int32_t* chain_buf, int chain_cap)
+                                    int32_t* read_a, int32_t* cand_score, uint8_t* cand_flag, int32_t* chain_buf,
+                                    int chain_cap)
 {
     return launch_sweep<1>(R, has_n, chain, st, n_tasks, tasks, reads, regions, pool, q2bit, qnmask, sp, kmin, kmax,
-                           coff, snap_h, snap_e, snap_e2, arr_a, cand_score, cand_flag, chain_buf, chain_cap);
+                           coff, snap_h, snap_e, snap_e2, arr_a, read_a, cand_score, cand_flag, chain_buf, chain_cap);
 }
 #endif
