@@ -140,6 +140,13 @@ bool scoring_ok(const nra_scoring_t* sc)
     return true;
 }
 
+// Largest alignment score a read of qlen bases can reach, against what a cell format holds:
+// int32 cells keep the score in their upper 16 bits; the packed int16 kernels keep value + 8192
+// (brute force), two biased values added (chained sweep: 2 x 8192 + score), or the same with
+// doubled scores (origin-bit sweep).
+const int64_t kScoreCapI32 = 32000, kScoreCapPk16 = 24000, kScoreCapChain = 16000, kScoreCapBit = 8000;
+inline int64_t max_score(const nra_scoring_t* sc, int64_t qlen) { return (int64_t)sc->match * qlen; }
+
 // executed cells of one wave sweep: 64*R rows x (ceil((tlen+63)/64)*64) columns
 int64_t sweep_cells(int R, int tlen) { return (int64_t)64 * R * (((int64_t)tlen + 126) / 64 * 64); }
 
@@ -393,6 +400,14 @@ int nra_batch1d_create(int device, const nra_region_t* regions, int32_t n_region
         // (doubled: the low bit of every state is the origin bit)
         const int o1 = sc->gap_open1 + sc->gap_ext1;
         if (o1 < sc->mismatch || o1 < sc->sc_ambi || 2 * (sc->match + o1) > 127) brute = true;
+    }
+    for (int32_t r = 0; r < n_reads; ++r) {       // unusual scoring: do the scores fit the 16-bit cells?
+        if (kmin[r] > kmax[r]) continue;
+        const int64_t ms = max_score(sc, pr.reads[r].qlen);
+        const bool chained = pr.reads[r].qlen > NRA_MAX_QLEN_1BLOCK;
+        if (ms > (chained ? kScoreCapChain : kScoreCapPk16))
+            return fail(NRA_E_RANGE, "read " + std::to_string(r) + ": match score x read length does not fit the 16-bit cells");
+        if (!chained && ms > kScoreCapBit) brute = true;
     }
     b->brute = brute;
     std::vector<NraSweepTask> sweep_tasks;
@@ -721,6 +736,9 @@ int nra_batch2d_create(int device, const nra_joint_region_t* reg, int32_t n_read
     PackedReads pr;
     rc = pack_reads(n_reads, seqs, seq_off, nullptr, 1, pr);
     if (rc) return rc;
+    for (int32_t r = 0; r < n_reads; ++r)
+        if (max_score(sc, pr.reads[r].qlen) > kScoreCapPk16)
+            return fail(NRA_E_RANGE, "read " + std::to_string(r) + ": match score x read length does not fit the 16-bit cells");
 
     std::vector<uint32_t> first((size_t)n_reads, 0), cnt((size_t)n_reads, 0);
     int32_t k1max = 0, k2max = 0;
@@ -1097,6 +1115,8 @@ int prepare_pairs(int device, int32_t n_seqs, const char* seqs, const int64_t* s
         }
         if (ps.as_query[s] == 0) {
             if (len > NRA_MAX_QLEN_1BLOCK) return fail(NRA_E_RANGE, "query longer than " + std::to_string(NRA_MAX_QLEN_1BLOCK));
+            if (max_score(sc, len) > kScoreCapI32)
+                return fail(NRA_E_RANGE, "query " + std::to_string(s) + ": match score x length does not fit 16 bits");
             NraDevRead r{};
             r.qoff = (uint32_t)base; r.qlen = (int32_t)len; r.region = 0; r.rc = 0;
             ps.as_query[s] = (int32_t)ps.dreads.size();

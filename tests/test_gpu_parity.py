@@ -129,6 +129,19 @@ def test_1d_scoring_variants(capi, oracle):
         same_1d(capi, oracle, d["regions"], d["reads"], d["kmin"], d["kmax"], sc_over=over)
 
 
+def test_1d_large_match_scores(capi, oracle):
+    """Scores that outgrow the 16-bit cell formats: the doubled (origin-bit) sweep hands over to the
+    brute-force kernel above match x length = 8000; beyond 24000 the call is refused."""
+    d = synth.make_1d(6, "TATTG", (20, 60), "ont_q20", kwin=(10, 70), anchor=600, flank=500, seed=77)   # reads of 1.1-1.3 kb
+    assert max(len(r) for r in d["reads"]) > 1000
+    for over in (dict(match=7, mismatch=9, gap_open1=9, gap_ext1=4, gap_open2=40, gap_ext2=2),          # 7 x 1300 > 8000
+                 dict(match=6, mismatch=12, gap_open1=12, gap_ext1=6, gap_open2=72, gap_ext2=3, min_dp_score=240)):
+        same_1d(capi, oracle, d["regions"], d["reads"], d["kmin"], d["kmax"], sc_over=over)
+    with pytest.raises(capi.NraError) as e:
+        capi.round3_1d(d["regions"], d["reads"], d["kmin"], d["kmax"], sc=capi.default_scoring(match=30, mismatch=40, gap_open1=40, gap_ext1=20, gap_open2=240, gap_ext2=10))
+    assert e.value.code == -3
+
+
 def test_1d_errors(capi):
     L, R = "ACGT" * 20, "TTGCA" * 16
     with pytest.raises(capi.NraError) as e:
