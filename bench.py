@@ -175,7 +175,7 @@ def main():
         achieved = alg_cells_per_s * LANEOPS_PER_CELL / 1e12
         executed = exe_cells_per_s * LANEOPS_PER_CELL / 1e12
         traffic = None
-        prof = os.path.join(ROOT, "profiles", "r01e_pmc_traffic.json")
+        prof = os.path.join(ROOT, "profiles", "r01f_pmc_traffic.json")
         if os.path.exists(prof):
             try:
                 traffic = json.load(open(prof)).get("hbm_bytes_per_step_sweep_kernels")
