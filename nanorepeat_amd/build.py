@@ -60,7 +60,7 @@ def build_library(force=False, jobs=None, verbose=False):
     cmds.append(common + ["-DNRA_PART=9", "-c", os.path.join(CSRC, "nra_trace.hip"), "-o", o])
     o = os.path.join(OBJ, "nra_host.o")
     objs.append(o)
-    cmds.append(common + ["-c", os.path.join(CSRC, "nra_host.cpp"), "-o", o])
+    cmds.append(common + ["-pthread", "-c", os.path.join(CSRC, "nra_host.cpp"), "-o", o])
 
     def run(cmd):
         if verbose:
@@ -72,7 +72,7 @@ def build_library(force=False, jobs=None, verbose=False):
     jobs = jobs or min(len(cmds), max(1, (os.cpu_count() or 2) - 1))
     with ThreadPoolExecutor(max_workers=jobs) as ex:
         list(ex.map(run, cmds))
-    run([hipcc, f"--offload-arch={ARCH}", "-shared", "-fPIC", "-o", LIB] + objs)
+    run([hipcc, f"--offload-arch={ARCH}", "-shared", "-fPIC", "-pthread", "-o", LIB] + objs)
     return LIB
 
 

@@ -9,11 +9,14 @@
 #include "nra_internal.h"
 
 #include <algorithm>
+#include <chrono>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <memory>
+#include <mutex>
 #include <string>
+#include <thread>
 #include <vector>
 
 #define NRA_VERSION_STR "nanorepeat_amd 0.1.0 (gfx950)"
@@ -50,6 +53,18 @@ static const bool g_debug = getenv("NRA_DEBUG") != nullptr;
         }                                                                                        \
     } while (0)
 
+// NRA_DEBUG: wall time of the host phases of a create call
+struct PhaseClock {
+    std::chrono::steady_clock::time_point t = std::chrono::steady_clock::now();
+    void mark(const char* what)
+    {
+        if (!g_debug) return;
+        const auto now = std::chrono::steady_clock::now();
+        fprintf(stderr, "[nra]   %-28s %8.3f ms\n", what, std::chrono::duration<double, std::milli>(now - t).count());
+        t = now;
+    }
+};
+
 const int kRList[] = {
 #define X(r) r,
     NRA_R_LIST(X)
@@ -64,6 +79,19 @@ int rows_for_qlen(int qlen)   // index into kRList, -1 if too long
     return -1;
 }
 
+// ASCII -> code table for the bulk encoder (same mapping as encode_base)
+struct BaseCodeTable {
+    uint8_t v[256];
+    BaseCodeTable()
+    {
+        for (int i = 0; i < 256; ++i) v[i] = NRA_CODE_N;
+        v['A'] = v['a'] = 0; v['C'] = v['c'] = 1; v['G'] = v['g'] = 2;
+        v['T'] = v['t'] = v['U'] = v['u'] = 3;
+    }
+    uint8_t operator[](uint8_t c) const { return v[c]; }
+};
+static const BaseCodeTable kBaseCode;
+
 inline uint8_t encode_base(char c)
 {
     switch (c) {
@@ -75,15 +103,49 @@ inline uint8_t encode_base(char c)
     }
 }
 
+// Device memory of one call or batch: hipMalloc costs ~0.3 ms per call, a batch has ~25 buffers, so
+// they are carved out of a few large chunks.  While an Arena is "current" on this thread, DevBuf
+// allocations come from it (and are released with it); otherwise a DevBuf owns its allocation.
+struct Arena {
+    struct Chunk { char* p; size_t size, used; };
+    std::vector<Chunk> chunks;
+    size_t next_chunk = 1 << 20;
+    ~Arena() { for (Chunk& c : chunks) (void)hipFree(c.p); }
+    void expect(size_t bytes) { next_chunk = std::max(next_chunk, bytes); }
+    hipError_t alloc(size_t bytes, void** out)
+    {
+        bytes = (bytes + 255) & ~(size_t)255;
+        if (chunks.empty() || chunks.back().size - chunks.back().used < bytes) {
+            Chunk c{nullptr, std::max(bytes, next_chunk), 0};
+            hipError_t e = hipMalloc((void**)&c.p, c.size);
+            if (e != hipSuccess) return e;
+            chunks.push_back(c);
+        }
+        Chunk& c = chunks.back();
+        *out = c.p + c.used;
+        c.used += bytes;
+        return hipSuccess;
+    }
+};
+thread_local Arena* g_arena = nullptr;
+struct ArenaScope {
+    Arena* prev;
+    explicit ArenaScope(Arena* a) : prev(g_arena) { g_arena = a; }
+    ~ArenaScope() { g_arena = prev; }
+};
+
 template <class T>
 struct DevBuf {
     T* p = nullptr;
     size_t n = 0;
-    ~DevBuf() { if (p) (void)hipFree(p); }
+    bool owned = false;
+    ~DevBuf() { if (p && owned) (void)hipFree(p); }
     hipError_t alloc(size_t count)
     {
         n = count;
         if (count == 0) count = 1;
+        if (g_arena) { owned = false; return g_arena->alloc(count * sizeof(T), (void**)&p); }
+        owned = true;
         return hipMalloc((void**)&p, count * sizeof(T));
     }
     hipError_t upload(const std::vector<T>& v)
@@ -93,6 +155,48 @@ struct DevBuf {
         return hipMemcpy(p, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice);
     }
 };
+
+// Streams and events are expensive to create (~2 ms a stream) and a batch needs a handful: they
+// are handed back to a per-device pool when a batch is destroyed and reused by the next one.
+struct HandlePool {
+    std::mutex mu;
+    std::vector<std::vector<hipStream_t>> streams;      // [device]
+    std::vector<std::vector<hipEvent_t>> timed, untimed;
+    template <class V> static V& at(std::vector<V>& v, int device)
+    {
+        if ((int)v.size() <= device) v.resize((size_t)device + 1);
+        return v[(size_t)device];
+    }
+    hipError_t stream(int device, hipStream_t* out)
+    {
+        {
+            std::lock_guard<std::mutex> lk(mu);
+            auto& v = at(streams, device);
+            if (!v.empty()) { *out = v.back(); v.pop_back(); return hipSuccess; }
+        }
+        return hipStreamCreateWithFlags(out, hipStreamNonBlocking);
+    }
+    hipError_t event(int device, bool timing, hipEvent_t* out)
+    {
+        {
+            std::lock_guard<std::mutex> lk(mu);
+            auto& v = at(timing ? timed : untimed, device);
+            if (!v.empty()) { *out = v.back(); v.pop_back(); return hipSuccess; }
+        }
+        return timing ? hipEventCreate(out) : hipEventCreateWithFlags(out, hipEventDisableTiming);
+    }
+    void put_stream(int device, hipStream_t q)
+    {
+        std::lock_guard<std::mutex> lk(mu);
+        at(streams, device).push_back(q);
+    }
+    void put_event(int device, bool timing, hipEvent_t e)
+    {
+        std::lock_guard<std::mutex> lk(mu);
+        at(timing ? timed : untimed, device).push_back(e);
+    }
+};
+HandlePool g_handles;
 
 // 2D decomposition: reads of one bucket whose wave states fit the state buffer together; the
 // prefix sweeps of a group run, then its tail sweeps, then the next group reuses the buffer.
@@ -153,6 +257,7 @@ int64_t sweep_cells(int R, int tlen) { return (int64_t)64 * R * (((int64_t)tlen 
 }  // namespace
 
 struct nra_batch {
+    Arena arena;               // declared first: released after every DevBuf below
     int kind = 0;              // 1 = 1D, 2 = 2D
     int device = 0;
     int flags = 0;
@@ -208,13 +313,16 @@ struct nra_batch {
 
     ~nra_batch()
     {
-        for (hipEvent_t e : ev) (void)hipEventDestroy(e);
-        for (hipEvent_t e : bdone) (void)hipEventDestroy(e);
-        if (fork_ev) (void)hipEventDestroy(fork_ev);
-        if (fork2_ev) (void)hipEventDestroy(fork2_ev);
-        for (hipEvent_t e : phase_ev) if (e) (void)hipEventDestroy(e);
-        for (hipStream_t q : bstreams) (void)hipStreamDestroy(q);
-        if (stream) (void)hipStreamDestroy(stream);
+        // all work of the batch has to be over before its handles serve another batch
+        if (stream) (void)hipStreamSynchronize(stream);
+        for (hipStream_t q : bstreams) if (q) (void)hipStreamSynchronize(q);
+        for (hipEvent_t e : ev) if (e) g_handles.put_event(device, true, e);
+        for (hipEvent_t e : phase_ev) if (e) g_handles.put_event(device, true, e);
+        for (hipEvent_t e : bdone) if (e) g_handles.put_event(device, false, e);
+        if (fork_ev) g_handles.put_event(device, false, fork_ev);
+        if (fork2_ev) g_handles.put_event(device, false, fork2_ev);
+        for (hipStream_t q : bstreams) if (q) g_handles.put_stream(device, q);
+        if (stream) g_handles.put_stream(device, stream);
     }
 };
 
@@ -249,16 +357,42 @@ int pack_reads(int32_t n_reads, const char* seqs, const int64_t* seq_off, const 
     }
     out.q2bit.assign((size_t)(base / 16) + 1, 0);
     out.nmask.assign((size_t)(base / 32) + 1, 0);
-    for (int32_t r = 0; r < n_reads; ++r) {
-        const char* s = seqs + seq_off[r];
-        const uint32_t q0 = out.reads[r].qoff;
-        for (int32_t i = 0; i < out.reads[r].qlen; ++i) {
-            uint8_t c = encode_base(s[i]);
-            uint32_t b = q0 + (uint32_t)i;
-            if (c >= 4) { out.nmask[b >> 5] |= 1u << (b & 31); out.has_n = true; c = 0; }
-            out.q2bit[b >> 4] |= (uint32_t)c << ((b & 15) * 2);
+    // every read starts on a 32-base boundary, so reads write disjoint words: encode in parallel
+    const unsigned hw = std::max(1u, std::thread::hardware_concurrency());
+    const int nthreads = base < (1u << 20) ? 1 : (int)std::min<unsigned>(hw, 16);
+    std::vector<uint8_t> saw_n((size_t)nthreads, 0);
+    auto work = [&](int t) {
+        bool has_n = false;
+        for (int32_t r = t; r < n_reads; r += nthreads) {
+            const uint8_t* s = reinterpret_cast<const uint8_t*>(seqs + seq_off[r]);
+            const int32_t len = out.reads[r].qlen;
+            uint32_t* q2 = out.q2bit.data() + (out.reads[r].qoff >> 4);
+            uint32_t* nm = out.nmask.data() + (out.reads[r].qoff >> 5);
+            for (int32_t i = 0; i < len; i += 32) {
+                const int32_t n = std::min(32, len - i);
+                uint32_t w0 = 0, w1 = 0, mask = 0;
+                for (int32_t j = 0; j < n; ++j) {
+                    const uint32_t c = kBaseCode[s[i + j]];
+                    if (c >= 4) mask |= 1u << j;
+                    else if (j < 16) w0 |= c << (2 * j);
+                    else w1 |= c << (2 * (j - 16));
+                }
+                q2[(i >> 4)] = w0;
+                if (n > 16) q2[(i >> 4) + 1] = w1;
+                nm[i >> 5] = mask;
+                has_n |= mask != 0;
+            }
         }
+        saw_n[(size_t)t] = has_n ? 1 : 0;
+    };
+    if (nthreads == 1) {
+        work(0);
+    } else {
+        std::vector<std::thread> pool;
+        for (int t = 0; t < nthreads; ++t) pool.emplace_back(work, t);
+        for (std::thread& th : pool) th.join();
     }
+    for (uint8_t v : saw_n) out.has_n |= v != 0;
     return NRA_OK;
 }
 
@@ -282,15 +416,15 @@ int common_init(nra_batch* b, int device, const nra_scoring_t* sc, int flags)
     b->device = device;
     b->flags = flags;
     b->sp = to_params(*sc);
-    HIP_TRY(hipStreamCreateWithFlags(&b->stream, hipStreamNonBlocking));
+    HIP_TRY(g_handles.stream(device, &b->stream));
     return NRA_OK;
 }
 
 int make_events(nra_batch* b, int n)
 {
-    b->ev.resize((size_t)n);
-    for (int i = 0; i < n; ++i) HIP_TRY(hipEventCreate(&b->ev[i]));
-    for (int i = 0; i < 2; ++i) HIP_TRY(hipEventCreate(&b->phase_ev[i]));
+    b->ev.assign((size_t)n, nullptr);
+    for (int i = 0; i < n; ++i) HIP_TRY(g_handles.event(b->device, true, &b->ev[i]));
+    for (int i = 0; i < 2; ++i) HIP_TRY(g_handles.event(b->device, true, &b->phase_ev[i]));
     return NRA_OK;
 }
 
@@ -341,13 +475,17 @@ int nra_batch1d_create(int device, const nra_region_t* regions, int32_t n_region
 
     nra_batch* b = new nra_batch();
     std::unique_ptr<nra_batch> guard(b);
+    ArenaScope arena_scope(&b->arena);
     b->kind = 1; b->n_reads = n_reads; b->n_regions = n_regions;
     int rc = common_init(b, device, sc, flags);
     if (rc) return rc;
 
+    PhaseClock clk;
+    clk.mark("device, stream");
     PackedReads pr;
     rc = pack_reads(n_reads, seqs, seq_off, read_region, n_regions, pr, NRA_MAX_QLEN);
     if (rc) return rc;
+    clk.mark("2-bit packing");
 
     // per-region largest k, candidate offsets
     std::vector<int32_t> region_kmax((size_t)n_regions, 0);
@@ -456,12 +594,15 @@ int nra_batch1d_create(int device, const nra_region_t* regions, int32_t n_region
         for (int32_t r : by_bucket[bi]) {
             read_bucket[r] = (int32_t)b->buckets.size();
             const NraDevRegion& d = dregs[pr.reads[r].region];
-            for (int32_t k = kmin[r]; k <= kmax[r]; ++k) {
-                const int tl = d.l1 + d.m1 * k + d.l3;
-                alg_cells += (int64_t)pr.reads[r].qlen * tl;
-                if (all_ext) {
+            {   // algorithmic cells: q x sum over k of (|L| + m k + |R|)
+                const int64_t K = (int64_t)kmax[r] - kmin[r] + 1;
+                const int64_t sum_k = ((int64_t)kmin[r] + kmax[r]) * K / 2;
+                alg_cells += (int64_t)pr.reads[r].qlen * (K * ((int64_t)d.l1 + d.l3) + (int64_t)d.m1 * sum_k);
+            }
+            if (all_ext) {
+                for (int32_t k = kmin[r]; k <= kmax[r]; ++k) {
                     queue_tasks.push_back(NraTask{r, k, 0, (int32_t)(coff[r] + (uint32_t)(k - kmin[r]))});
-                    bk.cells_queue += sweep_cells(bk.R, tl);
+                    bk.cells_queue += sweep_cells(bk.R, d.l1 + d.m1 * k + d.l3);
                 }
             }
             if (!all_ext && brute) {
@@ -517,7 +658,11 @@ int nra_batch1d_create(int device, const nra_region_t* regions, int32_t n_region
         b->buckets.push_back(bk);
     }
     const size_t nb = b->buckets.size();
+    clk.mark("templates, buckets, tasks");
 
+    // one chunk for everything: ~7 B per read base, ~40 B per candidate, the tasks, the chain strips
+    b->arena.expect(pr.q2bit.size() * 16 * 8 + (size_t)total * 40 + pool.size() + sweep_tasks.size() * 16 +
+                    pair_tasks.size() * sizeof(NraPairTask) + (size_t)n_reads * 64 + (4u << 20));
     HIP_TRY(b->pool.upload(pool));
     HIP_TRY(b->q2bit.upload(pr.q2bit));
     HIP_TRY(b->qnmask.upload(pr.nmask));
@@ -557,17 +702,19 @@ int nra_batch1d_create(int device, const nra_region_t* regions, int32_t n_region
     HIP_TRY(b->n_ties.alloc((size_t)n_reads));
     HIP_TRY(b->sum_k.alloc((size_t)n_reads));
     HIP_TRY(b->status.alloc((size_t)n_reads));
+    clk.mark("device buffers, H2D");
     rc = make_events(b, 2 + 6 * (int)nb + 2);
     if (rc) return rc;
     if (!brute) {
-        b->bstreams.resize(nb); b->bdone.resize(nb);
+        b->bstreams.assign(nb, nullptr); b->bdone.assign(nb, nullptr);
         for (size_t i = 0; i < nb; ++i) {
-            HIP_TRY(hipStreamCreateWithFlags(&b->bstreams[i], hipStreamNonBlocking));
-            HIP_TRY(hipEventCreateWithFlags(&b->bdone[i], hipEventDisableTiming));
+            HIP_TRY(g_handles.stream(b->device, &b->bstreams[i]));
+            HIP_TRY(g_handles.event(b->device, false, &b->bdone[i]));
         }
-        HIP_TRY(hipEventCreateWithFlags(&b->fork_ev, hipEventDisableTiming));
+        HIP_TRY(g_handles.event(b->device, false, &b->fork_ev));
     }
 
+    clk.mark("events, streams");
     b->stats.n_alignments = total;
     b->stats.algorithmic_cells = alg_cells;
     int64_t ex = 0;
@@ -729,6 +876,7 @@ int nra_batch2d_create(int device, const nra_joint_region_t* reg, int32_t n_read
 
     nra_batch* b = new nra_batch();
     std::unique_ptr<nra_batch> guard(b);
+    ArenaScope arena_scope(&b->arena);
     b->kind = 2; b->n_reads = n_reads; b->n_regions = 1; b->n_cands = n_cells;
     int rc = common_init(b, device, sc, flags);
     if (rc) return rc;
@@ -876,6 +1024,10 @@ int nra_batch2d_create(int device, const nra_joint_region_t* reg, int32_t n_read
     }
     const size_t nb = b->buckets.size();
 
+    // one chunk for everything but the wave states, which get their own
+    b->arena.expect(pr.q2bit.size() * 16 * 13 + (size_t)n_cells * 20 + pool.size() + (size_t)n_reads * 128 +
+                    (jbwd.size() + jpre.size() + jtail.size()) * sizeof(NraJointTask) + k1list.size() * 4 +
+                    queue_tasks.size() * sizeof(NraTask) + (4u << 20));
     HIP_TRY(b->pool.upload(pool));
     HIP_TRY(b->q2bit.upload(pr.q2bit));
     HIP_TRY(b->qnmask.upload(pr.nmask));
@@ -917,11 +1069,11 @@ int nra_batch2d_create(int device, const nra_joint_region_t* reg, int32_t n_read
     rc = make_events(b, 2 + 6 * (int)nb + 4 * (int)b->jgroups.size() + 2);
     if (rc) return rc;
     // two streams per bucket: the buckets' chains overlap, and so do a bucket's reverse and prefix sweeps
-    b->bstreams.resize(2 * nb); b->bdone.resize(3 * nb);
-    for (size_t i = 0; i < 2 * nb; ++i) HIP_TRY(hipStreamCreateWithFlags(&b->bstreams[i], hipStreamNonBlocking));
-    for (size_t i = 0; i < 3 * nb; ++i) HIP_TRY(hipEventCreateWithFlags(&b->bdone[i], hipEventDisableTiming));
-    HIP_TRY(hipEventCreateWithFlags(&b->fork_ev, hipEventDisableTiming));
-    HIP_TRY(hipEventCreateWithFlags(&b->fork2_ev, hipEventDisableTiming));
+    b->bstreams.assign(2 * nb, nullptr); b->bdone.assign(3 * nb, nullptr);
+    for (size_t i = 0; i < 2 * nb; ++i) HIP_TRY(g_handles.stream(b->device, &b->bstreams[i]));
+    for (size_t i = 0; i < 3 * nb; ++i) HIP_TRY(g_handles.event(b->device, false, &b->bdone[i]));
+    HIP_TRY(g_handles.event(b->device, false, &b->fork_ev));
+    HIP_TRY(g_handles.event(b->device, false, &b->fork2_ev));
 
     b->stats.n_alignments = n_cells;
     b->stats.algorithmic_cells = alg_cells;
@@ -1169,6 +1321,9 @@ int nra_align_pairs(int device, int32_t n_seqs, const char* seqs, const int64_t*
         counts.push_back((int32_t)by_bucket[bi].size());
         tasks.insert(tasks.end(), by_bucket[bi].begin(), by_bucket[bi].end());
     }
+    Arena arena;                       // before the buffers: released after them
+    ArenaScope arena_scope(&arena);
+    arena.expect(ps.pool.size() + ps.q2bit.size() * 6 + (size_t)n_pairs * 32 + (2u << 20));
     DevBuf<uint8_t> d_pool; DevBuf<uint32_t> d_q2, d_nm; DevBuf<NraDevRegion> d_regs; DevBuf<NraDevRead> d_reads;
     DevBuf<NraTask> d_tasks; DevBuf<int32_t> d_counts, d_score, d_ts, d_te;
     HIP_TRY(d_pool.upload(ps.pool)); HIP_TRY(d_q2.upload(ps.q2bit)); HIP_TRY(d_nm.upload(ps.nmask));
@@ -1234,6 +1389,9 @@ int nra_align_pairs_cigar(int device, int32_t n_seqs, const char* seqs, const in
     }
     if (trace_bytes > (8ull << 30)) return fail(NRA_E_RANGE, "trace needs more than 8 GiB: split the call");
     const size_t nt = tasks.size();
+    Arena arena;                       // before the buffers: released after them
+    ArenaScope arena_scope(&arena);
+    arena.expect(ps.pool.size() + ps.q2bit.size() * 6 + nt * 128 + (size_t)ops_bytes + (2u << 20));
     DevBuf<uint8_t> d_pool, d_trace, d_ops; DevBuf<uint32_t> d_q2, d_nm; DevBuf<NraDevRegion> d_regs;
     DevBuf<NraDevRead> d_reads; DevBuf<NraTraceTask> d_tasks; DevBuf<int32_t> d_fill, d_back;
     HIP_TRY(d_pool.upload(ps.pool)); HIP_TRY(d_q2.upload(ps.q2bit)); HIP_TRY(d_nm.upload(ps.nmask));
