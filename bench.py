@@ -134,24 +134,36 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    # One step = one pass of the hot path over the rank's batch + the exchange of its per-read
+    # results.  The exchange of step i runs while the kernels of step i+1 do (it is host/RCCL work
+    # on other streams); the last one is exposed before the closing barrier.
+    pending = []
+
+    def exchange():
+        if dist is None or not pending:
+            return None
+        out = pending.pop()
+        mine = torch.from_numpy(np.stack([out["sum_k"], out["n_ties"].astype(np.int64),
+                                          out["status"].astype(np.int64)], 1)).to(gather_dev)
+        gathered = [torch.empty_like(mine) for _ in range(world)]
+        dist.all_gather(gathered, mine)
+        return gathered
+
     def step():
         batch.run()
+        exchange()                      # the previous step's results
         batch.sync()
         if dist is not None:
-            out = batch.fetch(per_candidate=False)
-            mine = torch.from_numpy(np.stack([out["sum_k"], out["n_ties"].astype(np.int64),
-                                              out["status"].astype(np.int64)], 1)).to(gather_dev)
-            gathered = [torch.empty_like(mine) for _ in range(world)]
-            dist.all_gather(gathered, mine)
-            return gathered
-        return None
+            pending.append(batch.fetch(per_candidate=False))
 
     for _ in range(args.warmup):
         step()
+    exchange()
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
+    exchange()
     barrier()
     dt = time.perf_counter() - t0
     if dist is not None:
