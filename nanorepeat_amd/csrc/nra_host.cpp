@@ -925,6 +925,21 @@ int nra_batch2d_create(int device, const nra_joint_region_t* reg, int32_t n_read
         if (cnt[r] == 0 || pr.reads[r].qlen == 0) continue;
         by_bucket[rows_for_qlen(pr.reads[r].qlen)].push_back(r);
     }
+    // a bucket with few reads would run as its own under-filled launches: fold it into the next
+    // larger rows-per-lane instantiation (the extra rows are padding), like the 1D path
+    {   // measured on config 3 (5000 reads, R = 13..28): (2048, 4) beats (1024, 2) and wider spans
+        const size_t fold_min = 2048;
+        const int fold_span = 4;
+        for (int bi = 0; bi + 1 < kNumR; ++bi) {
+            if (by_bucket[bi].empty() || by_bucket[bi].size() >= fold_min) continue;
+            int up = -1;
+            for (int bj = bi + 1; bj < kNumR && kRList[bj] <= kRList[bi] + fold_span; ++bj)
+                if (!by_bucket[bj].empty()) { up = bj; break; }
+            if (up < 0) continue;
+            by_bucket[up].insert(by_bucket[up].end(), by_bucket[bi].begin(), by_bucket[bi].end());
+            by_bucket[bi].clear();
+        }
+    }
     std::vector<NraPairTask> pair_tasks;
     std::vector<NraTask> queue_tasks;
     std::vector<int32_t> queue_count;
