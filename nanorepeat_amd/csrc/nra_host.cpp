@@ -569,10 +569,12 @@ int nra_batch1d_create(int device, const nra_region_t* regions, int32_t n_region
     b->chain_cap = (chain_cols + 127) / 64 * 64 + 64;
     // a bucket with a handful of reads would run as its own under-filled launch: fold it into the
     // next larger rows-per-lane instantiation (the extra rows are padding)
+    const size_t fold_min = 1024;     // wider folding (up to 16384 reads / 4 rows) changes nothing in 1D
+    const int fold_span = 2;
     for (int bi = 0; bi + 1 < kNumR; ++bi) {
-        if (by_bucket[bi].empty() || by_bucket[bi].size() >= 1024) continue;
+        if (by_bucket[bi].empty() || by_bucket[bi].size() >= fold_min) continue;
         int up = -1;
-        for (int bj = bi + 1; bj < kNumR && kRList[bj] <= kRList[bi] + 2; ++bj)
+        for (int bj = bi + 1; bj < kNumR && kRList[bj] <= kRList[bi] + fold_span; ++bj)
             if (!by_bucket[bj].empty()) { up = bj; break; }
         if (up < 0) continue;
         by_bucket[up].insert(by_bucket[up].end(), by_bucket[bi].begin(), by_bucket[bi].end());
