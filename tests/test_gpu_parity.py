@@ -527,3 +527,39 @@ def test_differential_fuzz_small():
     for _ in range(60):
         assert fz.fuzz_1d(rng) is None
         assert fz.fuzz_2d(rng) is None
+
+
+def test_concurrent_calls_from_two_threads(capi, oracle):
+    """The C ABI is thread-safe per call: thread-local error text and allocation arena, pooled
+    streams/events behind a mutex.  Two threads issue 1D, 2D and pair calls at the same time."""
+    import threading
+    d1 = synth.make_1d(16, "TATTG", (8, 30), "ont", kwin=(0, 42), anchor=300, seed=501)
+    d2 = synth.make_1d(16, "CAG", (5, 41), "ont_q20", kwin=(0, 50), anchor=250, seed=502)
+    j = synth.make_joint(6, alleles=((6, 4), (11, 3)), read_len=500, read_sd=30, anchor=300, seed=503)
+    cr, k1, k2 = _cells(j, step=2)
+    want = [oracle.round3_1d(d["regions"], d["reads"], d["kmin"], d["kmax"]) for d in (d1, d2)]
+    want2d = oracle.joint_2d(j["region"], j["reads"], cr, k1, k2)
+    errors = []
+
+    def worker(which):
+        try:
+            for rep in range(6):
+                d, o = ((d1, want[0]), (d2, want[1]))[(which + rep) % 2]
+                g = capi.round3_1d(d["regions"], d["reads"], d["kmin"], d["kmax"])
+                for k in KEYS_1D:
+                    assert np.array_equal(g[k], o[k]), (which, rep, k)
+                g2 = capi.joint_2d(j["region"], j["reads"], cr, k1, k2)
+                for k in KEYS_2D:
+                    assert np.array_equal(g2[k], want2d[k]), (which, rep, k)
+                with pytest.raises(capi.NraError) as e:          # the error text belongs to this thread's call
+                    capi.round3_1d(d["regions"], ["A" * (8001 + which)], [0], [1])
+                assert str(8001 + which) in str(e.value)
+        except BaseException as exc:                              # noqa: BLE001 - reported in the main thread
+            errors.append(exc)
+
+    threads = [threading.Thread(target=worker, args=(i,)) for i in range(2)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errors, errors
