@@ -563,3 +563,23 @@ def test_concurrent_calls_from_two_threads(capi, oracle):
     for t in threads:
         t.join()
     assert not errors, errors
+
+
+def test_1d_largest_single_block_reads(capi, oracle):
+    """Reads of 3000-3072 bases: the largest rows-per-lane instantiation (R = 48) and the widest score
+    range the doubled (origin-bit) int16 cells see with the default scoring."""
+    rng = np.random.default_rng(47)
+    L, R, u = synth.rand_seq(rng, 150), synth.rand_seq(rng, 150), "CAG"
+    reads, kmin, kmax = [], [], []
+    for k in (944, 943, 920, 944):                        # 120 + 3k + 120 = 3072, 3069, 3000, 3072 bases
+        core = L[-120:] + u * k + R[:120]
+        read = synth.apply_errors(rng, core, "hifi")[:3072] if len(reads) else core      # one exactly 3072, error-free
+        assert 2900 < len(read) <= 3072
+        reads.append(read); kmin.append(k - 3); kmax.append(k + 3)
+    reads.append(L[-100:] + u * 1000)                     # 3100 > 3072: chained, in the same batch
+    kmin.append(998); kmax.append(1001)
+    g = capi.round3_1d([(L, u, R)], reads, kmin, kmax)
+    o = oracle.round3_1d([(L, u, R)], reads, kmin, kmax)
+    for k in KEYS_1D:
+        assert np.array_equal(g[k], o[k]), k
+    assert max(o["best_score"]) > 5000
