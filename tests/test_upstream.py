@@ -113,3 +113,19 @@ def test_align_pairs_matches_oracle(capi, oracle):
             assert np.array_equal(g[k], o[k]), (k, g[k], o[k])
     with pytest.raises(capi.NraError):
         capi.align_pairs([synth.rand_seq(rng, 3073), "ACGT"], [0], [1])
+
+
+def test_round3_keeps_round2_size_for_cores_beyond_the_kernel_limits(oracle):
+    """A core longer than 8000 bases (or a template beyond 65000 columns) does not fail the batch."""
+    import numpy as np
+    from nanorepeat_amd import round3 as R3, synth
+    rng = np.random.default_rng(8)
+    rr = R3.RepeatRegion("chr1\t100\t160\tCAG")
+    rr.left_anchor_seq, rr.right_anchor_seq = synth.rand_seq(rng, 200), synth.rand_seq(rng, 200)
+    for name, k, r2 in (("ok", 20, 19.6), ("huge", 2700, 2700.0)):
+        rd = R3.Read(name, r2)
+        rr.read_dict[name] = rd
+        rr.read_core_seq_dict[name] = rr.left_anchor_seq[-100:] + "CAG" * k + rr.right_anchor_seq[:100]
+    R3.round3_estimation("ont", False, rr, 1, scorer=oracle.round3_1d)
+    assert rr.read_dict["ok"].round3_repeat_size == 20.0 and rr.read_dict["ok"].round3_status == 0
+    assert rr.read_dict["huge"].round3_repeat_size == 2700.0 and rr.read_dict["huge"].round3_status == R3.READ_TOO_LONG
