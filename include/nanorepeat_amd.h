@@ -186,7 +186,8 @@ int nra_joint_2d(int device,
  *
  * n_seqs sequences concatenated in `seqs` (offsets seq_off[n_seqs+1]); n_pairs pairs
  * (pair_query[i], pair_target[i]) of sequence indices.  A sequence used as a query holds at
- * most 3072 bases, as a target at most 65000.  Outputs per pair: score (AS; -1 when below
+ * most 8000 bases (above 3072: chained row blocks; nra_align_pairs_cigar: 3072), as a target
+ * at most 65000.  Outputs per pair: score (AS; -1 when below
  * min_dp_score), tstart, tend (target coordinates, 0-based half-open; oracle tie-breaks:
  * largest tstart, then smallest tend; -1 when no record). */
 int nra_align_pairs(int device,

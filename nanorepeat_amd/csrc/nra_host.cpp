@@ -1248,7 +1248,8 @@ struct PairSetup {
 };
 
 int prepare_pairs(int device, int32_t n_seqs, const char* seqs, const int64_t* seq_off, int64_t n_pairs,
-                  const int32_t* pair_query, const int32_t* pair_target, const nra_scoring_t* sc, PairSetup& ps)
+                  const int32_t* pair_query, const int32_t* pair_target, const nra_scoring_t* sc, PairSetup& ps,
+                  int64_t max_query = NRA_MAX_QLEN_1BLOCK)
 {
     if (n_seqs < 0 || n_pairs < 0) return fail(NRA_E_ARG, "negative count");
     if (n_seqs > 0 && (!seqs || !seq_off)) return fail(NRA_E_ARG, "NULL sequence array");
@@ -1283,7 +1284,7 @@ int prepare_pairs(int device, int32_t n_seqs, const char* seqs, const int64_t* s
             if (ps.pool.size() > 0xfff00000ull) return fail(NRA_E_RANGE, "target pool exceeds 4 GB");
         }
         if (ps.as_query[s] == 0) {
-            if (len > NRA_MAX_QLEN_1BLOCK) return fail(NRA_E_RANGE, "query longer than " + std::to_string(NRA_MAX_QLEN_1BLOCK));
+            if (len > max_query) return fail(NRA_E_RANGE, "query longer than " + std::to_string(max_query));
             if (max_score(sc, len) > kScoreCapI32)
                 return fail(NRA_E_RANGE, "query " + std::to_string(s) + ": match score x length does not fit 16 bits");
             NraDevRead r{};
@@ -1320,21 +1321,28 @@ int nra_align_pairs(int device, int32_t n_seqs, const char* seqs, const int64_t*
     (void)flags;
     if (n_pairs > 0 && (!score || !tstart || !tend)) return fail(NRA_E_ARG, "NULL output array");
     PairSetup ps;
-    int rc = prepare_pairs(device, n_seqs, seqs, seq_off, n_pairs, pair_query, pair_target, sc, ps);
+    int rc = prepare_pairs(device, n_seqs, seqs, seq_off, n_pairs, pair_query, pair_target, sc, ps, NRA_MAX_QLEN);
     if (rc || n_pairs == 0) return rc;
-    // tasks by rows-per-lane bucket of the query
-    std::vector<std::vector<NraTask>> by_bucket((size_t)kNumR);
+    // tasks by rows-per-lane bucket of the query; bucket kNumR = queries longer than one register
+    // block, swept as chained row blocks (scratch strip per wave)
+    std::vector<std::vector<NraTask>> by_bucket((size_t)kNumR + 1);
+    int chain_cols = 0;
     for (int64_t i = 0; i < n_pairs; ++i) {
         const int32_t qi = ps.as_query[pair_query[i]];
+        const int32_t ti = ps.as_target[pair_target[i]];
         if (ps.dreads[qi].qlen == 0) continue;
-        by_bucket[rows_for_qlen(ps.dreads[qi].qlen)].push_back(NraTask{qi, ps.as_target[pair_target[i]], -1, (int32_t)i});
+        const bool lng = ps.dreads[qi].qlen > NRA_MAX_QLEN_1BLOCK;
+        if (lng) chain_cols = std::max(chain_cols, ps.dregs[ti].l1);
+        by_bucket[lng ? kNumR : rows_for_qlen(ps.dreads[qi].qlen)].push_back(NraTask{qi, ti, -1, (int32_t)i});
     }
+    const int chain_cap = (chain_cols + 127) / 64 * 64 + 64;
+    const int chain_waves = 512;
     std::vector<NraTask> tasks;
     std::vector<int32_t> counts;
-    std::vector<std::pair<int, size_t>> launches;     // (R, offset)
-    for (int bi = kNumR - 1; bi >= 0; --bi) {
+    std::vector<std::pair<int, size_t>> launches;     // (R, offset); R = 0 marks the chained bucket
+    for (int bi = kNumR; bi >= 0; --bi) {
         if (by_bucket[bi].empty()) continue;
-        launches.push_back({kRList[bi], tasks.size()});
+        launches.push_back({bi == kNumR ? 0 : kRList[bi], tasks.size()});
         counts.push_back((int32_t)by_bucket[bi].size());
         tasks.insert(tasks.end(), by_bucket[bi].begin(), by_bucket[bi].end());
     }
@@ -1342,19 +1350,23 @@ int nra_align_pairs(int device, int32_t n_seqs, const char* seqs, const int64_t*
     ArenaScope arena_scope(&arena);
     arena.expect(ps.pool.size() + ps.q2bit.size() * 6 + (size_t)n_pairs * 32 + (2u << 20));
     DevBuf<uint8_t> d_pool; DevBuf<uint32_t> d_q2, d_nm; DevBuf<NraDevRegion> d_regs; DevBuf<NraDevRead> d_reads;
-    DevBuf<NraTask> d_tasks; DevBuf<int32_t> d_counts, d_score, d_ts, d_te;
+    DevBuf<NraTask> d_tasks; DevBuf<int32_t> d_counts, d_score, d_ts, d_te, d_chain;
     HIP_TRY(d_pool.upload(ps.pool)); HIP_TRY(d_q2.upload(ps.q2bit)); HIP_TRY(d_nm.upload(ps.nmask));
     HIP_TRY(d_regs.upload(ps.dregs)); HIP_TRY(d_reads.upload(ps.dreads)); HIP_TRY(d_tasks.upload(tasks));
     HIP_TRY(d_counts.upload(counts));
     HIP_TRY(d_score.alloc((size_t)n_pairs)); HIP_TRY(d_ts.alloc((size_t)n_pairs)); HIP_TRY(d_te.alloc((size_t)n_pairs));
+    if (!by_bucket[kNumR].empty()) HIP_TRY(d_chain.alloc((size_t)chain_waves * 6 * (size_t)chain_cap));
     HIP_TRY(hipMemset(d_score.p, 0xff, (size_t)n_pairs * 4));
     HIP_TRY(hipMemset(d_ts.p, 0xff, (size_t)n_pairs * 4));
     HIP_TRY(hipMemset(d_te.p, 0xff, (size_t)n_pairs * 4));
     const NraScoreParams sp = to_params(*sc);
     for (size_t i = 0; i < launches.size(); ++i) {
-        LAUNCH_TRY(nra_launch_payload_origin(launches[i].first, ps.has_n ? 1 : 0, nullptr, std::min(counts[i], 256 * 16),
+        const bool chained = launches[i].first == 0;
+        LAUNCH_TRY(nra_launch_payload_origin(chained ? NRA_CHAIN_R : launches[i].first, ps.has_n ? 1 : 0, nullptr,
+                                             std::min(counts[i], chained ? chain_waves : 256 * 16),
                                              d_tasks.p + launches[i].second, d_counts.p + i, d_reads.p, d_regs.p,
-                                             d_pool.p, d_q2.p, d_nm.p, sp, d_score.p, d_ts.p, d_te.p, nullptr, 0));
+                                             d_pool.p, d_q2.p, d_nm.p, sp, d_score.p, d_ts.p, d_te.p,
+                                             chained ? d_chain.p : nullptr, chained ? chain_cap : 0));
     }
     HIP_TRY(hipDeviceSynchronize());
     HIP_TRY(hipMemcpy(score, d_score.p, (size_t)n_pairs * 4, hipMemcpyDeviceToHost));

@@ -583,3 +583,24 @@ def test_1d_largest_single_block_reads(capi, oracle):
     for k in KEYS_1D:
         assert np.array_equal(g[k], o[k]), k
     assert max(o["best_score"]) > 5000
+
+
+def test_align_pairs_long_queries(capi, oracle):
+    """nra_align_pairs with queries of 3.1-7.9 kb (chained row blocks) next to short ones, as the
+    round-2 estimate of a long core needs (nanoRepeat_bam.py:362)."""
+    rng = np.random.default_rng(55)
+    L, u = synth.rand_seq(rng, 300), "GGCCCC"
+    target = L + u * 1400
+    seqs = [target]
+    for k in (500, 900, 1290, 30):
+        seqs.append(synth.apply_errors(rng, L[-100:] + u * k + synth.rand_seq(rng, 80), "ont_q20")[:7990])
+    seqs.append("N" * 10 + seqs[1][10:3500])
+    pq = list(range(1, len(seqs))); pt = [0] * len(pq)
+    g = capi.align_pairs(seqs, pq, pt)
+    o = oracle.align_pairs(seqs, pq, pt)
+    assert max(len(s) for s in seqs[1:]) > 7000
+    for k in ("score", "tstart", "tend"):
+        assert np.array_equal(g[k], o[k]), (k, g[k], o[k])
+    with pytest.raises(capi.NraError) as e:
+        capi.align_pairs([target, "A" * 8001], [1], [0])
+    assert e.value.code == -3

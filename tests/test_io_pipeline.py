@@ -146,3 +146,26 @@ def test_joint_mode_readers_match_reference(golden, tmp_path):
     fq = tmp_path / "x.fastq"; fq.write_text(golden["fastq_dict"]["text"])
     got = IO.fastq_file_to_dict(str(fq))
     assert got == golden["fastq_dict"]["dict"] and list(got) == list(golden["fastq_dict"]["dict"])
+
+
+@pytest.mark.gpu
+def test_pipeline_with_a_long_expansion_gpu_equals_oracle(capi, oracle):
+    """An allele of 1150 CAG units (core of 3.6 kb: more than one register block) goes through
+    anchors -> core -> round 2 (chained pair alignment) -> round 3 (chained sweeps) like the short one."""
+    rng = np.random.default_rng(91)
+    left, right = synth.rand_seq(rng, 500), synth.rand_seq(rng, 500)
+    out = {}
+    for name, kw in (("gpu", {}), ("cpu", dict(aligner=oracle.align_pairs, scorer=oracle.round3_1d))):
+        rr = R3.RepeatRegion("chrL\t500\t560\tCAG")
+        rr.left_anchor_seq, rr.right_anchor_seq = left, right
+        rr.left_anchor_len = rr.right_anchor_len = 500
+        rng2 = np.random.default_rng(92)
+        reads = {}
+        for i, k in enumerate((30, 1150, 31, 1148)):
+            s = synth.apply_errors(rng2, left[-300:] + "CAG" * k + right[:300], "hifi")
+            reads[f"x{i}"] = synth.revcomp(s) if i == 2 else s
+        pipeline.quantify_regions([rr], [reads], "hifi", **kw)
+        out[name] = {n: (r.round2_repeat_size, r.round3_repeat_size, r.round3_status) for n, r in rr.read_dict.items()}
+    assert out["gpu"] == out["cpu"]
+    sizes = [out["gpu"][f"x{i}"][1] for i in range(4)]
+    assert abs(sizes[0] - 30) <= 1 and abs(sizes[1] - 1150) <= 12 and abs(sizes[3] - 1148) <= 12, sizes   # ~1 % indel noise

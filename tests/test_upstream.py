@@ -111,8 +111,10 @@ def test_align_pairs_matches_oracle(capi, oracle):
         o = oracle.align_pairs(seqs, pq, pt, sc=oracle.default_scoring(**over))
         for k in ("score", "tstart", "tend"):
             assert np.array_equal(g[k], o[k]), (k, g[k], o[k])
-    with pytest.raises(capi.NraError):
-        capi.align_pairs([synth.rand_seq(rng, 3073), "ACGT"], [0], [1])
+    with pytest.raises(capi.NraError):                       # queries: <= 8000 bases (chained above 3072)
+        capi.align_pairs([synth.rand_seq(rng, 8001), "ACGT"], [0], [1])
+    with pytest.raises(capi.NraError):                       # the traceback keeps one register block
+        capi.align_pairs_cigar([synth.rand_seq(rng, 3073), "ACGT"], [0], [1])
 
 
 def test_round3_keeps_round2_size_for_cores_beyond_the_kernel_limits(oracle):
