@@ -526,6 +526,7 @@ def test_differential_fuzz_small():
     rng = np.random.default_rng(20260104)
     for _ in range(60):
         assert fz.fuzz_1d(rng) is None
+        assert fz.fuzz_1d_multi(rng) is None
         assert fz.fuzz_2d(rng) is None
 
 

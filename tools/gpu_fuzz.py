@@ -70,6 +70,49 @@ def fuzz_1d(rng):
     return None
 
 
+def fuzz_1d_multi(rng):
+    """Several regions in one batch (reads paired per region, buckets folded), N bases in the
+    templates, skipped reads, per-candidate extents of the ties."""
+    n_reg = int(rng.integers(2, 5))
+    regions, reads, kmin, kmax, rr = [], [], [], [], []
+    for g in range(n_reg):
+        unit = synth.rand_unit(rng, int(rng.integers(1, 7)))
+        L = synth.rand_seq(rng, int(rng.choice([3, 40, 200, 600]))); R = synth.rand_seq(rng, int(rng.choice([2, 50, 200, 600])))
+        if rng.random() < 0.2:
+            L = mangle(rng, L)
+        regions.append((L, unit, R))
+        for _ in range(int(rng.integers(1, 9))):
+            k = int(rng.integers(0, 60))
+            fl, fr = int(rng.integers(1, min(len(L), 120) + 1)), int(rng.integers(1, min(len(R), 120) + 1))
+            s = synth.apply_errors(rng, L[len(L) - fl:] + unit * k + R[:fr], ["hifi", "ont_q20", "ont"][int(rng.integers(0, 3))])
+            reads.append(mangle(rng, s)); rr.append(g)
+            lo = max(0, k - int(rng.integers(0, 16))); hi = k + int(rng.integers(0, 16))
+            if rng.random() < 0.08: lo, hi = 3, 2
+            kmin.append(lo); kmax.append(hi)
+    order = rng.permutation(len(reads))
+    reads = [reads[i] for i in order]; kmin = [kmin[i] for i in order]; kmax = [kmax[i] for i in order]; rr = [rr[i] for i in order]
+    o = O.round3_1d(regions, reads, kmin, kmax, read_region=rr)
+    for flags in (0, A.F_TIE_EXTENTS, A.F_ALL_EXTENTS):
+        g = A.round3_1d(regions, reads, kmin, kmax, read_region=rr, flags=flags)
+        keys, want = K1, o
+        if flags == A.F_ALL_EXTENTS:
+            keys = K1 + ("cand_tstart", "cand_tend")
+            want = O.round3_1d(regions, reads, kmin, kmax, read_region=rr, flags=flags)
+        for k in keys:
+            if not np.array_equal(g[k], want[k]):
+                return dict(kind="1d-multi", flags=flags, key=k, regions=regions, reads=reads, kmin=kmin, kmax=kmax, rr=rr,
+                            got=g[k].tolist(), want=want[k].tolist())
+        if flags == A.F_TIE_EXTENTS:      # extents are defined for the candidates tied at the best score
+            ncand = np.maximum(np.array(kmax) - np.array(kmin) + 1, 0)
+            tied = np.repeat(o["best_score"], ncand) == o["cand_score"]
+            tied &= o["cand_score"] > 0
+            for k in ("cand_tstart", "cand_tend"):
+                if not np.array_equal(g[k][tied], o[k][tied]):
+                    return dict(kind="1d-multi", flags=flags, key=k, regions=regions, reads=reads, kmin=kmin, kmax=kmax, rr=rr,
+                                got=g[k][tied].tolist(), want=o[k][tied].tolist())
+    return None
+
+
 def fuzz_2d(rng):
     u1 = synth.rand_unit(rng, int(rng.integers(1, 6))); u2 = synth.rand_unit(rng, int(rng.integers(1, 6)))
     L = synth.rand_seq(rng, int(rng.choice([1, 3, 9, 10, 11, 60, 300]))); R = synth.rand_seq(rng, int(rng.choice([1, 2, 3, 9, 10, 11, 60, 300])))
@@ -105,7 +148,7 @@ if __name__ == "__main__":
     rng = np.random.default_rng(seed)
     t0 = time.time(); bad = 0
     for i in range(rounds):
-        for f in (fuzz_1d, fuzz_2d):
+        for f in (fuzz_1d, fuzz_1d_multi, fuzz_2d):
             r = f(rng)
             if r is not None:
                 bad += 1
