@@ -48,3 +48,32 @@ def test_no_cpu_fallback_in_product(capi):
                 src = open(os.path.join(dirpath, f)).read()
                 for bad in ("import oracle", "from oracle", "libnr_oracle", "nr_oracle.h", "nro_"):
                     assert bad not in src, (f, bad)
+
+
+def test_fails_loudly_without_a_device_and_validates_arguments_first(capi):
+    """No CPU path: on a box without a HIP device every compute entry point returns NRA_E_DEVICE
+    (argument errors are reported before the device is touched).  Skipped where a GPU is present --
+    the GPU suite covers the error paths there."""
+    import numpy as np
+    if capi.load().nra_device_count() > 0:
+        import pytest
+        pytest.skip("a HIP device is present")
+    good = ([("ACGTACGTAC", "CAG", "TTGACCA")], ["ACGTACCAGCAGTTGA"], [0], [3])
+    for call in (lambda: capi.round3_1d(*good),
+                 lambda: capi.joint_2d(("ACGTAC", "CAG", "AT", "CCG", "GGTTAA"), ["ACGTACCAGCAGATCCGGGTT"], [0], [2], [1]),
+                 lambda: capi.align_pairs(["ACGTACGT", "ACGTTCGT"], [0], [1]),
+                 lambda: capi.align_pairs_cigar(["ACGTACGT", "ACGTTCGT"], [0], [1])):
+        try:
+            call()
+        except capi.NraError as e:
+            assert e.code == -2 and "no HIP device" in str(e)
+        else:
+            raise AssertionError("a compute call succeeded without a HIP device")
+    for bad in (lambda: capi.round3_1d([("ACGT", "", "TT")], ["ACGT"], [0], [3]),                 # empty unit
+                lambda: capi.round3_1d(good[0], good[1], [0], [3], sc=capi.default_scoring(match=0))):
+        try:
+            bad()
+        except capi.NraError as e:
+            assert e.code == -1, e
+        else:
+            raise AssertionError("an invalid argument was accepted")
