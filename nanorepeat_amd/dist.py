@@ -83,3 +83,62 @@ def round3_1d_sharded(regions, reads, kmin, kmax, read_region=None, sc=None, fla
         out["n_ties"][idx] = p[:, 3]
         out["status"][idx] = p[:, 4]
     return out
+
+
+def estimate_cells_2d(region, reads, cell_read, cell_k1, cell_k2):
+    """Algorithmic DP cells of every read of a joint batch: qlen * sum over its cells of the
+    template length (every rank runs the full grid of its own reads)."""
+    left, u1, mid, u2, right = region
+    tl = (len(left) + len(mid) + len(right) + len(u1) * np.asarray(cell_k1, np.int64) +
+          len(u2) * np.asarray(cell_k2, np.int64))
+    per_read = np.bincount(np.asarray(cell_read, np.int64), weights=tl, minlength=len(reads)).astype(np.int64)
+    return np.array([len(r) for r in reads], np.int64) * per_read
+
+
+def joint_2d_sharded(region, reads, cell_read, cell_k1, cell_k2, read_strand=None, sc=None, flags=0,
+                     device=None, group=None, scorer=None):
+    """The joint grid on several GPUs: every rank calls this with the SAME full inputs (cells
+    grouped by read, as nra_joint_2d wants them), scores the cells of its shard of the reads and
+    all ranks return the full per-read arrays (read_strand, best_wscore, sum_k1, sum_k2, n_ties,
+    status).  One all_gather of 56 B per read; per-cell arrays stay on the rank that made them."""
+    import torch
+    import torch.distributed as dist
+
+    world = dist.get_world_size(group) if dist.is_initialized() else 1
+    rank = dist.get_rank(group) if dist.is_initialized() else 0
+    scorer = scorer or _capi.joint_2d
+    cr = np.asarray(cell_read, np.int64)
+    k1 = np.asarray(cell_k1, np.int32)
+    k2 = np.asarray(cell_k2, np.int32)
+    n = len(reads)
+    shards = shard_reads(estimate_cells_2d(region, reads, cr, k1, k2), world)
+    mine = shards[rank]
+    new_index = np.full(n, -1, np.int64)
+    new_index[mine] = np.arange(len(mine))
+    keep = new_index[cr] >= 0                                  # cells of my reads, original (grouped) order
+    order = np.argsort(new_index[cr][keep], kind="stable")      # regroup by the shard's read numbering
+    st_in = None if read_strand is None else np.asarray(read_strand, np.int8)[mine]
+    if device is None:
+        device = rank if not torch.cuda.is_available() else torch.cuda.current_device()
+    local = scorer(region, [reads[i] for i in mine], new_index[cr][keep][order].astype(np.int32), k1[keep][order],
+                   k2[keep][order], read_strand=st_in, sc=sc, flags=flags, device=device)
+    cols = ("read_strand", "best_wscore", "sum_k1", "sum_k2", "n_ties", "status")
+    packed = np.stack([mine.astype(np.int64)] + [np.asarray(local[c]).astype(np.int64) for c in cols], 1)
+    if world == 1:
+        parts = [packed]
+    else:
+        backend = dist.get_backend(group)
+        dev = torch.device("cuda", torch.cuda.current_device()) if backend == "nccl" else torch.device("cpu")
+        cap = max(len(s) for s in shards)
+        buf = torch.full((cap, 1 + len(cols)), -1, dtype=torch.int64, device=dev)
+        if len(mine):
+            buf[:len(mine)] = torch.from_numpy(packed).to(dev)
+        gathered = [torch.empty_like(buf) for _ in range(world)]
+        dist.all_gather(gathered, buf, group=group)
+        parts = [g.cpu().numpy()[:len(shards[r])] for r, g in enumerate(gathered)]
+    out = dict(read_strand=np.zeros(n, np.int8), best_wscore=np.zeros(n, np.int32), sum_k1=np.zeros(n, np.int64),
+               sum_k2=np.zeros(n, np.int64), n_ties=np.zeros(n, np.int32), status=np.zeros(n, np.uint8))
+    for p in parts:
+        for j, c in enumerate(cols):
+            out[c][p[:, 0]] = p[:, 1 + j]
+    return out

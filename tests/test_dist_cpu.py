@@ -47,6 +47,60 @@ def test_sharded_equals_single_process(oracle):
             assert res[r][k] == want[k].tolist(), (r, k)
 
 
+def _worker_2d(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    import torch.distributed as dist
+    from nanorepeat_amd import dist as D, synth
+    from oracle import oracle as O
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        j, cr, k1, k2 = _joint_case(synth)
+        out = D.joint_2d_sharded(j["region"], j["reads"], cr, k1, k2,
+                                 scorer=lambda *a, **k: O.joint_2d(*a, threads=1, **{x: y for x, y in k.items() if x != "device"}))
+        q.put((rank, {k: v.tolist() for k, v in out.items()}))
+    finally:
+        dist.destroy_process_group()
+
+
+def _joint_case(synth):
+    j = synth.make_joint(7, alleles=((6, 4), (11, 3)), read_len=420, read_sd=25, anchor=200, seed=19)
+    cr, k1, k2 = [], [], []
+    for r in range(7):
+        for a in range(3, 14, 2 + r % 2):
+            for b in range(1, 7, 2):
+                cr.append(r); k1.append(a); k2.append(b)
+    return j, cr, k1, k2
+
+
+@pytest.mark.timeout(300)
+def test_joint_sharded_equals_single_process(oracle):
+    """2D: reads sharded over two ranks, every rank runs the full grid of its own reads."""
+    from nanorepeat_amd import synth, dist as D
+    world, port = 2, 33500 + os.getpid() % 2000
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker_2d, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = dict(q.get(timeout=240) for _ in range(world))
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    j, cr, k1, k2 = _joint_case(synth)
+    want = oracle.joint_2d(j["region"], j["reads"], cr, k1, k2)
+    for r in range(world):
+        for k in ("read_strand", "best_wscore", "sum_k1", "sum_k2", "n_ties", "status"):
+            assert res[r][k] == want[k].tolist(), (r, k)
+    cells = D.estimate_cells_2d(j["region"], j["reads"], cr, k1, k2)
+    assert cells.shape == (7,) and (cells > 0).all()
+    # world size 1 (no process group): same answer, no collective
+    one = D.joint_2d_sharded(j["region"], j["reads"], cr, k1, k2, scorer=lambda *a, **k: oracle.joint_2d(*a, **{x: y for x, y in k.items() if x != "device"}))
+    for k in ("read_strand", "best_wscore", "sum_k1", "sum_k2", "n_ties", "status"):
+        assert one[k].tolist() == want[k].tolist(), k
+
+
 def test_shard_reads_is_a_balanced_partition():
     from nanorepeat_amd import dist as D
     rng = np.random.default_rng(0)
