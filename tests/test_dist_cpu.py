@@ -156,3 +156,39 @@ def test_sharded_hip_path_two_ranks_one_gpu(capi, oracle):
     for r in range(world):
         for k in ("best_score", "sum_k", "n_ties", "status"):
             assert res[r][k] == want[k].tolist(), (r, k)
+
+
+def _gpu_worker_2d(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    import torch.distributed as dist
+    from nanorepeat_amd import dist as D, synth
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        j, cr, k1, k2 = _joint_case(synth)
+        out = D.joint_2d_sharded(j["region"], j["reads"], cr, k1, k2, device=0)      # both ranks share GPU 0
+        q.put((rank, {k: v.tolist() for k, v in out.items()}))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+@pytest.mark.timeout(300)
+def test_joint_sharded_hip_path_two_ranks_one_gpu(capi, oracle):
+    from nanorepeat_amd import synth
+    world, port = 2, 35500 + os.getpid() % 2000
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_gpu_worker_2d, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = dict(q.get(timeout=240) for _ in range(world))
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    j, cr, k1, k2 = _joint_case(synth)
+    want = oracle.joint_2d(j["region"], j["reads"], cr, k1, k2)
+    for r in range(world):
+        for k in ("read_strand", "best_wscore", "sum_k1", "sum_k2", "n_ties", "status"):
+            assert res[r][k] == want[k].tolist(), (r, k)
