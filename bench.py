@@ -186,13 +186,18 @@ def main():
         exe_cells_per_s = st["executed_cells"] / kernel_s
         achieved = alg_cells_per_s * LANEOPS_PER_CELL / 1e12
         executed = exe_cells_per_s * LANEOPS_PER_CELL / 1e12
-        traffic = None
+        traffic, counters = None, None
         prof = os.path.join(ROOT, "profiles", "r01f_pmc_traffic.json")
-        if os.path.exists(prof):
+        if os.path.exists(prof) and not args.brute:
             try:
-                traffic = json.load(open(prof)).get("hbm_bytes_per_step_sweep_kernels")
+                pmc = json.load(open(prof))
+                traffic = pmc.get("hbm_bytes_per_step_sweep_kernels")
+                counters = {"source": "profiles/r01f_pmc_traffic.json (rocprofv3 --pmc passes of this command, --steps 1)",
+                            "valu_wave_instructions_per_step": pmc["sweep_kernels"]["valu_wave_instructions_per_step"],
+                            "simd_cycles_per_valu_instruction": pmc.get("simd_cycles_per_valu_instruction"),
+                            "VALUBusy_pct": pmc["sweep_kernels"].get("VALUBusy_pct")}
             except Exception:
-                traffic = None
+                traffic, counters = None, None
         hbm_gbps = st["algorithmic_bytes"] / kernel_s / 1e9
         line = {
             "metric": "read-alignments/sec (reads x candidate-k)",
@@ -210,7 +215,7 @@ def main():
                        "parallelism": f"reads sharded over {world} GPU(s), no data-path collective"},
             "roofline": {"bound": "valu", "achieved": achieved, "peak": VALU_PEAK_TLANEOPS,
                          "unit": "Tlane-op/s", "frac": achieved / VALU_PEAK_TLANEOPS,
-                         "traffic": traffic,
+                         "traffic": traffic, "counters": counters,
                          "note": "achieved prices the ALGORITHMIC cells (SURVEY 8d: q x tlen for each of the K "
                                  "independent alignments) at 10 lane-ops per cell; the decomposition executes "
                                  "far fewer cells, so frac can exceed 1 -- 'executed' prices the cells the "
