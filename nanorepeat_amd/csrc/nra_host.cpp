@@ -677,7 +677,7 @@ int nra_batch1d_create(int device, const nra_region_t* regions, int32_t n_region
         HIP_TRY(b->snap_h.alloc(nbases));
         HIP_TRY(b->snap_e.alloc(nbases));
         HIP_TRY(b->snap_e2.alloc(nbases));
-        HIP_TRY(b->arr_a.alloc((size_t)total));
+        HIP_TRY(b->arr_a.alloc(by_bucket[kNumR].empty() ? 1 : (size_t)total));   // A_k: chained reads only
         HIP_TRY(b->read_a1d.alloc((size_t)n_reads));
     }
     HIP_TRY(b->cand_flag.alloc((size_t)total));
