@@ -251,6 +251,21 @@ bool scoring_ok(const nra_scoring_t* sc)
 const int64_t kScoreCapI32 = 32000, kScoreCapPk16 = 24000, kScoreCapChain = 16000, kScoreCapBit = 8000;
 inline int64_t max_score(const nra_scoring_t* sc, int64_t qlen) { return (int64_t)sc->match * qlen; }
 
+// A rows-per-lane bucket with few reads would run as its own under-filled launches: fold it into the
+// next non-empty instantiation within `span` more rows per lane (the extra rows are padding).
+void fold_small_buckets(std::vector<std::vector<int32_t>>& by_bucket, size_t min_reads, int span)
+{
+    for (int bi = 0; bi + 1 < kNumR; ++bi) {
+        if (by_bucket[bi].empty() || by_bucket[bi].size() >= min_reads) continue;
+        int up = -1;
+        for (int bj = bi + 1; bj < kNumR && kRList[bj] <= kRList[bi] + span; ++bj)
+            if (!by_bucket[bj].empty()) { up = bj; break; }
+        if (up < 0) continue;
+        by_bucket[up].insert(by_bucket[up].end(), by_bucket[bi].begin(), by_bucket[bi].end());
+        by_bucket[bi].clear();
+    }
+}
+
 // executed cells of one wave sweep: 64*R rows x (ceil((tlen+63)/64)*64) columns
 int64_t sweep_cells(int R, int tlen) { return (int64_t)64 * R * (((int64_t)tlen + 126) / 64 * 64); }
 
@@ -567,19 +582,7 @@ int nra_batch1d_create(int device, const nra_region_t* regions, int32_t n_region
         return fail(NRA_E_RANGE, "reads longer than " + std::to_string(NRA_MAX_QLEN_1BLOCK) +
                                      " bases need the junction decomposition (no brute force / ALL_EXTENTS, flanks >= 1)");
     b->chain_cap = (chain_cols + 127) / 64 * 64 + 64;
-    // a bucket with a handful of reads would run as its own under-filled launch: fold it into the
-    // next larger rows-per-lane instantiation (the extra rows are padding)
-    const size_t fold_min = 1024;     // wider folding (up to 16384 reads / 4 rows) changes nothing in 1D
-    const int fold_span = 2;
-    for (int bi = 0; bi + 1 < kNumR; ++bi) {
-        if (by_bucket[bi].empty() || by_bucket[bi].size() >= fold_min) continue;
-        int up = -1;
-        for (int bj = bi + 1; bj < kNumR && kRList[bj] <= kRList[bi] + fold_span; ++bj)
-            if (!by_bucket[bj].empty()) { up = bj; break; }
-        if (up < 0) continue;
-        by_bucket[up].insert(by_bucket[up].end(), by_bucket[bi].begin(), by_bucket[bi].end());
-        by_bucket[bi].clear();
-    }
+    fold_small_buckets(by_bucket, 1024, 2);    // wider folding (up to 16384 reads / 4 rows) changes nothing in 1D
     std::vector<NraPairTask> pair_tasks;
     std::vector<NraTask> queue_tasks;       // ALL_EXTENTS only; otherwise just capacity
     std::vector<int32_t> queue_count;
@@ -927,21 +930,8 @@ int nra_batch2d_create(int device, const nra_joint_region_t* reg, int32_t n_read
         if (cnt[r] == 0 || pr.reads[r].qlen == 0) continue;
         by_bucket[rows_for_qlen(pr.reads[r].qlen)].push_back(r);
     }
-    // a bucket with few reads would run as its own under-filled launches: fold it into the next
-    // larger rows-per-lane instantiation (the extra rows are padding), like the 1D path
-    {   // measured on config 3 (5000 reads, R = 13..28): (2048, 4) beats (1024, 2) and wider spans
-        const size_t fold_min = 2048;
-        const int fold_span = 4;
-        for (int bi = 0; bi + 1 < kNumR; ++bi) {
-            if (by_bucket[bi].empty() || by_bucket[bi].size() >= fold_min) continue;
-            int up = -1;
-            for (int bj = bi + 1; bj < kNumR && kRList[bj] <= kRList[bi] + fold_span; ++bj)
-                if (!by_bucket[bj].empty()) { up = bj; break; }
-            if (up < 0) continue;
-            by_bucket[up].insert(by_bucket[up].end(), by_bucket[bi].begin(), by_bucket[bi].end());
-            by_bucket[bi].clear();
-        }
-    }
+    // measured on config 3 (5000 reads, R = 13..28): (2048, 4) beats (1024, 2) and wider spans
+    fold_small_buckets(by_bucket, 2048, 4);
     std::vector<NraPairTask> pair_tasks;
     std::vector<NraTask> queue_tasks;
     std::vector<int32_t> queue_count;
