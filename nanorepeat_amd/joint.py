@@ -277,23 +277,29 @@ def cut_long_read(seq, candidate, limit=MAX_READ_2D, margin=TRIM_MARGIN):
     return seq[lo:hi]
 
 
+def _grid_product(k1_values, k2_values):
+    """All (k1, k2) pairs, k1-major: the order the reference's nested loops list a read's cells in."""
+    return np.repeat(k1_values, len(k2_values)), np.tile(k2_values, len(k1_values))
+
+
 def _score_cells(region, readnames, fastq_dict, cells_by_read, device, scoring, scorer, strands, candidates=None):
     """One C-ABI call for every (read, k1, k2) cell; returns (RepeatSize, raw outputs)."""
     scorer = scorer or _capi.joint_2d
-    names = [n for n in readnames if cells_by_read.get(n)]
+    names = [n for n in readnames if n in cells_by_read and len(cells_by_read[n][0])]
     reads = [cut_long_read(_read_seq(fastq_dict[n]), (candidates or {}).get(n)) for n in names]
-    cell_read, k1, k2 = [], [], []
-    for i, n in enumerate(names):
-        for a, b in cells_by_read[n]:
-            cell_read.append(i); k1.append(a); k2.append(b)
+    # cells of a read: (k1 array, k2 array), k1-major like the reference's nested grid loops
+    per_read = [cells_by_read[n] for n in names]
+    counts = [len(c[0]) for c in per_read]
+    cell_read = np.repeat(np.arange(len(names), dtype=np.int32), counts)
+    k1 = np.concatenate([c[0] for c in per_read]).astype(np.int32) if names else np.zeros(0, np.int32)
+    k2 = np.concatenate([c[1] for c in per_read]).astype(np.int32) if names else np.zeros(0, np.int32)
     est = RepeatSize()
     if not names:
         return est, None
     st_in = None
     if strands is not None:
         st_in = np.array([strands.get(n, 0) for n in names], np.int8)
-    out = scorer(region, reads, np.array(cell_read, np.int32), np.array(k1, np.int32),
-                 np.array(k2, np.int32), read_strand=st_in, sc=scoring, device=device)
+    out = scorer(region, reads, cell_read, k1, k2, read_strand=st_in, sc=scoring, device=device)
     for i, n in enumerate(names):
         if int(out["status"][i]) == _capi.READ_OK:        # nanoRepeat_joint.py:473-476
             nt = np.float64(out["n_ties"][i])
@@ -315,16 +321,17 @@ def round2_estimation_of_repeat_size(initial_estimation, fastq_dict, repeat_chro
     step_size1 = choose_best_step_size(repeat1, initial_estimation.repeat1_count_range_dict)
     step_size2 = choose_best_step_size(repeat2, initial_estimation.repeat2_count_range_dict)
     left, mid, right = extract_anchor_seq_for_two_repeats(repeat_chrom_seq, repeat1, repeat2, max_flanking_len)
+    # The reference loops grid cell by grid cell over all reads (:397-409); per read that is the
+    # product of the grid values inside its two round-1 ranges, k1-major.
+    grid1 = np.arange(repeat1.round1_min_size, repeat1.round1_max_size + 1, step_size1)
+    grid2 = np.arange(repeat2.round1_min_size, repeat2.round1_max_size + 1, step_size2)
     cells = {}
-    for repeat_count1 in range(repeat1.round1_min_size, repeat1.round1_max_size + 1, step_size1):
-        for repeat_count2 in range(repeat2.round1_min_size, repeat2.round1_max_size + 1, step_size2):
-            for readname in fastq_dict:                                   # :402-409
-                if readname not in initial_estimation.repeat1_count_range_dict: continue
-                if readname not in initial_estimation.repeat2_count_range_dict: continue
-                min1, max1 = initial_estimation.repeat1_count_range_dict[readname]
-                min2, max2 = initial_estimation.repeat2_count_range_dict[readname]
-                if min1 <= repeat_count1 < max1 and min2 <= repeat_count2 < max2:
-                    cells.setdefault(readname, []).append((repeat_count1, repeat_count2))
+    for readname in fastq_dict:
+        if readname not in initial_estimation.repeat1_count_range_dict: continue
+        if readname not in initial_estimation.repeat2_count_range_dict: continue
+        min1, max1 = initial_estimation.repeat1_count_range_dict[readname]
+        min2, max2 = initial_estimation.repeat2_count_range_dict[readname]
+        cells[readname] = _grid_product(grid1[(grid1 >= min1) & (grid1 < max1)], grid2[(grid2 >= min2) & (grid2 < max2)])
     region = (left, repeat1.repeat_unit, mid, repeat2.repeat_unit, right)
     est, _ = _score_cells(region, list(fastq_dict), fastq_dict, cells, device, scoring, scorer, strands,
                           getattr(initial_estimation, "potential_repeat_region_dict", None))
@@ -355,21 +362,19 @@ def round3_estimation_of_repeat_size(initial_estimation, round2_estimation, fast
     min_size2 = max(0, int(min(size2_list) - buffer_size2))
     max_size2 = int(max(size2_list) + buffer_size2 + 2)
     left, mid, right = extract_anchor_seq_for_two_repeats(repeat_chrom_seq, repeat1, repeat2, max_flanking_len)
+    grid1 = np.arange(min_size1, max_size1)
+    grid2 = np.arange(min_size2, max_size2)
     cells = {}
-    for repeat_count1 in range(min_size1, max_size1):
-        for repeat_count2 in range(min_size2, max_size2):
-            for readname in fastq_dict:                                   # :320-330
-                if readname not in round2_estimation.repeat1_count_dict: continue
-                if readname not in round2_estimation.repeat2_count_dict: continue
-                size1 = round2_estimation.repeat1_count_dict[readname]
-                size2 = round2_estimation.repeat2_count_dict[readname]
-                if repeat_count1 < size1 - buffer_size1 or repeat_count1 >= size1 + buffer_size1: continue
-                if repeat_count2 < size2 - buffer_size2 or repeat_count2 >= size2 + buffer_size2: continue
-                r1min1, r1max1 = initial_estimation.repeat1_count_range_dict[readname]
-                r1min2, r1max2 = initial_estimation.repeat2_count_range_dict[readname]
-                if repeat_count1 < r1min1 or repeat_count1 >= r1max1: continue
-                if repeat_count2 < r1min2 or repeat_count2 >= r1max2: continue
-                cells.setdefault(readname, []).append((repeat_count1, repeat_count2))
+    for readname in fastq_dict:                                           # :320-330, per read
+        if readname not in round2_estimation.repeat1_count_dict: continue
+        if readname not in round2_estimation.repeat2_count_dict: continue
+        size1 = round2_estimation.repeat1_count_dict[readname]
+        size2 = round2_estimation.repeat2_count_dict[readname]
+        r1min1, r1max1 = initial_estimation.repeat1_count_range_dict[readname]
+        r1min2, r1max2 = initial_estimation.repeat2_count_range_dict[readname]
+        keep1 = (grid1 >= size1 - buffer_size1) & (grid1 < size1 + buffer_size1) & (grid1 >= r1min1) & (grid1 < r1max1)
+        keep2 = (grid2 >= size2 - buffer_size2) & (grid2 < size2 + buffer_size2) & (grid2 >= r1min2) & (grid2 < r1max2)
+        cells[readname] = _grid_product(grid1[keep1], grid2[keep2])
     region = (left, repeat1.repeat_unit, mid, repeat2.repeat_unit, right)
     est, _ = _score_cells(region, list(fastq_dict), fastq_dict, cells, device, scoring, scorer, strands,
                           getattr(initial_estimation, "potential_repeat_region_dict", None))
