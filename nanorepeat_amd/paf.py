@@ -35,18 +35,26 @@ class PAF:
             self.qstart, self.qend = self.qlen - self.qend, self.qlen - self.qstart
 
 
+_CIGAR_ITEM = re.compile(r"(\d+)([=XIDNSHPM])")
+_CIGAR_WHOLE = re.compile(r"(?:\d+[=XIDNSHPM])*\Z")
+
+
 def cigar_ops(cigar):
     """[(op, length)] of a CIGAR string (tk.analysis_cigar_string, tk.py:379-401)."""
-    ops = [(op, int(n)) for n, op in re.findall(r"(\d+)([=XIDNSHPM])", cigar)]
-    if sum(len(str(n)) + 1 for _, n in ops) != len(cigar):
+    if not _CIGAR_WHOLE.match(cigar):
         raise ValueError(f"unknown CIGAR operation in: {cigar[:40]}")
-    return ops
+    return [(op, int(n)) for n, op in _CIGAR_ITEM.findall(cigar)]
 
 
 def cigar_counts(cigar):
     """(matches, alignment block length) of an --eqx CIGAR."""
-    n_match = sum(int(n) for n, op in re.findall(r"(\d+)([=XID])", cigar) if op == "=")
-    block = sum(int(n) for n, op in re.findall(r"(\d+)([=XID])", cigar))
+    n_match = block = 0
+    for op, n in cigar_ops(cigar):
+        if op == "=":
+            n_match += n
+            block += n
+        elif op in "XID":
+            block += n
     return n_match, block
 
 
