@@ -369,20 +369,38 @@ def output_phased_fastq(in_fastq_file, readinfo_dict, num_alleles, out_prefix):
             f.close()
 
 
-def split_allele_using_gmm_1d(repeat_region, ploidy, error_rate, max_mutual_overlap, max_num_components,
-                              remove_noisy_reads, seed=None):
-    """Drop-in for nanoRepeat_bam.split_allele_using_gmm_1d (nanoRepeat_bam.py:517-574) minus the
-    plots: fills `repeat_region.results`, writes `<out_prefix>.phased_reads.txt`, `.summary.txt`
-    (unless `no_details`) and `.alleleN.fastq` (when `region_fq_file` is set).  Returns the allele
-    list, or None when fewer than 2 reads have a size."""
-    if ploidy < 1:
-        raise ValueError("ploidy must be >= 1")
-    count_dict = {name: r.round3_repeat_size for name, r in repeat_region.read_dict.items()
-                  if r.round3_repeat_size is not None}
+def region_count_dict(repeat_region):
+    """{read: round-3 size} of the reads of a region that have one (nanoRepeat_bam.py:527-530)."""
+    return {name: r.round3_repeat_size for name, r in repeat_region.read_dict.items()
+            if r.round3_repeat_size is not None}
+
+
+def phase_1d_job(args):
+    """The mixture fit of one region without the region object (picklable in, picklable out): what
+    `pipeline.phase_regions` hands to its worker processes.  Returns (alleles, num_removed) or None."""
+    count_dict, ploidy, error_rate, max_mutual_overlap, max_num_components, remove_noisy_reads, seed = args
     if len(count_dict) < 2:
         return None
     alleles, num_removed, _ = phase(count_dict, 1, ploidy, error_rate, max_mutual_overlap,
                                     max_num_components, remove_noisy_reads, seed)
+    return alleles, num_removed
+
+
+def split_allele_using_gmm_1d(repeat_region, ploidy, error_rate, max_mutual_overlap, max_num_components,
+                              remove_noisy_reads, seed=None, fitted=None):
+    """Drop-in for nanoRepeat_bam.split_allele_using_gmm_1d (nanoRepeat_bam.py:517-574) minus the
+    plots: fills `repeat_region.results`, writes `<out_prefix>.phased_reads.txt`, `.summary.txt`
+    (unless `no_details`) and `.alleleN.fastq` (when `region_fq_file` is set).  Returns the allele
+    list, or None when fewer than 2 reads have a size.  `fitted` = the result of `phase_1d_job` for
+    this region when the fit was done elsewhere (a worker process)."""
+    if ploidy < 1:
+        raise ValueError("ploidy must be >= 1")
+    if fitted is None:
+        fitted = phase_1d_job((region_count_dict(repeat_region), ploidy, error_rate, max_mutual_overlap,
+                               max_num_components, remove_noisy_reads, seed))
+    if fitted is None:
+        return None
+    alleles, num_removed = fitted
     res = results_of(repeat_region)
     for label, a in enumerate(alleles):
         for i, readname in enumerate(a.readname_list):
@@ -415,21 +433,39 @@ def split_allele_using_gmm_1d(repeat_region, ploidy, error_rate, max_mutual_over
     return alleles
 
 
-def split_alleles_using_gmm_2d(ploidy, error_rate, max_mutual_overlap, remove_noisy_reads, max_num_components,
-                               repeat1, repeat2, read_repeat_joint_count_dict, num_removed_reads, in_fastq_file,
-                               out_prefix, seed=None):
-    """Drop-in for nanoRepeat_joint.split_alleles_using_gmm_2d (nanoRepeat_joint.py:699-747) minus
-    the plots.  `num_removed_reads` is accepted and ignored like in the reference (it is reset to
-    0 before use).  Returns the allele list or None (too few reads)."""
-    if ploidy < 1:
-        raise ValueError("ploidy must be >= 1")
-    if len(read_repeat_joint_count_dict) < ploidy or len(read_repeat_joint_count_dict) == 1:
+def phase_2d_job(args):
+    """The 2D mixture fit as a picklable job (see phase_1d_job): (alleles, components of the final
+    mixture) or None."""
+    count_dict, ploidy, error_rate, max_mutual_overlap, max_num_components, remove_noisy_reads, seed = args
+    if len(count_dict) < ploidy or len(count_dict) == 1:
         return None
-    got = phase(read_repeat_joint_count_dict, 2, ploidy, error_rate, max_mutual_overlap, max_num_components,
-                remove_noisy_reads, seed)
+    got = phase(count_dict, 2, ploidy, error_rate, max_mutual_overlap, max_num_components, remove_noisy_reads, seed)
     if got is None:
         return None
-    alleles, _, gmm = got
+    return got[0], int(got[2].n_components)
+
+
+def run_job(job):
+    """("1d" | "2d", args) -> result: the unit of work of the worker processes."""
+    kind, args = job
+    return phase_1d_job(args) if kind == "1d" else phase_2d_job(args)
+
+
+def split_alleles_using_gmm_2d(ploidy, error_rate, max_mutual_overlap, remove_noisy_reads, max_num_components,
+                               repeat1, repeat2, read_repeat_joint_count_dict, num_removed_reads, in_fastq_file,
+                               out_prefix, seed=None, fitted=None):
+    """Drop-in for nanoRepeat_joint.split_alleles_using_gmm_2d (nanoRepeat_joint.py:699-747) minus
+    the plots.  `num_removed_reads` is accepted and ignored like in the reference (it is reset to
+    0 before use).  Returns the allele list or None (too few reads).  `fitted` = the result of
+    `phase_2d_job` when the fit was done elsewhere (a worker process)."""
+    if ploidy < 1:
+        raise ValueError("ploidy must be >= 1")
+    if fitted is None:
+        fitted = phase_2d_job((read_repeat_joint_count_dict, ploidy, error_rate, max_mutual_overlap,
+                               max_num_components, remove_noisy_reads, seed))
+    if fitted is None:
+        return None
+    alleles, n_components = fitted
     id1, id2 = repeat1.repeat_id, repeat2.repeat_id
     header = (f"##Input_FASTQ={in_fastq_file}\n"
               f"#Read_Name\tAllele_ID\tPhasing_Confidence\t{id1}.Repeat_Size\t{id2}.Repeat_Size\n")
@@ -438,7 +474,7 @@ def split_alleles_using_gmm_2d(ploidy, error_rate, max_mutual_overlap, remove_no
     if in_fastq_file and os.path.exists(in_fastq_file):
         # one file per mixture component, also for components that ended up without reads
         output_phased_fastq(in_fastq_file, create_readinfo_dict_from_allele_list(alleles, 2),
-                            max(gmm.n_components, len(alleles)), out_prefix)
+                            max(n_components, len(alleles)), out_prefix)
     text = f"Input_FASTQ\t{in_fastq_file}\nMethod\t2D-GMM\nNum_Alleles\t{len(alleles)}\nNum_Removed_Reads\t0\n"
     for label, a in enumerate(alleles):
         text += (f"Allele{label + 1}_Num_Reads\t{a.num_reads}\n"

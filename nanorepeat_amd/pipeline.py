@@ -20,17 +20,56 @@ def quantify_regions(repeat_regions, reads_by_region, data_type="ont", fast_mode
     return [round3.output_repeat_size_1d(region) for region in repeat_regions]
 
 
+def _fit_in_worker_processes(jobs, n_jobs):
+    """phasing.run_job over `jobs` in n_jobs fresh interpreters (`python -m
+    nanorepeat_amd._phase_worker`): they get only the sizes, never import the caller's main module
+    and never open the GPU."""
+    import os, pickle, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ)
+    env["PYTHONPATH"] = root + os.pathsep + env.get("PYTHONPATH", "")
+    shares = [list(range(w, len(jobs), n_jobs)) for w in range(n_jobs)]
+    procs = []
+    for share in shares:
+        p = subprocess.Popen([sys.executable, "-m", "nanorepeat_amd._phase_worker"], stdin=subprocess.PIPE,
+                             stdout=subprocess.PIPE, env=env)
+        p.stdin.write(pickle.dumps([jobs[i] for i in share]))
+        p.stdin.close()
+        procs.append(p)
+    fitted = [None] * len(jobs)
+    for share, p in zip(shares, procs):
+        data = p.stdout.read()
+        if p.wait() != 0:
+            raise RuntimeError("a phasing worker process failed")
+        for i, res in zip(share, pickle.loads(data)):
+            fitted[i] = res
+    return fitted
+
+
 def phase_regions(repeat_regions, data_type="ont", ploidy=2, max_mutual_overlap=0.15, max_num_components=-1,
-                  remove_noisy_reads=False, seed=None, out_tsv_file=None):
+                  remove_noisy_reads=False, seed=None, out_tsv_file=None, n_jobs=None):
     """Step 4 for every region (nanoRepeat_bam.py:683-684) and the final table (:737-743); defaults
-    are the CLI's (nanoRepeat.py:121-129,159-160).  With a seed, region i uses seed + i."""
+    are the CLI's (nanoRepeat.py:121-129,159-160).  With a seed, region i uses seed + i.  The mixture
+    fits -- by far the longest step of the whole command -- run in up to 16 worker processes like
+    the reference's region workers (nanoRepeat_bam.py:712-724); the workers are fresh interpreters
+    that get only the sizes and never touch the GPU.  n_jobs=1 keeps everything in this process."""
+    import os
     if max_num_components == -1:
         max_num_components = ploidy + 20
     error_rate = phasing.data_type_error_rate(data_type)
+    jobs = [(phasing.region_count_dict(region), ploidy, error_rate, max_mutual_overlap, max_num_components,
+             remove_noisy_reads, None if seed is None else seed + i) for i, region in enumerate(repeat_regions)]
+    if n_jobs is None:
+        n_jobs = min(16, os.cpu_count() or 1, max(1, sum(len(j[0]) >= 2 for j in jobs)))
+    if n_jobs > 1:
+        fitted = _fit_in_worker_processes([("1d", j) for j in jobs], n_jobs)
+    else:
+        fitted = [phasing.phase_1d_job(j) for j in jobs]
     rows = []
-    for i, region in enumerate(repeat_regions):
-        phasing.split_allele_using_gmm_1d(region, ploidy, error_rate, max_mutual_overlap, max_num_components,
-                                          remove_noisy_reads, None if seed is None else seed + i)
+    for region, job, fit in zip(repeat_regions, jobs, fitted):
+        if fit is not None:
+            phasing.split_allele_using_gmm_1d(region, ploidy, error_rate, max_mutual_overlap, max_num_components,
+                                              remove_noisy_reads, fitted=fit)
         rows.append(phasing.final_output_row(region))
     if out_tsv_file:
         with open(out_tsv_file, "w") as f:
@@ -40,7 +79,7 @@ def phase_regions(repeat_regions, data_type="ont", ploidy=2, max_mutual_overlap=
 
 def quantify_joint(in_fq, ref_fasta, repeat1_string, repeat2_string, out_prefix, data_type="ont", num_threads=1,
                    ploidy=2, error_rate=0.1, max_mutual_overlap=0.1, remove_noisy_reads=False,
-                   max_num_components=-1, device=0, scoring=None, seed=None, **engines):
+                   max_num_components=-1, device=0, scoring=None, seed=None, phase_in_worker=True, **engines):
     """The joint (2D) command from files to files (nanoRepeat_joint.py:160-232): round 1 ->
     grid rounds 2/3 -> `<out_prefix>.repeat_size.txt` -> 2D GMM phasing -> `.phased_reads.txt`,
     `.summary.txt`, `.alleleN.fastq`.  `engines` may carry aligner / cigar_aligner / scorer
@@ -71,9 +110,13 @@ def quantify_joint(in_fq, ref_fasta, repeat1_string, repeat2_string, out_prefix,
     joint_counts, _ = joint.output_repeat_size_2d(in_fq, repeat1.repeat_id, repeat2.repeat_id, out_prefix,
                                                   final_estimation.repeat1_count_dict,
                                                   final_estimation.repeat2_count_dict)
+    # the fit runs in a fresh single-threaded interpreter: scikit-learn's small-matrix algebra is several
+    # times slower with this process's BLAS/OpenMP thread pools (split_alleles.py:28-32 pins them to 1)
+    job = ("2d", (joint_counts, ploidy, error_rate, max_mutual_overlap, max_num_components, remove_noisy_reads, seed))
+    fitted = _fit_in_worker_processes([job], 1)[0] if phase_in_worker else None
     alleles = phasing.split_alleles_using_gmm_2d(ploidy, error_rate, max_mutual_overlap, remove_noisy_reads,
                                                  max_num_components, repeat1, repeat2, joint_counts, 0, in_fq,
-                                                 out_prefix, seed=seed)
+                                                 out_prefix, seed=seed, fitted=fitted)
     return final_estimation, alleles
 
 

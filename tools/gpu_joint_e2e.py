@@ -22,7 +22,10 @@ a = J.Repeat().init_from_string(r1); b = J.Repeat().init_from_string(r2); a.max_
 t0 = time.time(); init = J.initial_estimate_repeat_size(chrom, fq, "ont", 1, a, b, 1000); t["round1"] = time.time() - t0
 t0 = time.time(); fin = J.fine_tune_read_count(init, fq, chrom, a, b, "ont"); t["rounds_2_3"] = time.time() - t0
 t0 = time.time(); counts, _ = J.output_repeat_size_2d("reads.fastq", a.repeat_id, b.repeat_id, os.path.join(tmp, "out"), fin.repeat1_count_dict, fin.repeat2_count_dict); t["repeat_size_txt"] = time.time() - t0
-t0 = time.time(); alleles = phasing.split_alleles_using_gmm_2d(2, 0.1, 0.1, False, 22, a, b, counts, 0, os.path.join(tmp, "reads.fastq"), os.path.join(tmp, "out"), seed=1); t["gmm_phasing"] = time.time() - t0
+t0 = time.time()
+fitted = pipeline._fit_in_worker_processes([("2d", (counts, 2, 0.1, 0.1, 22, False, 1))], 1)[0]      # what quantify_joint does
+alleles = phasing.split_alleles_using_gmm_2d(2, 0.1, 0.1, False, 22, a, b, counts, 0, os.path.join(tmp, "reads.fastq"), os.path.join(tmp, "out"), fitted=fitted)
+t["gmm_phasing"] = time.time() - t0
 k1 = np.array([fin.repeat1_count_dict.get(f"r{i}", -1) for i in range(n)])
 print(json.dumps({"reads": n, "reads_with_round1_ranges": len(init.repeat1_count_range_dict), "seconds": {k: round(v, 3) for k, v in t.items()},
                   "k1_within1": float(np.mean(np.abs(k1 - j["truth"][:, 0]) <= 1)),
