@@ -8,14 +8,14 @@ from . import upstream, round3, phasing, joint, io as nr_io
 def quantify_regions(repeat_regions, reads_by_region, data_type="ont", fast_mode=False, num_cpu=1,
                      device=0, scoring=None, aligner=None, scorer=None):
     """repeat_regions: RepeatRegion objects with anchors set (io.extract_ref_sequence);
-    reads_by_region: one {read_name: sequence} dict per region.  Steps 1-2 run per region (their
-    alignments are few and long); step 3 -- the hot path -- runs for all regions in one batch."""
+    reads_by_region: one {read_name: sequence} dict per region.  Every step runs for all regions in
+    one C-ABI call (per ~256 M bases): a call costs a few milliseconds however small it is."""
+    upstream.find_anchor_locations_in_reads_many(data_type, repeat_regions, reads_by_region, num_cpu, device=device,
+                                                 scoring=scoring, aligner=aligner)
     for region, reads in zip(repeat_regions, reads_by_region):
-        upstream.find_anchor_locations_in_reads(data_type, region, num_cpu, region_reads=reads, device=device,
-                                                scoring=scoring, aligner=aligner)
         upstream.make_core_seq(region, reads)
-        upstream.round1_and_round2_estimation(data_type, region, num_cpu, device=device, scoring=scoring,
-                                              aligner=aligner)
+    upstream.round1_and_round2_estimation_many(data_type, repeat_regions, num_cpu, device=device, scoring=scoring,
+                                               aligner=aligner)
     round3.round3_estimation_regions(data_type, fast_mode, repeat_regions, num_cpu, device, scoring, scorer)
     return [round3.output_repeat_size_1d(region) for region in repeat_regions]
 

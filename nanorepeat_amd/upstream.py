@@ -152,3 +152,105 @@ def round1_and_round2_estimation(data_type, repeat_region, num_cpu=1, device=0, 
         ts, te = int(out["tstart"][i]), int(out["tend"][i])
         if ts <= len(left) and te >= len(left):                              # :371
             repeat_region.read_dict[n].round2_repeat_size = float(te - len(left)) / len(unit)
+
+
+# ---------------------------------------------------------------------------------------------
+# many regions per aligner call (a call costs a few milliseconds however small it is)
+# ---------------------------------------------------------------------------------------------
+MAX_BASES_PER_CALL = 1 << 28
+
+
+def _chunks_by_bases(sizes, limit):
+    """Consecutive index ranges whose sizes add up to at most `limit` (at least one item each)."""
+    out, lo, acc = [], 0, 0
+    for i, sz in enumerate(sizes):
+        if i > lo and acc + sz > limit:
+            out.append((lo, i)); lo, acc = i, 0
+        acc += sz
+    if lo < len(sizes):
+        out.append((lo, len(sizes)))
+    return out
+
+
+def find_anchor_locations_in_reads_many(data_type, repeat_regions, reads_by_region, num_cpu=1, device=0,
+                                        scoring=None, aligner=None, max_bases=MAX_BASES_PER_CALL):
+    """find_anchor_locations_in_reads for many regions with ONE aligner call per ~256 M bases:
+    same pairs, same per-read rule, one set of device buffers instead of one per region."""
+    aligner = aligner or _capi.align_pairs
+    sizes = [2 * sum(len(s) for s in reads.values()) for reads in reads_by_region]
+    for lo, hi in _chunks_by_bases(sizes, max_bases):
+        seqs, pq, pt, where = [], [], [], []
+        for g in range(lo, hi):
+            region, reads = repeat_regions[g], reads_by_region[g]
+            base = len(seqs)
+            seqs += [region.left_anchor_seq, region.right_anchor_seq]
+            where.append((g, len(pq), list(reads)))
+            for i, n in enumerate(reads):
+                s = reads[n].strip()
+                seqs += [s, rev_comp(s)]
+                for a in (0, 1):
+                    for o in (0, 1):
+                        pq.append(base + a); pt.append(base + 2 + 2 * i + o)
+        if not pq:
+            continue
+        out = aligner(seqs, np.array(pq, np.int32), np.array(pt, np.int32), sc=scoring, device=device)
+        for g, p0, names in where:
+            region, reads = repeat_regions[g], reads_by_region[g]
+            for i, n in enumerate(names):
+                recs = []
+                qlen = len(reads[n].strip())
+                for a, tname in ((0, "left_anchor"), (1, "right_anchor")):
+                    for o, strand in ((0, "+"), (1, "-")):
+                        j = p0 + 4 * i + 2 * a + o
+                        if out["score"][j] < 0:
+                            continue
+                        ts, te = int(out["tstart"][j]), int(out["tend"][j])
+                        recs.append(AnchorHit(n, qlen, ts, te, strand, tname, int(out["score"][j]), te - ts))
+                find_anchor_locations_for1read(recs, region)
+
+
+def round1_and_round2_estimation_many(data_type, repeat_regions, num_cpu=1, device=0, scoring=None, aligner=None,
+                                      max_bases=MAX_BASES_PER_CALL):
+    """round1_and_round2_estimation for many regions with one aligner call per ~256 M bases."""
+    aligner = aligner or _capi.align_pairs
+    plans = []
+    for region in repeat_regions:
+        if len(region.read_dict) == 0:
+            plans.append(None)
+            continue
+        unit = region.repeat_unit_seq
+        round1 = []
+        for read in region.read_dict.values():
+            read.round1_repeat_size = float(read.dist_between_anchors) / len(unit)
+            round1.append(read.round1_repeat_size)
+        template_repeat_size = int(max(round1) * 1.5) + 1
+        if template_repeat_size < max(round1) + 10:
+            template_repeat_size = int(max(round1) + 10)
+        names = [n for n in region.read_dict if n in region.read_core_seq_dict]
+        plans.append((region.left_anchor_seq + unit * template_repeat_size, names))
+    sizes = [0 if p is None else len(p[0]) + sum(len(repeat_regions[g].read_core_seq_dict[n]) for n in p[1])
+             for g, p in enumerate(plans)]
+    for lo, hi in _chunks_by_bases(sizes, max_bases):
+        seqs, pq, pt, where = [], [], [], []
+        for g in range(lo, hi):
+            if plans[g] is None:
+                continue
+            template, names = plans[g]
+            base = len(seqs)
+            seqs.append(template)
+            seqs += [repeat_regions[g].read_core_seq_dict[n] for n in names]
+            where.append((g, len(pq), names))
+            pq += list(range(base + 1, base + 1 + len(names))); pt += [base] * len(names)
+        if not pq:
+            continue
+        out = aligner(seqs, np.array(pq, np.int32), np.array(pt, np.int32), sc=scoring, device=device)
+        for g, p0, names in where:
+            region = repeat_regions[g]
+            left_len, unit_len = len(region.left_anchor_seq), len(region.repeat_unit_seq)
+            for i, n in enumerate(names):
+                j = p0 + i
+                if out["score"][j] < 0:
+                    continue
+                ts, te = int(out["tstart"][j]), int(out["tend"][j])
+                if ts <= left_len and te >= left_len:                            # :371
+                    region.read_dict[n].round2_repeat_size = float(te - left_len) / unit_len

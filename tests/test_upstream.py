@@ -131,3 +131,42 @@ def test_round3_keeps_round2_size_for_cores_beyond_the_kernel_limits(oracle):
     R3.round3_estimation("ont", False, rr, 1, scorer=oracle.round3_1d)
     assert rr.read_dict["ok"].round3_repeat_size == 20.0 and rr.read_dict["ok"].round3_status == 0
     assert rr.read_dict["huge"].round3_repeat_size == 2700.0 and rr.read_dict["huge"].round3_status == R3.READ_TOO_LONG
+
+
+def test_many_region_calls_equal_per_region_calls(oracle):
+    """find_anchor_locations_in_reads_many / round1_and_round2_estimation_many (one aligner call for
+    all regions, chunked by bases) leave every region exactly as the per-region functions do."""
+    import copy
+    from nanorepeat_amd import round3 as R3, synth
+    rng = np.random.default_rng(17)
+    regions, reads_by_region = [], []
+    for g, unit in enumerate(("CAG", "TATTG", "AT", "GGCCCC")):
+        left, right = synth.rand_seq(rng, 400), synth.rand_seq(rng, 400)
+        rr = R3.RepeatRegion(f"chr2\t{1000 * g}\t{1000 * g + 30}\t{unit}")
+        rr.left_anchor_seq, rr.right_anchor_seq, rr.left_anchor_len, rr.right_anchor_len = left, right, 400, 400
+        reads = {}
+        for i in range(0 if g == 2 else 7):                       # one region without reads
+            k = (9, 24)[i % 2]
+            s = synth.apply_errors(rng, left[-250:] + unit * k + right[:250], "ont_q20")
+            reads[f"g{g}r{i}"] = synth.revcomp(s) if i % 3 == 1 else s
+        reads["junk%d" % g] = synth.rand_seq(rng, 300)
+        regions.append(rr); reads_by_region.append(reads)
+    one, many = copy.deepcopy(regions), copy.deepcopy(regions)
+    for rr, reads in zip(one, reads_by_region):
+        U.find_anchor_locations_in_reads("ont_q20", rr, 1, region_reads=reads, aligner=oracle.align_pairs)
+        U.make_core_seq(rr, reads)
+        U.round1_and_round2_estimation("ont_q20", rr, 1, aligner=oracle.align_pairs)
+    for limit in (U.MAX_BASES_PER_CALL, 3000):                     # 3000: a chunk per region
+        test = copy.deepcopy(many)
+        sizes = [2 * sum(len(s) for s in r.values()) for r in reads_by_region]
+        assert len(U._chunks_by_bases(sizes, limit)) == (1 if limit > 10 ** 6 else 4)
+        U.find_anchor_locations_in_reads_many("ont_q20", test, reads_by_region, aligner=oracle.align_pairs, max_bases=limit)
+        for rr, reads in zip(test, reads_by_region):
+            U.make_core_seq(rr, reads)
+        U.round1_and_round2_estimation_many("ont_q20", test, aligner=oracle.align_pairs, max_bases=limit)
+        for a, b in zip(one, test):
+            assert list(a.read_dict) == list(b.read_dict) and a.read_core_seq_dict == b.read_core_seq_dict
+            for n in a.read_dict:
+                ra, rb = a.read_dict[n], b.read_dict[n]
+                assert ((ra.round1_repeat_size, ra.round2_repeat_size, ra.strand, ra.core_seq_start_pos, ra.core_seq_end_pos) ==
+                        (rb.round1_repeat_size, rb.round2_repeat_size, rb.strand, rb.core_seq_start_pos, rb.core_seq_end_pos))
