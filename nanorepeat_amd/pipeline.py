@@ -29,13 +29,12 @@ def _fit_in_worker_processes(jobs, n_jobs):
     env = dict(os.environ)
     env["PYTHONPATH"] = root + os.pathsep + env.get("PYTHONPATH", "")
     shares = [list(range(w, len(jobs), n_jobs)) for w in range(n_jobs)]
-    procs = []
-    for share in shares:
-        p = subprocess.Popen([sys.executable, "-m", "nanorepeat_amd._phase_worker"], stdin=subprocess.PIPE,
-                             stdout=subprocess.PIPE, env=env)
+    # start every interpreter first (they import scikit-learn side by side), then hand out the work
+    procs = [subprocess.Popen([sys.executable, "-m", "nanorepeat_amd._phase_worker"], stdin=subprocess.PIPE,
+                              stdout=subprocess.PIPE, env=env) for _ in shares]
+    for share, p in zip(shares, procs):
         p.stdin.write(pickle.dumps([jobs[i] for i in share]))
         p.stdin.close()
-        procs.append(p)
     fitted = [None] * len(jobs)
     for share, p in zip(shares, procs):
         data = p.stdout.read()
