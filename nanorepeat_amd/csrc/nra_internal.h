@@ -134,8 +134,9 @@ int nra_launch_payload_window(int R, int has_n, hipStream_t st, int n_waves,
                               NraScoreParams sp,
                               int32_t* out_score, int32_t* out_p, int32_t* out_tend);
 
-// junction decomposition (nra_sweep.hip): reverse sweep writes the R-side snapshot and A_k,
-// forward sweep combines and writes Score(k) + the flank-test verdict (0 fail, 1 pass, 2 ambiguous)
+// junction decomposition (nra_sweep.hip): the reverse sweep writes the R-side snapshot and A (per read:
+// read_a, origin-bit scheme) or A_k (per candidate: arr_a, chained reads); the forward sweep combines and
+// writes Score(k) + the flank-test verdict (0 fail, 1 pass, 2 ambiguous)
 int nra_launch_sweep_bwd(int R, int has_n, int chain, hipStream_t st, int n_tasks, const NraSweepTask* tasks,
                          const NraDevRead* reads, const NraDevRegion* regions, const uint8_t* pool,
                          const uint32_t* q2bit, const uint32_t* qnmask, NraScoreParams sp,
