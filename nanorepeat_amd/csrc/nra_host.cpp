@@ -266,8 +266,11 @@ void fold_small_buckets(std::vector<std::vector<int32_t>>& by_bucket, size_t min
     }
 }
 
-// executed cells of one wave sweep: 64*R rows x (ceil((tlen+63)/64)*64) columns
+// executed cells of one wave sweep with 64 cells in flight (k_score_pk16, payload, joint kernels):
+// 64*R rows x (ceil((tlen+63)/64)*64) columns
 int64_t sweep_cells(int R, int tlen) { return (int64_t)64 * R * (((int64_t)tlen + 126) / 64 * 64); }
+// k_sweep_pk16: two virtual cells per lane, 128 in flight, the step loop stops with the last column
+int64_t sweep128_cells(int R, int ncols) { return (int64_t)64 * R * ((int64_t)ncols + 127); }
 
 }  // namespace
 
@@ -289,7 +292,7 @@ struct nra_batch {
     DevBuf<NraDevRead> reads, reads_init;
     DevBuf<NraPairTask> pair_tasks;
     DevBuf<NraSweepTask> sweep_tasks;
-    DevBuf<int16_t> snap_h, snap_e, snap_e2;   // R side of the junction, one entry per read base
+    DevBuf<int32_t> snap;                      // R side of the junction: per sweep task 3 planes of R x 64 (both reads packed)
     DevBuf<int32_t> arr_a;                     // A_k per candidate (chained reads only)
     DevBuf<int32_t> read_a1d;                  // A per read: best alignment inside R (origin-bit scheme)
     DevBuf<uint8_t> cand_flag;                 // flank verdict per candidate
@@ -553,6 +556,9 @@ int nra_batch1d_create(int device, const nra_region_t* regions, int32_t n_region
         // (doubled: the low bit of every state is the origin bit)
         const int o1 = sc->gap_open1 + sc->gap_ext1;
         if (o1 < sc->mismatch || o1 < sc->sc_ambi || 2 * (sc->match + o1) > 127) brute = true;
+        // and every state in [0x0400, 0x7bff] (nra_sweep.hip: bias 4096, "minus infinity" 1280)
+        const int o2 = sc->gap_open2 + sc->gap_ext2;
+        if (2 * sc->gap_ext1 > 256 || 2 * sc->gap_ext2 > 256 || 2 * o2 > 2048) brute = true;
     }
     for (int32_t r = 0; r < n_reads; ++r) {       // unusual scoring: do the scores fit the 16-bit cells?
         if (kmin[r] > kmax[r]) continue;
@@ -564,6 +570,7 @@ int nra_batch1d_create(int device, const nra_region_t* regions, int32_t n_region
     }
     b->brute = brute;
     std::vector<NraSweepTask> sweep_tasks;
+    uint64_t snap_total = 0;
     // bucket kNumR = reads longer than one register block (or every read with NRA_F_TEST_CHAIN)
     std::vector<std::vector<int32_t>> by_bucket((size_t)kNumR + 1);
     const bool test_chain = (flags & NRA_F_TEST_CHAIN) != 0;
@@ -649,8 +656,10 @@ int nra_batch1d_create(int device, const nra_region_t* regions, int32_t n_region
                 if (t.read_b >= 0) qmax = std::max(qmax, pr.reads[t.read_b].qlen);
                 const int nblk = bk.chain ? (qmax + 64 * bk.R - 1) / (64 * bk.R) : 1;
                 // chained reads sweep rev(unit)^kmax for A_k; the others stop at the end of rev(R)
-                bk.cells_sweep += (int64_t)nblk * 2 * (sweep_cells(bk.R, d.l1 + d.m1 * t.kmax + 64) +
-                                                       sweep_cells(bk.R, d.l3 + (bk.chain ? d.m1 * t.kmax : 0) + 64));
+                bk.cells_sweep += (int64_t)nblk * 2 * (sweep128_cells(bk.R, d.l1 + d.m1 * t.kmax) +
+                                                       sweep128_cells(bk.R, d.l3 + (bk.chain ? d.m1 * t.kmax : 0)));
+                t.snap_off = snap_total;
+                snap_total += (uint64_t)nblk * 3 * bk.R * 64;
                 sweep_tasks.push_back(t);
             }
             bk.n_sweep = (int)(sweep_tasks.size() - bk.sweep_off);
@@ -666,7 +675,7 @@ int nra_batch1d_create(int device, const nra_region_t* regions, int32_t n_region
     clk.mark("templates, buckets, tasks");
 
     // one chunk for everything: ~7 B per read base, ~40 B per candidate, the tasks, the chain strips
-    b->arena.expect(pr.q2bit.size() * 16 * 8 + (size_t)total * 40 + pool.size() + sweep_tasks.size() * 16 +
+    b->arena.expect(pr.q2bit.size() * 16 * 2 + (size_t)snap_total * 4 + (size_t)total * 40 + pool.size() + sweep_tasks.size() * sizeof(NraSweepTask) +
                     pair_tasks.size() * sizeof(NraPairTask) + (size_t)n_reads * 64 + (4u << 20));
     HIP_TRY(b->pool.upload(pool));
     HIP_TRY(b->q2bit.upload(pr.q2bit));
@@ -676,10 +685,7 @@ int nra_batch1d_create(int device, const nra_region_t* regions, int32_t n_region
     HIP_TRY(b->pair_tasks.upload(pair_tasks));
     HIP_TRY(b->sweep_tasks.upload(sweep_tasks));
     if (!brute) {
-        const size_t nbases = pr.q2bit.size() * 16;
-        HIP_TRY(b->snap_h.alloc(nbases));
-        HIP_TRY(b->snap_e.alloc(nbases));
-        HIP_TRY(b->snap_e2.alloc(nbases));
+        HIP_TRY(b->snap.alloc((size_t)snap_total));
         HIP_TRY(b->arr_a.alloc(by_bucket[kNumR].empty() ? 1 : (size_t)total));   // A_k: chained reads only
         HIP_TRY(b->read_a1d.alloc((size_t)n_reads));
     }
@@ -758,14 +764,14 @@ static int run_1d(nra_batch* b)
             HIP_TRY(hipEventRecord(b->ev[ev++], q));
             LAUNCH_TRY(nra_launch_sweep_bwd(bk.R, b->has_n, bk.chain ? 1 : 0, q, bk.n_sweep, b->sweep_tasks.p + bk.sweep_off,
                                             b->reads.p, b->regions.p, b->pool.p, b->q2bit.p, b->qnmask.p, b->sp,
-                                            b->kmin.p, b->kmax.p, b->coff.p, b->snap_h.p, b->snap_e.p,
-                                            b->snap_e2.p, b->arr_a.p, b->read_a1d.p, b->chain_sweep.p, b->chain_cap));
+                                            b->kmin.p, b->kmax.p, b->coff.p, b->snap.p,
+                                            b->arr_a.p, b->read_a1d.p, b->chain_sweep.p, b->chain_cap));
             HIP_TRY(hipEventRecord(b->ev[ev++], q));
             HIP_TRY(hipEventRecord(b->ev[ev++], q));
             LAUNCH_TRY(nra_launch_sweep_fwd(bk.R, b->has_n, bk.chain ? 1 : 0, q, bk.n_sweep, b->sweep_tasks.p + bk.sweep_off,
                                             b->reads.p, b->regions.p, b->pool.p, b->q2bit.p, b->qnmask.p, b->sp,
-                                            b->kmin.p, b->kmax.p, b->coff.p, b->snap_h.p, b->snap_e.p,
-                                            b->snap_e2.p, b->arr_a.p, b->read_a1d.p, b->cand_score.p, b->cand_flag.p,
+                                            b->kmin.p, b->kmax.p, b->coff.p, b->snap.p,
+                                            b->arr_a.p, b->read_a1d.p, b->cand_score.p, b->cand_flag.p,
                                             b->chain_sweep.p, b->chain_cap));
             HIP_TRY(hipEventRecord(b->ev[ev++], q));
             b->n_score_ev += 2;

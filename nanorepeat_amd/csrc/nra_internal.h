@@ -46,6 +46,7 @@ struct NraPairTask {
 struct NraSweepTask {
     int32_t read_a, read_b;   // read_b < 0: no second read
     int32_t kmin, kmax;
+    uint64_t snap_off;        // the task's R-side snapshot (int32 index): 3 planes of R x 64 per row block
 };
 
 // Tasks of the joint sweeps (nra_joint.hip).
@@ -141,13 +142,13 @@ int nra_launch_sweep_bwd(int R, int has_n, int chain, hipStream_t st, int n_task
                          const NraDevRead* reads, const NraDevRegion* regions, const uint8_t* pool,
                          const uint32_t* q2bit, const uint32_t* qnmask, NraScoreParams sp,
                          const int32_t* kmin, const int32_t* kmax, const uint32_t* coff,
-                         int16_t* snap_h, int16_t* snap_e, int16_t* snap_e2, int32_t* arr_a,
+                         int32_t* snap, int32_t* arr_a,
                          int32_t* read_a, int32_t* chain_buf, int chain_cap);
 int nra_launch_sweep_fwd(int R, int has_n, int chain, hipStream_t st, int n_tasks, const NraSweepTask* tasks,
                          const NraDevRead* reads, const NraDevRegion* regions, const uint8_t* pool,
                          const uint32_t* q2bit, const uint32_t* qnmask, NraScoreParams sp,
                          const int32_t* kmin, const int32_t* kmax, const uint32_t* coff,
-                         int16_t* snap_h, int16_t* snap_e, int16_t* snap_e2, int32_t* arr_a,
+                         int32_t* snap, int32_t* arr_a,
                          int32_t* read_a, int32_t* cand_score, uint8_t* cand_flag, int32_t* chain_buf,
                          int chain_cap);
 

@@ -50,22 +50,35 @@
 #endif
 #define NRA_HAS_PART(n) (NRA_PART == 0 || NRA_PART == (n))
 
-// Registers hold (value + BIAS) in both int16 halves, so that every add/subtract of a small
-// constant or of another biased value is carry-safe as ONE full-rate 32-bit v_add/v_sub_u32
-// (2 cycles per wave) instead of a half-rate VOP3P v_pk_add/sub_i16 (4 cycles); only the
-// maxima need the packed op.  The substitution score is one v_perm_b32 through a 4-entry
-// byte table that travels with the template base.  (Issue rates: profiles/r01_valu_ubench_*.)
-#define BIAS 8192
-#define NEGB 1024                     // biased "minus infinity" (value -7168): below any real state (>= -1100),
-                                      // survives a subtraction of any gap constant, and two of them still fit
+// Registers hold (value + BIAS) in both int16 halves and every state stays inside [0x0400, 0x7bff]: there
+// the bit pattern read as an f16 is a positive normal number whose order is the integer order, so
+// gfx950's 3-input v_pk_maximum3_f16 is a packed 3-input INTEGER max (checked on hardware together
+// with its issue cost: tools/ubench/valu_max3.hip, profiles/r02_valu_max3.txt) -- the 5-way max of a
+// cell is two instructions instead of four.  Being non-negative, the halves never carry into each
+// other, so adding or subtracting a small constant or another biased value is a plain 32-bit
+// v_add/v_sub_u32.  The substitution score is one v_perm_b32 through a 4-entry byte table that travels
+// with the template base.
+//   range: one bias 4096 + doubled score <= 16000 -> 20096; the junction combine adds two biased
+//   values -> <= 24192 < 0x7bff; the smallest real state is 4096 - (gap open 2 + a mismatch) ~ 4000,
+//   "minus infinity" is NEGB and survives one subtraction of a gap extension (host: nra_host.cpp
+//   sends scoring schemes that do not fit these bounds to the brute-force kernel).
+#define BIAS 4096
+#define NEGB 1280                     // biased "minus infinity": below any real state, >= 0x0400 after - ext
 #define FLAG_BOUNDARY 0x00000080      // bit 7 of table byte 0
 #define FLAG_SNAPSHOT 0x00008000      // bit 7 of table byte 1 (reverse sweep)
 #define FLAG_INREP    0x80008000      // bits 7 of table bytes 1 and 3 (forward sweep, origin bit): column >= |L|
 
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ int half_lo(int v) { return v & 0xffff; }
 __device__ __forceinline__ int half_hi(int v) { return (v >> 16) & 0xffff; }
 __device__ __forceinline__ int pack2(int lo, int hi) { return (lo & 0xffff) | (hi << 16); }
 __device__ __forceinline__ int pmaxi(int a, int b) { return as_i(pmax(as_s(a), as_s(b))); }
+// packed 3-input max of values in [0x0400, 0x7bff]: one v_pk_maximum3_f16
+__device__ __forceinline__ int pmax3(int a, int b, int c)
+{
+    const f16x2 x = __builtin_bit_cast(f16x2, a), y = __builtin_bit_cast(f16x2, b), z = __builtin_bit_cast(f16x2, c);
+    return __builtin_bit_cast(int, __builtin_elementwise_maximum(__builtin_elementwise_maximum(x, y), z));
+}
 
 // selector byte of one query row for v_perm_b32: 0..3 base, 4 padding row, 5 N
 template <bool HAS_N>
@@ -92,6 +105,7 @@ __device__ __forceinline__ void sweep_cell(int (&Hq)[R], int (&Hq2)[R], int (&E)
 {
     if (N == 0) return;
     int d = pmaxi(diag, v_floor) + (int)__builtin_amdgcn_perm(tbl_hi, tbl, qc[OFF]);
+    int h_prev = 0;
 #pragma unroll
     for (int n = 0; n < N; ++n) {
         const int i = OFF + n;
@@ -100,8 +114,10 @@ __device__ __forceinline__ void sweep_cell(int (&Hq)[R], int (&Hq2)[R], int (&E)
             d_next = pmaxi(Hq[i], v_floor) + (int)__builtin_amdgcn_perm(tbl_hi, tbl, qc[i + 1]);
         const int ein = pmaxi(E[i] - v_e1, Hq[i]);            // E(i,j) from column j-1, lazily
         const int e2in = pmaxi(E2[i] - v_e2, Hq2[i]);
-        const int h = pmaxi(pmaxi(d, ein), pmaxi(F, pmaxi(e2in, F2)));   // H(i,j)
-        M = pmaxi(M, h);
+        const int h = pmax3(pmax3(d, ein, F), e2in, F2);      // H(i,j)
+        if (n & 1) M = pmax3(M, h_prev, h);                   // running maximum, two rows per instruction
+        else if (n == N - 1) M = pmaxi(M, h);
+        else h_prev = h;
         E[i] = ein;
         E2[i] = e2in;
         const int hq = h - v_o1;               // stored instead of H: feeds E, F and the diagonal
@@ -114,43 +130,44 @@ __device__ __forceinline__ void sweep_cell(int (&Hq)[R], int (&Hq2)[R], int (&E)
     }
 }
 
-// junction combine of one cell's rows at a boundary column (values biased twice)
+// junction combine of one cell's rows at a boundary column (values biased twice).  The forward H is
+// taken as it is, not as max(H, 0): a term with H < 0 is below Hb alone, an alignment inside R, and
+// that is in the final maximum anyway (A, or A_k for chained reads).
 template <int OFF, int N, int R>
 __device__ __forceinline__ int sweep_combine(const int (&Hq)[R], const int (&E)[R], const int (&E2)[R],
                                              const int (&Hbo)[R], const int (&Ebo)[R],
-                                             const int (&E2bo)[R], int v_floor, int tS)
+                                             const int (&E2bo)[R], int tS)
 {
+    int t3_prev = 0;
 #pragma unroll
     for (int n = 0; n < N; ++n) {
         const int i = OFF + n;
-        const int t1 = pmaxi(Hq[i], v_floor) + Hbo[i];
+        const int t1 = Hq[i] + Hbo[i];
         const int t2 = E[i] + Ebo[i];
         const int t3 = E2[i] + E2bo[i];
-        tS = pmaxi(pmaxi(tS, t1), pmaxi(t2, t3));
+        tS = pmax3(tS, t1, t2);
+        if (n & 1) tS = pmax3(tS, t3_prev, t3);
+        else if (n == N - 1) tS = pmaxi(tS, t3);
+        else t3_prev = t3;
     }
     return tS;
 }
 
+// R side of the junction, as the reverse sweep's registers hold it (both reads packed, biased):
+// per task and row block three planes [H - o1 | E_in | E2_in] of R x 64 dwords, [row of the lane][lane],
+// so that every store of the reverse sweep and every load of the forward sweep is one coalesced line.
 template <int OFF, int N, int R>
 __device__ __forceinline__ void sweep_snapshot(const int (&Hq)[R], const int (&E)[R], const int (&E2)[R],
-                                               int row0, const NraDevRead& rda, const NraDevRead& rdb,
-                                               bool has_b, int o1, int16_t* __restrict__ snap_h,
-                                               int16_t* __restrict__ snap_e, int16_t* __restrict__ snap_e2)
+                                               int32_t* __restrict__ snap_blk, int lane)
 {
+    int32_t* p = snap_blk + lane;
+    asm volatile("" : "+v"(p));    // keeps the 3N store addresses out of the step loop's registers
 #pragma unroll
     for (int n = 0; n < N; ++n) {
         const int i = OFF + n;
-        const int a = row0 + i;
-        if (a < rda.qlen) {
-            snap_h[rda.qoff + a] = (int16_t)(half_lo(Hq[i]) + o1 - BIAS);      // H itself
-            snap_e[rda.qoff + a] = (int16_t)(half_lo(E[i]) - BIAS);
-            snap_e2[rda.qoff + a] = (int16_t)(half_lo(E2[i]) - BIAS);
-        }
-        if (has_b && a < rdb.qlen) {
-            snap_h[rdb.qoff + a] = (int16_t)(half_hi(Hq[i]) + o1 - BIAS);
-            snap_e[rdb.qoff + a] = (int16_t)(half_hi(E[i]) - BIAS);
-            snap_e2[rdb.qoff + a] = (int16_t)(half_hi(E2[i]) - BIAS);
-        }
+        p[(0 * R + i) * 64] = Hq[i];
+        p[(1 * R + i) * 64] = E[i];
+        p[(2 * R + i) * 64] = E2[i];
     }
 }
 
@@ -165,9 +182,7 @@ __global__ __launch_bounds__(WAVE) void k_sweep_pk16(int n_tasks, const NraSweep
                                                      const int32_t* __restrict__ kmin_arr,
                                                      const int32_t* __restrict__ kmax_arr,
                                                      const uint32_t* __restrict__ coff,
-                                                     int16_t* __restrict__ snap_h,
-                                                     int16_t* __restrict__ snap_e,
-                                                     int16_t* __restrict__ snap_e2,
+                                                     int32_t* __restrict__ snap,
                                                      int32_t* __restrict__ arr_a,
                                                      int32_t* __restrict__ read_a,
                                                      int32_t* __restrict__ cand_score,
@@ -193,17 +208,43 @@ __global__ __launch_bounds__(WAVE) void k_sweep_pk16(int n_tasks, const NraSweep
     const int kmin_a = kmin_arr[ra], kmax_a = kmax_arr[ra];
     const int kmin_b = kmin_arr[rb], kmax_b = kmax_arr[rb];
     const uint32_t coff_a = coff[ra], coff_b = coff[rb];
+    int32_t* __restrict__ snap_task = snap + tk.snap_off;
 
     const int o1 = SC * sp.open1, o2 = SC * sp.open2;
     const int P1 = 0x00010001;
     const int v_floor = (BIAS - o1) * P1;                   // max(H,0) - o1 (even: the origin bit is free)
-    const int v_floor1 = BIT ? v_floor | P1 : v_floor;      // the same for a path that starts at a column >= |L|
     const int v_o1 = o1 * P1, v_e1 = SC * sp.ext1 * P1, v_o2 = o2 * P1, v_e2 = SC * sp.ext2 * P1;
-    const int NEG1 = NEGB * P1, NEG2 = 2 * NEGB * P1;       // biased once / twice
+    const int NEG1 = NEGB * P1, NEG2 = 2 * NEGB * P1;       // "minus infinity", biased once / twice
     // substitution scores + o1 (the diagonal is read from Hq = H - o1): all in [0, 127]
     const int s_match = SC * sp.match + o1, s_mis = o1 - SC * sp.mismatch, s_ambi = o1 - SC * sp.ambi;
     const int tbl_hi = s_mis | (s_ambi << 8);               // selector 4: padding row, 5: N in the read
     const int tbl_mis4 = s_mis * 0x01010101, tbl_ambi4 = s_ambi * 0x01010101;
+
+    // Score(k) and the flank verdict (or A_k) leave through lane 63, one boundary column at a time.  They
+    // are collected in a lane-indexed register -- rotated one lane down per boundary, the newest value in
+    // lane 63 -- and written 64 candidates at a time, one coalesced line per read.
+    int out_a = 0, out_b = 0;
+    int n_out = 0;                                          // wave-uniform: boundaries collected
+    int kcur = tk.kmin;                                     // wave-uniform: k of the next boundary to leave
+    auto flush = [&](int n_valid) {
+        // lane l holds k = kcur - 64 + l; the oldest n_valid values sit in lanes [64 - n_valid, 64)
+        const int k = kcur - 64 + lane;
+        if (lane < 64 - n_valid) return;
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2) {
+            if (s2 == 1 && !has_b) break;
+            const int lo_k = s2 ? kmin_b : kmin_a, hi_k = s2 ? kmax_b : kmax_a;
+            if (k < lo_k || k > hi_k) continue;
+            const uint32_t idx = (s2 ? coff_b : coff_a) + (uint32_t)(k - lo_k);
+            const int v = s2 ? out_b : out_a;
+            if (DIR == 0) {
+                arr_a[idx] = v;                             // running max of the reverse sweep = A_k
+            } else {
+                cand_score[idx] = v >> 2;                   // (score << 2) | verdict; -1: below min_dp_score
+                cand_flag[idx] = (uint8_t)(v & 3);
+            }
+        }
+    };
 
     // CHAIN: reads longer than 64*R rows are swept in row blocks of 64*R, one after the other in this
     // wave; the last virtual cell of block b leaves its per-column hand-off (H, F, F2 and the two
@@ -225,7 +266,9 @@ __global__ __launch_bounds__(WAVE) void k_sweep_pk16(int n_tasks, const NraSweep
         qc[i] = ca | (0x0c << 8) | (cb << 16) | (0x0c << 24);
     }
 
-    // forward sweep: the R side of the junction, row r pairs with reverse-sweep row Q-2-r
+    // forward sweep: the R side of the junction, row r pairs with reverse-sweep row Q-2-r.  A row without
+    // a partner (the read's last row, padding rows) gets "-1": its terms stay below B_k, which holds the
+    // forward H of that very cell, so they never decide anything.
     int Hbo[DIR ? R : 1], Ebo[DIR ? R : 1], E2bo[DIR ? R : 1];
     if (DIR) {
         const int q1 = SC * (sp.open1 - sp.ext1), q2 = SC * (sp.open2 - sp.ext2);     // the refunded gap opens
@@ -235,13 +278,17 @@ __global__ __launch_bounds__(WAVE) void k_sweep_pk16(int n_tasks, const NraSweep
             int h[2], e[2], e2[2];
 #pragma unroll
             for (int s = 0; s < 2; ++s) {
-                const NraDevRead& rd = s ? rdb : rda;
-                const int a = rd.qlen - 2 - r;
+                const int a = (s ? rdb.qlen : rda.qlen) - 2 - r;
                 if (a >= 0) {
-                    h[s] = snap_h[rd.qoff + a] + o1 + BIAS;   // +o1 cancels the -o1 carried by Hq
-                    e[s] = snap_e[rd.qoff + a] + q1 + BIAS;
-                    e2[s] = snap_e2[rd.qoff + a] + q2 + BIAS;
-                } else { h[s] = NEGB; e[s] = NEGB; e2[s] = NEGB; }
+                    const int ablk = CHAIN ? a / (64 * R) : 0;
+                    const int w = a - ablk * 64 * R;
+                    const int al = w / R, ai = w - al * R;
+                    const int32_t* __restrict__ p = snap_task + ((size_t)ablk * 3 * R + ai) * 64 + al;
+                    const int vh = p[0], ve = p[R * 64], ve2 = p[2 * R * 64];
+                    h[s] = (s ? half_hi(vh) : half_lo(vh)) + 2 * o1;    // Hq carries -o1 on either side
+                    e[s] = (s ? half_hi(ve) : half_lo(ve)) + q1;
+                    e2[s] = (s ? half_hi(ve2) : half_lo(ve2)) + q2;
+                } else { h[s] = BIAS + o1 - SC; e[s] = BIAS - SC; e2[s] = BIAS - SC; }
             }
             Hbo[i] = pack2(h[0], h[1]);
             Ebo[i] = pack2(e[0], e[1]);
@@ -263,11 +310,11 @@ __global__ __launch_bounds__(WAVE) void k_sweep_pk16(int n_tasks, const NraSweep
     int HbotB = v_floor, FoutB = NEG1, F2outB = NEG1, HupB_prev = v_floor, MB = BIAS * P1;
     int accS_A = NEG2, accB_A = NEG1, accS_B = NEG2, accB_B = NEG1;
     int ttA = tbl_mis4, ttB = tbl_mis4;                   // padding column: everything mismatches
-    int kcur = tk.kmin;                                   // meaningful in lane 63 only
+    n_out = 0; kcur = tk.kmin;
 
     // One flat step loop (128 cells deep; a chunk loop around a 64-step loop costs registers: the
     // compiler keeps the row arrays twice).  Every 64 steps the lanes fetch the next 64 columns.
-    const int nsteps = ((ncols + 127 + 63) >> 6) << 6;
+    const int nsteps = ncols + 127;                       // cell 127 finishes the last column at step ncols + 126
     int feed = tbl_mis4;
     // what enters cell 0 at each column: constants for the first row block, else the strip
     int inH = v_floor, inF = NEG1, inF2 = NEG1, inS = NEG2, inB = NEG1;
@@ -327,12 +374,12 @@ __global__ __launch_bounds__(WAVE) void k_sweep_pk16(int n_tasks, const NraSweep
             ttA = ttA_new; ttB = ttB_new;
 
             const bool atA = (ttA & FLAG_BOUNDARY) != 0, atB = (ttB & FLAG_BOUNDARY) != 0;
+            const unsigned long long at_mask = __builtin_amdgcn_ballot_w64(atA || atB);
             int tSA = NEG2, tSB = NEG2;
             if constexpr (DIR != 0) {
-                if (__builtin_amdgcn_ballot_w64(atA || atB) != 0) {
-                    // a path that starts in R starts at a column >= |L|
-                    tSA = sweep_combine<0, RA, R>(Hq, E, E2, Hbo, Ebo, E2bo, v_floor1, tSA);
-                    tSB = sweep_combine<RA, RB, R>(Hq, E, E2, Hbo, Ebo, E2bo, v_floor1, tSB);
+                if (at_mask != 0) {
+                    tSA = sweep_combine<0, RA, R>(Hq, E, E2, Hbo, Ebo, E2bo, tSA);
+                    tSB = sweep_combine<RA, RB, R>(Hq, E, E2, Hbo, Ebo, E2bo, tSB);
                 }
             }
             accS_A = pmaxi(accS_Ain, tSA);
@@ -341,10 +388,9 @@ __global__ __launch_bounds__(WAVE) void k_sweep_pk16(int n_tasks, const NraSweep
             accB_B = RB > 0 ? pmaxi(accB_Bin, MB) : accB_Bin;   // an empty cell adds nothing of its own
 
             if (DIR == 0) {
-                if (ttA & FLAG_SNAPSHOT)
-                    sweep_snapshot<0, RA, R>(Hq, E, E2, row_base + lane * R, rda, rdb, has_b, o1, snap_h, snap_e, snap_e2);
-                if (ttB & FLAG_SNAPSHOT)
-                    sweep_snapshot<RA, RB, R>(Hq, E, E2, row_base + lane * R, rda, rdb, has_b, o1, snap_h, snap_e, snap_e2);
+                int32_t* __restrict__ snap_blk = snap_task + (size_t)blk * 3 * R * 64;
+                if (ttA & FLAG_SNAPSHOT) sweep_snapshot<0, RA, R>(Hq, E, E2, snap_blk, lane);
+                if (ttB & FLAG_SNAPSHOT) sweep_snapshot<RA, RB, R>(Hq, E, E2, snap_blk, lane);
             }
             if (CHAIN) {
                 const int col_out = step - 127;           // the column cell 127 has just finished
@@ -353,43 +399,56 @@ __global__ __launch_bounds__(WAVE) void k_sweep_pk16(int n_tasks, const NraSweep
                     cout[3 * chain_cap + col_out] = accS_B; cout[4 * chain_cap + col_out] = accB_B;
                 }
             }
-            if (lane == 63 && atB && last_blk) {          // cell 127 has finished a boundary column
-                const int k = kcur++;
+            // cell 127 (lane 63, cell B) has finished a boundary column: wave-uniform branch
+            if (last_blk && (__builtin_amdgcn_ballot_w64(atB) >> 63) != 0) {
+                if (BIT && DIR == 0) {
+                    // the one boundary of the short reverse sweep: A = best alignment inside R (doubled)
+                    if (lane == 63) {
+                        read_a[ra] = half_lo(accB_B) - BIAS;
+                        if (has_b) read_a[rb] = half_hi(accB_B) - BIAS;
+                    }
+                } else {
+                    const int k = kcur;
+                    int va = 0, vb = 0;
+                    if (lane == 63) {
 #pragma unroll
-                for (int s2 = 0; s2 < 2; ++s2) {
-                    const int lo_k = s2 ? kmin_b : kmin_a, hi_k = s2 ? kmax_b : kmax_a;
-                    const int B = (s2 ? half_hi(accB_B) : half_lo(accB_B)) - BIAS;
-                    if (BIT && DIR == 0) {
-                        // the one boundary of the short reverse sweep: A = best alignment inside R (doubled)
-                        if (s2 == 0 || has_b) read_a[s2 ? rb : ra] = B;
-                    } else if ((s2 == 0 || has_b) && k >= lo_k && k <= hi_k) {
-                        const uint32_t idx = (s2 ? coff_b : coff_a) + (uint32_t)(k - lo_k);
-                        if (DIR == 0) {
-                            arr_a[idx] = B;                       // running max of the reverse sweep = A_k
-                        } else {
-                            const int S = (s2 ? half_hi(accS_B) : half_lo(accS_B)) - 2 * BIAS;
-                            const int lo = sp.min_score > 1 ? sp.min_score : 1;
-                            int best, flag = 1;
-                            if (BIT) {
-                                // packed 2*score + origin bit; an alignment inside R starts at a column >= |L|
-                                const int V = imax(imax(S, B), read_a[s2 ? rb : ra] + 1);
-                                best = V >> 1;
-                                if (V & 1) flag = 0;                                  // an optimal alignment starts at >= |L|
-                                else if ((B >> 1) >= best) flag = ((S >> 1) >= best) ? 2 : 0;
+                        for (int s2 = 0; s2 < 2; ++s2) {
+                            const int B = (s2 ? half_hi(accB_B) : half_lo(accB_B)) - BIAS;
+                            int v;
+                            if (DIR == 0) {
+                                v = B;
                             } else {
-                                const int A = arr_a[idx];
-                                best = imax(imax(S, B), A);
-                                if (A >= best) flag = 0;                          // an optimal alignment starts in unit^k+R
-                                else if (B >= best) flag = (S >= best) ? 2 : 0;   // one ends inside L+unit^k
+                                const int lo_k = s2 ? kmin_b : kmin_a, hi_k = s2 ? kmax_b : kmax_a;
+                                const int S = (s2 ? half_hi(accS_B) : half_lo(accS_B)) - 2 * BIAS;
+                                const int lo = sp.min_score > 1 ? sp.min_score : 1;
+                                int best, flag = 1;
+                                if (BIT) {
+                                    // packed 2*score + origin bit; an alignment inside R starts at a column >= |L|
+                                    const int V = imax(imax(S, B), read_a[s2 ? rb : ra] + 1);
+                                    best = V >> 1;
+                                    if (V & 1) flag = 0;                                  // an optimal alignment starts at >= |L|
+                                    else if ((B >> 1) >= best) flag = ((S >> 1) >= best) ? 2 : 0;
+                                } else {
+                                    int A = 0;
+                                    if (k >= lo_k && k <= hi_k) A = arr_a[(s2 ? coff_b : coff_a) + (uint32_t)(k - lo_k)];
+                                    best = imax(imax(S, B), A);
+                                    if (A >= best) flag = 0;                          // an optimal alignment starts in unit^k+R
+                                    else if (B >= best) flag = (S >= best) ? 2 : 0;   // one ends inside L+unit^k
+                                }
+                                v = ((best >= lo ? best : -1) << 2) | flag;
                             }
-                            cand_score[idx] = best >= lo ? best : -1;
-                            cand_flag[idx] = (uint8_t)flag;
+                            if (s2) vb = v; else va = v;
                         }
                     }
+                    out_a = dpp_rol1(out_a); out_b = dpp_rol1(out_b);
+                    if (lane == 63) { out_a = va; out_b = vb; }
+                    ++kcur; ++n_out;
+                    if (n_out == 64) { flush(64); n_out = 0; }
                 }
             }
         }
     }
+    if (last_blk && n_out > 0) flush(n_out);
   }   // row blocks
 }
 
@@ -401,11 +460,11 @@ static int launch_sweep(int R, int has_n, int chain, hipStream_t st, int n_tasks
                         const NraDevRead* reads, const NraDevRegion* regions, const uint8_t* pool,
                         const uint32_t* q2bit, const uint32_t* qnmask, NraScoreParams sp,
                         const int32_t* kmin, const int32_t* kmax, const uint32_t* coff,
-                        int16_t* snap_h, int16_t* snap_e, int16_t* snap_e2, int32_t* arr_a, int32_t* read_a,
+                        int32_t* snap, int32_t* arr_a, int32_t* read_a,
                         int32_t* cand_score, uint8_t* cand_flag, int32_t* chain_buf, int chain_cap)
 {
     if (n_tasks <= 0) return 0;
-#define ARGS n_tasks, tasks, reads, regions, pool, q2bit, qnmask, sp, kmin, kmax, coff, snap_h, snap_e, snap_e2, arr_a, read_a, cand_score, cand_flag, chain_buf, chain_cap
+#define ARGS n_tasks, tasks, reads, regions, pool, q2bit, qnmask, sp, kmin, kmax, coff, snap, arr_a, read_a, cand_score, cand_flag, chain_buf, chain_cap
     if (chain) {      // row-block chaining: only the instantiations long reads (and the tests) use
         if (R == NRA_CHAIN_R) {
             if (has_n) k_sweep_pk16<NRA_CHAIN_R, true, DIR, true><<<n_tasks, WAVE, 0, st>>>(ARGS);
@@ -435,11 +494,11 @@ extern "C" int nra_launch_sweep_bwd(int R, int has_n, int chain, hipStream_t st,
                                     const NraDevRead* reads, const NraDevRegion* regions, const uint8_t* pool,
                                     const uint32_t* q2bit, const uint32_t* qnmask, NraScoreParams sp,
                                     const int32_t* kmin, const int32_t* kmax, const uint32_t* coff,
-                                    int16_t* snap_h, int16_t* snap_e, int16_t* snap_e2, int32_t* arr_a,
+                                    int32_t* snap, int32_t* arr_a,
                                     int32_t* read_a, int32_t* chain_buf, int chain_cap)
 {
     return launch_sweep<0>(R, has_n, chain, st, n_tasks, tasks, reads, regions, pool, q2bit, qnmask, sp, kmin, kmax,
-                           coff, snap_h, snap_e, snap_e2, arr_a, read_a, nullptr, nullptr, chain_buf, chain_cap);
+                           coff, snap, arr_a, read_a, nullptr, nullptr, chain_buf, chain_cap);
 }
 #endif
 #if NRA_HAS_PART(6)
@@ -447,11 +506,11 @@ extern "C" int nra_launch_sweep_fwd(int R, int has_n, int chain, hipStream_t st,
                                     const NraDevRead* reads, const NraDevRegion* regions, const uint8_t* pool,
                                     const uint32_t* q2bit, const uint32_t* qnmask, NraScoreParams sp,
                                     const int32_t* kmin, const int32_t* kmax, const uint32_t* coff,
-                                    int16_t* snap_h, int16_t* snap_e, int16_t* snap_e2, int32_t* arr_a,
+                                    int32_t* snap, int32_t* arr_a,
                                     int32_t* read_a, int32_t* cand_score, uint8_t* cand_flag, int32_t* chain_buf,
                                     int chain_cap)
 {
     return launch_sweep<1>(R, has_n, chain, st, n_tasks, tasks, reads, regions, pool, q2bit, qnmask, sp, kmin, kmax,
-                           coff, snap_h, snap_e, snap_e2, arr_a, read_a, cand_score, cand_flag, chain_buf, chain_cap);
+                           coff, snap, arr_a, read_a, cand_score, cand_flag, chain_buf, chain_cap);
 }
 #endif
