@@ -2,23 +2,34 @@
 """bench.py -- headline benchmark of the repeat-size scoring path on MI355X.
 
 Metric (BASELINE.json): read-alignments/sec = (reads x candidate-k) scored per second.
-Workload (BASELINE.json configs[1]): 10 000 synthetic ONT-error core reads over one 5 bp
-motif (TATTG), every read scored against k in [5,200] (196 candidates), alleles k=40/150.
 
-A "step" is one pass of the whole hot path (packed-int16 scoring of every candidate -- by the
-junction decomposition, or with --brute as K independent alignments -- per-read best score,
-flank test + tie mean) over one batch
-whose inputs are already resident in HBM (nra_batch1d_create has run).  N > 1: one process
-per GPU, every rank owns its own 10 000 reads (weak scaling, no data-path collective), then
-one small all_gather of the per-read results over RCCL.
+--config 2 (default; BASELINE.json configs[1]): 10 000 synthetic ONT-error core reads over one 5 bp
+    motif (TATTG), every read scored against k in [5,200] (196 candidates), alleles k=40/150.
+    N > 1: every rank owns one such region of 10 000 reads (weak scaling).
+--config 4 (BASELINE.json configs[3]): 1000 regions x 1000 reads, mixed 3-6 bp motifs, reference
+    window rule; the regions are dealt to the ranks by executed DP cells (strong scaling).
+--config 3 (BASELINE.json configs[2]): joint CAG+CCG grid rounds 2+3 on 5000 amplicon reads, N = 1.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W]
+A "step" is one pass of the whole hot path over the rank's shard, whose inputs are already
+resident in HBM (nanorepeat_amd.dist.ShardedBatch1D = nra_batch1d_create has run): every scoring
+kernel, the per-read selection (best score, flank test, tie mean) on the device, the fetch of the
+per-read results to the host and -- N > 1 -- the one all_gather that leaves them on every rank.
+The same product class runs at every N; there is no data-path collective.
+
+`value` is that resident-input rate (the contract of this benchmark: inputs in HBM when the clock
+starts).  SURVEY.md 8(d) defines the metric on the wall time of the scorer call from host buffers
+to host results; that figure is measured in the same run and reported beside it as `one_shot`
+(N = 1, config 2: one nra_round3_1d call = 2-bit packing + device buffers + H2D + kernels +
+selection + D2H, median of --one-shot-calls calls).
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--config 2|3|4]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W
 """
 import argparse
 import json
 import os
+import subprocess
 import sys
 import time
 
@@ -27,20 +38,24 @@ sys.path.insert(0, ROOT)
 
 # Integer-VALU roofline of the dominant kernel (DESIGN.md "Roofline"):
 #   peak lane-ops/s = 256 CU x 4 SIMD x 32 lanes/clk x 2.4 GHz
-#   a two-piece-affine local-alignment cell needs 20 packed-int16 VALU instructions per
-#   2 cells (3 substitution, 2 diagonal, 4 five-way max, 1 running max, 10 gap states)
-#   = 10 lane-ops per cell; that is the work counted as "achieved".
+#   a two-piece-affine local-alignment cell is priced at 20 packed-int16 VALU instructions per
+#   2 cells = 10 lane-ops per cell (SURVEY.md 8d's 8-13); `achieved` counts the cells the kernels
+#   EXECUTE (padding and pipeline fill included) at that price.
 VALU_PEAK_TLANEOPS = 256 * 4 * 32 * 2.4e9 / 1e12      # 78.6
 LANEOPS_PER_CELL = 10.0
 HBM_PEAK_GBPS = 8000.0
+PMC_PROFILE = os.path.join("profiles", "r02_pmc_traffic.json")
 
 
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
-    ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--reads", type=int, default=10000, help="reads per GPU (config 2: 10000)")
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--config", type=int, default=2, choices=(2, 3, 4))
+    ap.add_argument("--reads", type=int, default=10000, help="config 2: reads per GPU (10000); config 3: reads (5000)")
+    ap.add_argument("--regions", type=int, default=1000, help="config 4: regions in the whole job")
+    ap.add_argument("--reads-per-region", type=int, default=1000, help="config 4")
     ap.add_argument("--brute", action="store_true",
                     help="score K independent alignments per read (k_score_pk16) instead of the decomposition")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL)")
@@ -48,7 +63,24 @@ def parse():
                     help="rehearsal only: every rank uses GPU 0 (with --backend gloo on a one-GPU box)")
     ap.add_argument("--cpu-sample", type=int, default=-1,
                     help="reads in the CPU-baseline sample (-1: sized for ~15 s, 0: skip)")
+    ap.add_argument("--one-shot-calls", type=int, default=5, help="host-buffers-in/out calls timed at N = 1 (0: skip)")
     return ap.parse_args()
+
+
+def spawn_ranks_if_needed(args):
+    """`python bench.py --gpus N` without a launcher: start N ranks (before anything touches the
+    GPU) and leave with their exit code.  A launcher's WORLD_SIZE must agree with --gpus."""
+    ws = os.environ.get("WORLD_SIZE")
+    if ws is not None:
+        if int(ws) != args.gpus:
+            sys.exit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={ws}")
+        return
+    if args.gpus <= 1:
+        return
+    port = 29000 + os.getpid() % 3000
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    sys.exit(subprocess.call(cmd))
 
 
 def host_cores():
@@ -69,16 +101,17 @@ def host_cores():
     return min(n, 16)
 
 
-def cpu_baseline(data, n_sample):
+def cpu_baseline_1d(data, n_sample):
     """Times the CPU oracle (oracle/, the restatement of the reference algorithm: K independent
     optimal alignments per read) on a bounded sample of the same workload, all host cores."""
     from oracle import oracle as O
     cores = host_cores()
     n_total = len(data["reads"])
-    # calibrate on one read per thread, then size the sample for ~15 s of CPU work
+    rr = data.get("read_region")
+    sub = lambda n: dict(read_region=None if rr is None else rr[:n])
     n_cal = min(cores, n_total)
     t0 = time.perf_counter()
-    O.round3_1d(data["regions"], data["reads"][:n_cal], data["kmin"][:n_cal], data["kmax"][:n_cal], threads=cores)
+    O.round3_1d(data["regions"], data["reads"][:n_cal], data["kmin"][:n_cal], data["kmax"][:n_cal], threads=cores, **sub(n_cal))
     t_cal = max(time.perf_counter() - t0, 1e-3)
     if n_sample < 0:
         n_sample = int(n_cal * 15.0 / t_cal)
@@ -89,26 +122,65 @@ def cpu_baseline(data, n_sample):
     reads = data["reads"][:n_sample]
     kmin, kmax = data["kmin"][:n_sample], data["kmax"][:n_sample]
     t0 = time.perf_counter()
-    out = O.round3_1d(data["regions"], reads, kmin, kmax, threads=cores)
+    out = O.round3_1d(data["regions"], reads, kmin, kmax, threads=cores, **sub(n_sample))
     dt = time.perf_counter() - t0
     n_align = int((kmax.astype("int64") - kmin + 1).sum())
     return {"value": n_align / dt, "unit": "read-alignments/s", "cores": cores, "kind": "port",
-            "sample": f"first {n_sample} of the workload's reads x 196 candidates = {n_align} "
-                      f"alignments in {dt:.1f} s; CPU restatement (optimal DP, oracle/nr_oracle.c, "
+            "sample": f"first {n_sample} of the workload's reads = {n_align} alignments in {dt:.1f} s; CPU "
+                      f"restatement (optimal DP, K independent alignments per read, oracle/nr_oracle.c, "
                       f"OpenMP over reads), not minimap2"}, out
 
 
-def main():
-    args = parse()
+def roofline(st0, st1, n_steps, brute, kernel_name):
+    """The dominant kernels against the integer-VALU roof, from the HIP events of the timed steps
+    (st0/st1: batch statistics before/after them; the events sit on the streams the kernels run on)."""
+    runs = st1["n_runs"] - st0["n_runs"]
+    phase_ms = (st1["sum_score_phase_ms"] - st0["sum_score_phase_ms"]) / max(runs, 1)
+    launch_ms = (st1["sum_score_kernel_ms"] - st0["sum_score_kernel_ms"]) / max(runs, 1)
+    total_ms = (st1["sum_total_ms"] - st0["sum_total_ms"]) / max(runs, 1)
+    ext_ms = (st1["sum_extent_kernel_ms"] - st0["sum_extent_kernel_ms"]) / max(runs, 1)
+    kernel_s = phase_ms / 1e3
+    exe_cells_per_s = st1["executed_cells"] / kernel_s
+    alg_cells_per_s = st1["algorithmic_cells"] / kernel_s
+    achieved = exe_cells_per_s * LANEOPS_PER_CELL / 1e12
+    traffic, counters = None, None
+    prof = os.path.join(ROOT, PMC_PROFILE)
+    if os.path.exists(prof) and not brute:
+        try:
+            pmc = json.load(open(prof))
+            traffic = pmc.get("hbm_bytes_per_step_sweep_kernels")
+            counters = {"source": PMC_PROFILE + " (rocprofv3 --pmc passes of this command)",
+                        "valu_wave_instructions_per_step": pmc["sweep_kernels"]["valu_wave_instructions_per_step"],
+                        "simd_cycles_per_valu_instruction": pmc.get("simd_cycles_per_valu_instruction")}
+        except Exception:
+            traffic, counters = None, None
+    hbm_gbps = st1["algorithmic_bytes"] / kernel_s / 1e9
+    return {"bound": "valu", "achieved": achieved, "peak": VALU_PEAK_TLANEOPS, "unit": "Tlane-op/s",
+            "frac": achieved / VALU_PEAK_TLANEOPS, "traffic": traffic, "counters": counters,
+            "kernel": kernel_name,
+            "kernel_ms_per_step": phase_ms, "steps_averaged": runs,
+            "sum_of_launch_durations_ms": launch_ms, "n_launches_per_step": st1["n_score_launches"],
+            "executed_cells_per_step": st1["executed_cells"], "executed_Tcell_per_s": exe_cells_per_s / 1e12,
+            "laneops_per_cell": LANEOPS_PER_CELL,
+            "note": "achieved = cells the kernels execute (row padding to 64*R and pipeline fill/drain columns "
+                    "included) x 10 lane-ops / the scoring phase's HIP-event time averaged over the timed steps "
+                    "(launches of different read-length buckets overlap on their own streams). The K-fold "
+                    "algorithmic cell count of SURVEY 8d is in 'algorithmic': the junction decomposition "
+                    "shares L+unit^k and R across the K candidates and never executes those cells",
+            "algorithmic": {"cells_per_step": st1["algorithmic_cells"], "Tcell_per_s": alg_cells_per_s / 1e12,
+                            "over_executed": st1["algorithmic_cells"] / max(st1["executed_cells"], 1)},
+            "hbm": {"algorithmic_bytes_per_step": st1["algorithmic_bytes"], "achieved_GBps": hbm_gbps,
+                    "peak_GBps": HBM_PEAK_GBPS, "frac": hbm_gbps / HBM_PEAK_GBPS,
+                    "note": "compute-bound by design: ~5 B per read-alignment"},
+            "extent_kernel_ms_per_step": ext_ms, "device_ms_per_step": total_ms}
+
+
+def init_dist(args):
+    import torch
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-
-    import numpy as np
-    import torch
-    from nanorepeat_amd import _capi as A, synth
-
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: no HIP device visible (there is no CPU path)")
     if args.same_device:
@@ -121,138 +193,141 @@ def main():
             dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
         else:
             dist.init_process_group(backend=args.backend)
-    gather_dev = torch.device("cuda", local_rank) if args.backend == "nccl" else torch.device("cpu")
+    return rank, local_rank, world, dist
 
-    # every rank owns its own reads (weak scaling); rank 0's are BASELINE config 2 exactly
-    data = synth.config2(n_reads=args.reads, seed=synth.SEED + rank)
-    n_align = int((data["kmax"].astype(np.int64) - data["kmin"] + 1).sum())
-    batch = A.Batch.create_1d(data["regions"], data["reads"], data["kmin"], data["kmax"],
-                              device=local_rank, flags=A.F_BRUTE_FORCE if args.brute else 0)
+
+def timed_steps(args, dist, step, on_warm=None):
+    """W warm-up steps, then exactly K steps between barrier + synchronize; max over ranks."""
+    import torch
 
     def barrier():
         if dist is not None:
             dist.barrier()
         torch.cuda.synchronize()
 
-    # One step = one pass of the hot path over the rank's batch + the exchange of its per-read
-    # results.  The exchange of step i runs while the kernels of step i+1 do (it is host/RCCL work
-    # on other streams); the last one is exposed before the closing barrier.
-    pending = []
-
-    def exchange():
-        if dist is None or not pending:
-            return None
-        out = pending.pop()
-        mine = torch.from_numpy(np.stack([out["sum_k"], out["n_ties"].astype(np.int64),
-                                          out["status"].astype(np.int64)], 1)).to(gather_dev)
-        gathered = [torch.empty_like(mine) for _ in range(world)]
-        dist.all_gather(gathered, mine)
-        return gathered
-
-    def step():
-        batch.run()
-        exchange()                      # the previous step's results
-        batch.sync()
-        if dist is not None:
-            pending.append(batch.fetch(per_candidate=False))
-
     for _ in range(args.warmup):
         step()
-    exchange()
+    if on_warm is not None:
+        on_warm()
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
-    exchange()
     barrier()
     dt = time.perf_counter() - t0
     if dist is not None:
-        t = torch.tensor([dt], dtype=torch.float64, device=gather_dev)
+        dev = torch.device("cuda", torch.cuda.current_device()) if args.backend == "nccl" else torch.device("cpu")
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
+    return dt
 
-    st = batch.stats()
-    out = batch.fetch(per_candidate=False)
-    ok = out["status"] == 0
-    est = out["sum_k"][ok] / np.maximum(out["n_ties"][ok], 1)
-    exact = float(np.mean(est == data["k_true"][ok])) if ok.any() else 0.0
+
+def bench_1d(args):
+    import numpy as np
+    from nanorepeat_amd import _capi as A, dist as D, synth
+    rank, local_rank, world, dist = init_dist(args)
+
+    if args.config == 2:
+        # every rank owns one region of `reads` reads (weak scaling); rank 0's is BASELINE config 2 exactly
+        data = synth.config2(n_reads=args.reads, seed=synth.SEED + rank)
+        index = rank * args.reads + np.arange(args.reads, dtype=np.int64)
+        n_total = world * args.reads
+        workload = ("config2: 10k synthetic ONT-error core reads (q~400/950), motif TATTG, k in [5,200] "
+                    "(196 candidates/read), 1000 bp flanks" + ("" if world == 1 else f"; one such region per GPU x {world}"))
+        scaling = "weak"
+    else:
+        # the whole job is fixed; regions go to ranks by the cells the kernels will execute for them,
+        # computed from the region descriptors alone, and every rank materialises only its own reads
+        cost = np.array([synth.config4_region_cost(synth.config4_region(g), args.reads_per_region)
+                         for g in range(args.regions)], np.int64)
+        owner = D._lpt(cost, world)
+        data = synth.config4(args.regions, args.reads_per_region, only=np.nonzero(owner == rank)[0])
+        index = data["read_id"]
+        n_total = args.regions * args.reads_per_region
+        workload = (f"config4: {args.regions} regions x {args.reads_per_region} reads, mixed 3-6 bp motifs, ont_q20 "
+                    f"errors, reference window rule (K = 31 typical), sharded by region over {world} GPU(s)")
+        scaling = "strong"
+
+    n_align_local = int(np.maximum(data["kmax"].astype(np.int64) - data["kmin"] + 1, 0).sum())
+    sb = D.ShardedBatch1D(data["regions"], data["reads"], data["kmin"], data["kmax"], data.get("read_region"),
+                          index, n_total, flags=A.F_BRUTE_FORCE if args.brute else 0, device=local_rank)
+    last = {}
+
+    def step():
+        sb.run()
+        last["out"] = sb.gather()       # device selection -> D2H of the per-read results -> all_gather (N > 1)
+
+    warm = {}
+    dt = timed_steps(args, dist, step, on_warm=lambda: warm.update(sb.stats()))
+    st = sb.stats()
+    out = last["out"]
+    n_align = n_align_local
+    if dist is not None:
+        import torch
+        dev = torch.device("cuda", torch.cuda.current_device()) if args.backend == "nccl" else torch.device("cpu")
+        t = torch.tensor([n_align_local], dtype=torch.int64, device=dev)
+        dist.all_reduce(t)
+        n_align = int(t.item())
 
     if rank == 0:
-        # device wall time of the scoring phase (HIP events on the batch stream).  The launches of
-        # different read-length buckets overlap on their own streams, so this is what the kernels
-        # achieve together; the sum of their individual launch durations is reported beside it.
-        kernel_s = st["score_phase_ms"] / 1e3
-        alg_cells_per_s = st["algorithmic_cells"] / kernel_s
-        exe_cells_per_s = st["executed_cells"] / kernel_s
-        achieved = alg_cells_per_s * LANEOPS_PER_CELL / 1e12
-        executed = exe_cells_per_s * LANEOPS_PER_CELL / 1e12
-        traffic, counters = None, None
-        prof = os.path.join(ROOT, "profiles", "r01f_pmc_traffic.json")
-        if os.path.exists(prof) and not args.brute:
-            try:
-                pmc = json.load(open(prof))
-                traffic = pmc.get("hbm_bytes_per_step_sweep_kernels")
-                counters = {"source": "profiles/r01f_pmc_traffic.json (rocprofv3 --pmc passes of this command, --steps 1)",
-                            "valu_wave_instructions_per_step": pmc["sweep_kernels"]["valu_wave_instructions_per_step"],
-                            "simd_cycles_per_valu_instruction": pmc.get("simd_cycles_per_valu_instruction"),
-                            "VALUBusy_pct": pmc["sweep_kernels"].get("VALUBusy_pct")}
-            except Exception:
-                traffic, counters = None, None
-        hbm_gbps = st["algorithmic_bytes"] / kernel_s / 1e9
+        mine = out["status"][index] == 0
+        est = out["sum_k"][index][mine] / np.maximum(out["n_ties"][index][mine], 1)
+        exact = float(np.mean(est == data["k_true"][mine])) if mine.any() else 0.0
+        kern = "k_score_pk16<R>" if args.brute else "k_sweep_pk16<R,dir> (reverse + forward sweeps of all read-length buckets)"
         line = {
             "metric": "read-alignments/sec (reads x candidate-k)",
-            "value": world * n_align * args.steps / dt,
-            "unit": "read-alignments/s",
+            "value": n_align * args.steps / dt, "unit": "read-alignments/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": dt / args.steps * 1e3,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "higher_is_better": True, "scaling": scaling, "vs_baseline": None,
             "dtype": "int16", "data": "synthetic",
-            "config": {"workload": "config2: 10k synthetic ONT-error core reads (q~400/950), motif "
-                                   "TATTG, k in [5,200] (196 candidates/read), 1000 bp flanks",
-                       "reads_per_gpu": args.reads, "alignments_per_gpu": n_align,
+            "config": {"workload": workload, "reads": n_total, "alignments": n_align,
                        "mode": "brute force (K independent alignments)" if args.brute else
                                "junction decomposition (exact; shares L+unit^k and R across k)",
-                       "parallelism": f"reads sharded over {world} GPU(s), no data-path collective"},
-            "roofline": {"bound": "valu", "achieved": achieved, "peak": VALU_PEAK_TLANEOPS,
-                         "unit": "Tlane-op/s", "frac": achieved / VALU_PEAK_TLANEOPS,
-                         "traffic": traffic, "counters": counters,
-                         "note": "achieved prices the ALGORITHMIC cells (SURVEY 8d: q x tlen for each of the K "
-                                 "independent alignments) at 10 lane-ops per cell; the decomposition executes "
-                                 "far fewer cells, so frac can exceed 1 -- 'executed' prices the cells the "
-                                 "kernels actually update",
-                         "executed": {"achieved": executed, "frac": executed / VALU_PEAK_TLANEOPS,
-                                      "cells_per_step": st["executed_cells"],
-                                      "Tcell_per_s": exe_cells_per_s / 1e12},
-                         "kernel": "k_score_pk16<R>" if args.brute else "k_sweep_pk16<R,dir> (reverse + forward sweeps, all R)",
-                         "kernel_ms_per_step": st["score_phase_ms"],
-                         "sum_of_launch_durations_ms": st["score_kernel_ms"],
-                         "n_launches_per_step": st["n_score_launches"],
-                         "algorithmic_cells_per_step": st["algorithmic_cells"],
-                         "Tcell_per_s": alg_cells_per_s / 1e12,
-                         "laneops_per_cell": LANEOPS_PER_CELL,
-                         "hbm": {"algorithmic_bytes_per_step": st["algorithmic_bytes"],
-                                 "achieved_GBps": hbm_gbps, "peak_GBps": HBM_PEAK_GBPS,
-                                 "frac": hbm_gbps / HBM_PEAK_GBPS,
-                                 "note": "compute-bound by design: ~5 B per read-alignment"}},
-            "extent_kernel_ms_per_step": st["extent_kernel_ms"],
+                       "timed_region": "inputs resident in HBM; kernels + on-device selection + D2H of per-read "
+                                       "results" + (" + all_gather" if world > 1 else ""),
+                       "parallelism": f"region blocks sharded over {world} GPU(s), no data-path collective, one all_gather of 32 B/read"},
+            "roofline": roofline(warm, st, args.steps, args.brute, kern),
             "extent_tasks_per_step": st["n_extent_tasks"],
-            "device_ms_per_step": st["total_ms"],
             "exact_k_fraction": exact,
         }
-        if world == 1:
-            cb = cpu_baseline(data, args.cpu_sample) if args.cpu_sample != 0 else None
+        if world == 1 and args.config == 2 and args.one_shot_calls > 0 and not args.brute:
+            call, res = A.prepared_round3_1d(data["regions"], data["reads"], data["kmin"], data["kmax"], device=local_rank)
+            call()
+            ts = []
+            for _ in range(args.one_shot_calls):
+                t0 = time.perf_counter(); call(); ts.append(time.perf_counter() - t0)
+            med = float(np.median(ts))
+            same = all(np.array_equal(res[k], out[k]) for k in ("best_score", "sum_k", "n_ties", "status"))
+            line["one_shot"] = {"value": n_align / med, "unit": "read-alignments/s", "ms_per_call": med * 1e3,
+                                "calls": args.one_shot_calls, "ms_all": [t * 1e3 for t in ts],
+                                "equals_resident_results": bool(same),
+                                "what": "SURVEY 8(d) wall time of the scorer call: one nra_round3_1d from host buffers "
+                                        "(ASCII reads) to host results = 2-bit packing + device arena + H2D + kernels + "
+                                        "selection + D2H; median"}
+        if world == 1 and args.cpu_sample != 0:
+            cb = cpu_baseline_1d(data, args.cpu_sample)
             if cb is not None:
                 base, ref = cb
                 n = len(ref["sum_k"])
-                same = all(np.array_equal(out[k][:n], ref[k]) for k in ("sum_k", "n_ties", "status", "best_score"))
+                same = all(np.array_equal(out[k][index][:n], ref[k]) for k in ("sum_k", "n_ties", "status", "best_score"))
                 base["gpu_matches_sample"] = bool(same)
                 line["cpu_baseline"] = base
-                line["gpu_over_cpu"] = line["value"] / base["value"]
         print(json.dumps(line), flush=True)
-    batch.close()
+    sb.close()
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def main():
+    args = parse()
+    spawn_ranks_if_needed(args)
+    if args.config == 3:
+        from tools import bench_joint
+        return bench_joint.run(args, sys.modules[__name__])
+    bench_1d(args)
 
 
 if __name__ == "__main__":

@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define NRA_ABI_VERSION 1
+#define NRA_ABI_VERSION 2
 
 /* error codes */
 #define NRA_OK            0
@@ -95,7 +95,7 @@ typedef struct nra_joint_region {
     int32_t right_len;
 } nra_joint_region_t;
 
-/* Work and timing counters of the last run of a batch. */
+/* Work and timing counters of a batch (timings: HIP events on the streams the kernels run on). */
 typedef struct nra_stats {
     int64_t n_alignments;     /* (read, candidate) pairs scored */
     int64_t algorithmic_cells;/* sum of qlen * tlen over those pairs */
@@ -107,10 +107,12 @@ typedef struct nra_stats {
     double  extent_kernel_ms; /* second-pass kernel (1D extents) */
     double  total_ms;         /* first launch -> last launch of the run, HIP events */
     int32_t n_score_launches;
-    int32_t reserved;
+    int32_t n_runs;           /* completed runs (nra_batch_run + nra_batch_sync) the sums below cover */
     double  score_phase_ms;   /* wall time of the scoring phase on the device (first scoring launch ->
                                  last one done); < score_kernel_ms when launches of different read-length
                                  buckets overlap on their own streams */
+    /* the four timings above belong to the LAST run; these are summed over all n_runs runs */
+    double  sum_score_kernel_ms, sum_extent_kernel_ms, sum_total_ms, sum_score_phase_ms;
 } nra_stats_t;
 
 typedef struct nra_batch nra_batch_t;   /* device-resident inputs + outputs of one call */

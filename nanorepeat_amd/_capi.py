@@ -54,11 +54,13 @@ class Stats(C.Structure):
                 ("executed_cells", C.c_int64), ("algorithmic_bytes", C.c_int64),
                 ("n_extent_tasks", C.c_int64), ("score_kernel_ms", C.c_double),
                 ("extent_kernel_ms", C.c_double), ("total_ms", C.c_double),
-                ("n_score_launches", C.c_int32), ("reserved", C.c_int32),
-                ("score_phase_ms", C.c_double)]
+                ("n_score_launches", C.c_int32), ("n_runs", C.c_int32),
+                ("score_phase_ms", C.c_double),
+                ("sum_score_kernel_ms", C.c_double), ("sum_extent_kernel_ms", C.c_double),
+                ("sum_total_ms", C.c_double), ("sum_score_phase_ms", C.c_double)]
 
     def as_dict(self):
-        return {n: getattr(self, n) for n, _ in self._fields_ if n != "reserved"}
+        return {n: getattr(self, n) for n, _ in self._fields_}
 
 
 def load():
@@ -203,6 +205,30 @@ def round3_1d(regions, reads, kmin, kmax, read_region=None, sc=None, flags=0, de
                              _ptr(out["cand_tstart"], C.c_int32) if pc else None,
                              _ptr(out["cand_tend"], C.c_int32) if pc else None))
     return out
+
+
+def prepared_round3_1d(regions, reads, kmin, kmax, read_region=None, sc=None, flags=0, device=0):
+    """-> (call, out): `call()` is exactly one nra_round3_1d over prebuilt host buffers (ASCII reads in,
+    per-read results out), so that a benchmark times the C ABI and not the Python list handling."""
+    lib = load()
+    sc = sc or default_scoring()
+    n = len(reads)
+    seqs, off = pack_reads(reads)
+    kmin = np.ascontiguousarray(kmin, np.int32)
+    kmax = np.ascontiguousarray(kmax, np.int32)
+    rr = None if read_region is None else np.ascontiguousarray(read_region, np.int32)
+    regs, keep = _regions(regions)
+    out = _outputs_1d(n, 0)
+    args = (device, regs, len(regions), n, seqs, _ptr(off, C.c_int64), _ptr(rr, C.c_int32),
+            _ptr(kmin, C.c_int32), _ptr(kmax, C.c_int32), C.byref(sc), flags,
+            _ptr(out["best_score"], C.c_int32), _ptr(out["sum_k"], C.c_int64),
+            _ptr(out["n_ties"], C.c_int32), _ptr(out["status"], C.c_uint8), None, None, None)
+    hold = (seqs, off, kmin, kmax, rr, regs, keep, sc)
+
+    def call():
+        _check(lib.nra_round3_1d(*args))
+        return hold and out
+    return call, out
 
 
 def joint_2d(region, reads, cell_read, cell_k1, cell_k2, read_strand=None, sc=None, flags=0,

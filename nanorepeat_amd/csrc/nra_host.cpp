@@ -326,7 +326,7 @@ struct nra_batch {
     hipEvent_t phase_ev[2] = {nullptr, nullptr};   // scoring phase start / end (timing)
     std::vector<hipEvent_t> ev;    // [0]=run start, [1]=run end, then pairs per dominant launch
     int n_score_ev = 0, n_ext_ev = 0;
-    bool ran = false;
+    bool ran = false, accounted = false;
     nra_stats_t stats{};
 
     ~nra_batch()
@@ -1475,9 +1475,45 @@ int nra_batch_run(nra_batch_t* b)
 {
     if (!b) return fail(NRA_E_ARG, "batch is NULL");
     HIP_TRY(hipSetDevice(b->device));
+    // the events are about to be re-recorded: a finished run nobody synchronised on is accounted first
+    if (b->ran && !b->accounted) {
+        HIP_TRY(hipStreamSynchronize(b->stream));
+        int rc0 = account_run(b);
+        if (rc0) return rc0;
+    }
     int rc = b->kind == 1 ? run_1d(b) : run_2d(b);
-    if (!rc) b->ran = true;
+    if (!rc) { b->ran = true; b->accounted = false; }
     return rc;
+}
+
+// Reads the HIP events of the run that has just completed (the stream is idle) into the batch's
+// statistics: the last run's timings and their sums over all runs, so that a caller timing many runs
+// gets averages that belong to the same runs as its wall clock.
+static int account_run(nra_batch* b)
+{
+    if (!b->ran || b->accounted) return NRA_OK;
+    float ms = 0.f;
+    HIP_TRY(hipEventElapsedTime(&ms, b->ev[0], b->ev[1]));
+    b->stats.total_ms = ms;
+    HIP_TRY(hipEventElapsedTime(&ms, b->phase_ev[0], b->phase_ev[1]));
+    b->stats.score_phase_ms = ms;
+    // event pairs were recorded in launch order: 1D: score..., extents...; 2D: probe..., window...
+    double first = 0, second = 0;
+    const int n_first = b->kind == 1 ? b->n_score_ev : b->n_ext_ev;
+    const int n_second = b->kind == 1 ? b->n_ext_ev : b->n_score_ev;
+    int ev = 2;
+    for (int i = 0; i < n_first; ++i, ev += 2) { HIP_TRY(hipEventElapsedTime(&ms, b->ev[ev], b->ev[ev + 1])); first += ms; }
+    for (int i = 0; i < n_second; ++i, ev += 2) { HIP_TRY(hipEventElapsedTime(&ms, b->ev[ev], b->ev[ev + 1])); second += ms; }
+    b->stats.score_kernel_ms = b->kind == 1 ? first : second;
+    b->stats.extent_kernel_ms = b->kind == 1 ? second : first;
+    b->stats.n_score_launches = b->n_score_ev;
+    b->stats.n_runs += 1;
+    b->stats.sum_score_kernel_ms += b->stats.score_kernel_ms;
+    b->stats.sum_extent_kernel_ms += b->stats.extent_kernel_ms;
+    b->stats.sum_total_ms += b->stats.total_ms;
+    b->stats.sum_score_phase_ms += b->stats.score_phase_ms;
+    b->accounted = true;
+    return NRA_OK;
 }
 
 int nra_batch_sync(nra_batch_t* b)
@@ -1485,7 +1521,7 @@ int nra_batch_sync(nra_batch_t* b)
     if (!b) return fail(NRA_E_ARG, "batch is NULL");
     HIP_TRY(hipSetDevice(b->device));
     HIP_TRY(hipStreamSynchronize(b->stream));
-    return NRA_OK;
+    return account_run(b);
 }
 
 int nra_batch_stats(nra_batch_t* b, nra_stats_t* st)
@@ -1494,21 +1530,8 @@ int nra_batch_stats(nra_batch_t* b, nra_stats_t* st)
     HIP_TRY(hipSetDevice(b->device));
     if (b->ran) {
         HIP_TRY(hipStreamSynchronize(b->stream));
-        float ms = 0.f;
-        HIP_TRY(hipEventElapsedTime(&ms, b->ev[0], b->ev[1]));
-        b->stats.total_ms = ms;
-        HIP_TRY(hipEventElapsedTime(&ms, b->phase_ev[0], b->phase_ev[1]));
-        b->stats.score_phase_ms = ms;
-        // event pairs were recorded in launch order: 1D: score..., extents...; 2D: probe..., window...
-        double first = 0, second = 0;
-        const int n_first = b->kind == 1 ? b->n_score_ev : b->n_ext_ev;
-        const int n_second = b->kind == 1 ? b->n_ext_ev : b->n_score_ev;
-        int ev = 2;
-        for (int i = 0; i < n_first; ++i, ev += 2) { HIP_TRY(hipEventElapsedTime(&ms, b->ev[ev], b->ev[ev + 1])); first += ms; }
-        for (int i = 0; i < n_second; ++i, ev += 2) { HIP_TRY(hipEventElapsedTime(&ms, b->ev[ev], b->ev[ev + 1])); second += ms; }
-        b->stats.score_kernel_ms = b->kind == 1 ? first : second;
-        b->stats.extent_kernel_ms = b->kind == 1 ? second : first;
-        b->stats.n_score_launches = b->n_score_ev;
+        int rc = account_run(b);
+        if (rc) return rc;
         if (b->kind == 1 && !(b->flags & NRA_F_ALL_EXTENTS) && !b->buckets.empty()) {
             std::vector<int32_t> tc(b->buckets.size());
             HIP_TRY(hipMemcpy(tc.data(), b->tie_count.p, tc.size() * 4, hipMemcpyDeviceToHost));

@@ -1,13 +1,45 @@
-"""Multi-GPU sharding of the 1D path: one process per GPU, reads dealt across ranks by
-estimated DP cells, no data-path collective, one small all_gather of per-read results.
+"""Multi-GPU sharding of the scoring path: one process per GPU, no data-path collective, one
+small all_gather of per-read results.
 
-The reference parallelises the same way -- regions to forked workers, nothing shared but a
-result queue (nanoRepeat_bam.py:602-612, 712-728); here the unit is the read and the
-"queue" is one RCCL all_gather (torch.distributed backend "nccl"; "gloo" in CPU tests).
+The reference parallelises the same way -- regions go to forked workers, nothing is shared but a
+result queue (nanoRepeat_bam.py:602-612, 712-728).  Here the unit is a *region block* (a run of
+one region's reads: the sweep kernels pair two reads of a region per wave, so reads of a region
+stay together), blocks are dealt to ranks by the DP cells the kernels execute for them, and the
+"queue" is one un-chunked RCCL all_gather of 32 B per read (torch.distributed backend "nccl";
+"gloo" in the CPU tests).
 """
+import heapq
+
 import numpy as np
 
 from . import _capi
+
+# rows-per-lane instantiations of the sweep kernels (csrc/nra_internal.h NRA_R_LIST); longer reads
+# run as chained blocks of 64 * 24 rows
+_R_LIST = np.array([1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16, 18, 20, 22, 24, 28, 32, 40, 48], np.int64)
+_CHAIN_ROWS = 64 * 24
+
+
+def padded_rows(qlen):
+    """Rows a wave sweeps for a read of qlen bases (64 x the bucket's rows per lane)."""
+    q = np.asarray(qlen, np.int64)
+    need = (q + 63) // 64
+    one = _R_LIST[np.minimum(np.searchsorted(_R_LIST, need), len(_R_LIST) - 1)] * 64
+    chained = (q + _CHAIN_ROWS - 1) // _CHAIN_ROWS * _CHAIN_ROWS
+    return np.where(need <= _R_LIST[-1], one, chained)
+
+
+def executed_cells(regions, qlen, kmax, read_region=None):
+    """DP cells the junction-decomposition kernels execute for every read: padded rows x
+    (|L| + m*kmax forward columns + |R| reverse columns + the two pipelines' 127 fill/drain
+    columns).  This -- not the K-fold algorithmic count -- is what a shard costs."""
+    q = np.asarray(qlen, np.int64)
+    n = len(q)
+    rr = np.zeros(n, np.int64) if read_region is None else np.asarray(read_region, np.int64)
+    fl = np.array([len(l) + len(r) for l, _, r in regions], np.int64)[rr]
+    m = np.array([len(u) for _, u, _ in regions], np.int64)[rr]
+    km = np.maximum(np.asarray(kmax, np.int64), 0)
+    return padded_rows(q) * (fl + m * km + 254)
 
 
 def estimate_cells(regions, reads, kmin, kmax, read_region=None):
@@ -24,65 +56,191 @@ def estimate_cells(regions, reads, kmin, kmax, read_region=None):
     return q * sum_t
 
 
+def _lpt(cost, world):
+    """Longest-processing-time assignment of a few thousand items at most (heap)."""
+    owner = np.zeros(len(cost), np.int32)
+    heap = [(0, r) for r in range(world)]
+    for i in np.argsort(-np.asarray(cost, np.int64), kind="stable"):
+        load, r = heapq.heappop(heap)
+        owner[i] = r
+        heapq.heappush(heap, (load + int(cost[i]), r))
+    return owner
+
+
+def shard_region_blocks(cost, read_region, world, blocks_per_rank=8):
+    """Owner rank of every read.  Reads of one region are cut into blocks of about
+    total / (world * blocks_per_rank) cost (input order kept), and the blocks are dealt to ranks
+    longest first.  Vectorised over reads; the only Python loop runs over the blocks
+    (<= n_regions + world * blocks_per_rank)."""
+    cost = np.asarray(cost, np.int64)
+    n = len(cost)
+    if n == 0 or world <= 1:
+        return np.zeros(n, np.int32)
+    rr = np.zeros(n, np.int64) if read_region is None else np.asarray(read_region, np.int64)
+    order = np.argsort(rr, kind="stable")
+    c = cost[order]
+    g = rr[order]
+    cs = np.cumsum(c) - c                                   # exclusive prefix over the sorted reads
+    first = np.r_[True, g[1:] != g[:-1]]
+    region_start = np.maximum.accumulate(np.where(first, cs, 0))
+    target = max(1, int(c.sum()) // (world * blocks_per_rank))
+    blk_in_region = (cs - region_start) // target
+    new_blk = first | np.r_[False, blk_in_region[1:] != blk_in_region[:-1]]
+    blk = np.cumsum(new_blk) - 1
+    blk_owner = _lpt(np.bincount(blk, weights=c).astype(np.int64), world)
+    owner = np.empty(n, np.int32)
+    owner[order] = blk_owner[blk]
+    return owner
+
+
 def shard_reads(cost, world):
-    """Greedy longest-processing-time assignment: returns a list of index arrays, one per
-    rank; deterministic, every read assigned exactly once, loads balanced to within one unit."""
+    """Index arrays, one per rank, for independent reads (the joint mode): costs sorted, dealt
+    in snake order (0..W-1, W-1..0, ...), so the loads differ by at most the largest cost."""
     cost = np.asarray(cost, np.int64)
     order = np.argsort(-cost, kind="stable")
-    load = np.zeros(world, np.int64)
+    pos = np.arange(len(cost)) % (2 * world)
     owner = np.empty(len(cost), np.int64)
-    for i in order:
-        r = int(np.argmin(load))
-        owner[i] = r
-        load[r] += cost[i]
+    owner[order] = np.where(pos < world, pos, 2 * world - 1 - pos)
     return [np.nonzero(owner == r)[0] for r in range(world)]
+
+
+class _FnBatch:
+    """A scorer function behind the Batch interface (the CPU tests inject the oracle)."""
+
+    def __init__(self, fn, args, kw):
+        self.fn, self.args, self.kw, self.out = fn, args, kw, None
+
+    def run(self):
+        self.out = self.fn(*self.args, **self.kw)
+
+    def sync(self):
+        pass
+
+    def fetch(self, per_candidate=False):
+        return self.out
+
+    def close(self):
+        pass
+
+
+class ShardedBatch1D:
+    """This rank's shard of a 1D workload, resident on its GPU, plus the exchange of results.
+
+    create: every rank passes ITS OWN reads with their global indices (`index`, positions in the
+    n_total-read workload); run(): the kernels; gather(): per-read results of ALL ranks on every
+    rank (one all_gather; rows of 4 x int64, padded to the largest shard).  A rank whose scorer
+    fails still takes part in the collective and the error is raised on all ranks afterwards.
+    """
+
+    def __init__(self, regions, reads, kmin, kmax, read_region, index, n_total, sc=None, flags=0,
+                 device=None, group=None, scorer=None):
+        import torch
+        import torch.distributed as dist
+        self.group = group
+        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.rank = dist.get_rank(group) if dist.is_initialized() else 0
+        self.index = np.asarray(index, np.int64)
+        self.n_total = int(n_total)
+        self.error = None
+        self.batch = None
+        if device is None:
+            device = self.rank if not torch.cuda.is_available() else torch.cuda.current_device()
+        try:
+            if scorer is not None:
+                self.batch = _FnBatch(scorer, (regions, reads, kmin, kmax),
+                                      dict(read_region=read_region, sc=sc, flags=flags, device=device, per_candidate=False))
+            else:
+                self.batch = _capi.Batch.create_1d(regions, reads, kmin, kmax, read_region=read_region, sc=sc,
+                                                   flags=flags, device=device)
+        except Exception as e:          # reported to every rank by gather()
+            self.error = e
+        self._dev = torch.device("cpu")
+        self.cap = len(self.index)
+        if self.world > 1:
+            if dist.get_backend(group) == "nccl":
+                self._dev = torch.device("cuda", torch.cuda.current_device())
+            sizes = torch.tensor([len(self.index)], dtype=torch.int64, device=self._dev)
+            dist.all_reduce(sizes, op=dist.ReduceOp.MAX, group=group)
+            self.cap = int(sizes.item())
+
+    def run(self):
+        if self.error is None:
+            try:
+                self.batch.run()
+            except Exception as e:
+                self.error = e
+
+    def gather(self):
+        """-> dict(best_score, sum_k, n_ties, status) for all n_total reads, on every rank."""
+        import torch
+        import torch.distributed as dist
+        n_local = len(self.index)
+        rows = np.full((self.cap + 1, 4), -1, np.int64)
+        local = None
+        if self.error is None:
+            try:
+                self.batch.sync()
+                local = self.batch.fetch(per_candidate=False)
+            except Exception as e:
+                self.error = e
+        rows[0] = (n_local, 0 if self.error is None else 1, 0, 0)
+        if local is not None and n_local:
+            rows[1:n_local + 1, 0] = self.index
+            rows[1:n_local + 1, 1] = local["best_score"]
+            rows[1:n_local + 1, 2] = local["sum_k"]
+            rows[1:n_local + 1, 3] = (local["n_ties"].astype(np.int64) << 8) | local["status"].astype(np.int64)
+        if self.world == 1:
+            parts = [rows]
+        else:
+            buf = torch.from_numpy(rows).to(self._dev)
+            gathered = [torch.empty_like(buf) for _ in range(self.world)]
+            dist.all_gather(gathered, buf, group=self.group)      # the one exchange step, un-chunked
+            parts = [g.cpu().numpy() for g in gathered]
+        failed = [r for r, p in enumerate(parts) if p[0, 1] != 0]
+        if failed:
+            raise RuntimeError(f"scoring failed on rank(s) {failed}" +
+                               (f"; this rank: {self.error}" if self.error is not None else ""))
+        out = dict(best_score=np.zeros(self.n_total, np.int32), sum_k=np.zeros(self.n_total, np.int64),
+                   n_ties=np.zeros(self.n_total, np.int32), status=np.zeros(self.n_total, np.uint8))
+        for p in parts:
+            k = int(p[0, 0])
+            idx = p[1:k + 1, 0]
+            out["best_score"][idx] = p[1:k + 1, 1]
+            out["sum_k"][idx] = p[1:k + 1, 2]
+            out["n_ties"][idx] = p[1:k + 1, 3] >> 8
+            out["status"][idx] = p[1:k + 1, 3] & 0xff
+        return out
+
+    def stats(self):
+        return self.batch.stats()
+
+    def close(self):
+        if self.batch is not None:
+            self.batch.close()
+            self.batch = None
 
 
 def round3_1d_sharded(regions, reads, kmin, kmax, read_region=None, sc=None, flags=0,
                       device=None, group=None, scorer=None):
-    """Every rank calls this with the SAME full inputs; each scores its shard on its GPU and
-    all ranks return the full per-read arrays (best_score, sum_k, n_ties, status)."""
-    import torch
+    """Every rank calls this with the SAME full inputs; each scores its region blocks on its GPU
+    and all ranks return the full per-read arrays (best_score, sum_k, n_ties, status)."""
     import torch.distributed as dist
 
     world = dist.get_world_size(group) if dist.is_initialized() else 1
     rank = dist.get_rank(group) if dist.is_initialized() else 0
-    scorer = scorer or _capi.round3_1d
     kmin = np.asarray(kmin, np.int32)
     kmax = np.asarray(kmax, np.int32)
-    n = len(reads)
-    shards = shard_reads(estimate_cells(regions, reads, kmin, kmax, read_region), world)
-    mine = shards[rank]
+    qlen = np.fromiter((len(r) for r in reads), np.int64, len(reads))
+    owner = shard_region_blocks(executed_cells(regions, qlen, kmax, read_region), read_region, world)
+    mine = np.nonzero(owner == rank)[0]
     rr = None if read_region is None else np.asarray(read_region, np.int32)[mine]
-    if device is None:
-        device = rank if not torch.cuda.is_available() else torch.cuda.current_device()
-    local = scorer(regions, [reads[i] for i in mine], kmin[mine], kmax[mine], read_region=rr,
-                   sc=sc, flags=flags, device=device, per_candidate=False)
-    packed = np.stack([mine.astype(np.int64), local["best_score"].astype(np.int64),
-                       local["sum_k"].astype(np.int64), local["n_ties"].astype(np.int64),
-                       local["status"].astype(np.int64)], 1)
-    out = dict(best_score=np.zeros(n, np.int32), sum_k=np.zeros(n, np.int64),
-               n_ties=np.zeros(n, np.int32), status=np.zeros(n, np.uint8))
-    if world == 1:
-        parts = [packed]
-    else:
-        # one un-chunked all_gather, padded to the largest shard (rows of 5 x int64 = 40 B/read)
-        backend = dist.get_backend(group)
-        dev = torch.device("cuda", torch.cuda.current_device()) if backend == "nccl" else torch.device("cpu")
-        cap = max(len(s) for s in shards)
-        buf = torch.full((cap, 5), -1, dtype=torch.int64, device=dev)
-        if len(mine):
-            buf[:len(mine)] = torch.from_numpy(packed).to(dev)
-        gathered = [torch.empty_like(buf) for _ in range(world)]
-        dist.all_gather(gathered, buf, group=group)
-        parts = [g.cpu().numpy()[:len(shards[r])] for r, g in enumerate(gathered)]
-    for p in parts:
-        idx = p[:, 0]
-        out["best_score"][idx] = p[:, 1]
-        out["sum_k"][idx] = p[:, 2]
-        out["n_ties"][idx] = p[:, 3]
-        out["status"][idx] = p[:, 4]
-    return out
+    sb = ShardedBatch1D(regions, [reads[i] for i in mine], kmin[mine], kmax[mine], rr, mine, len(reads),
+                        sc=sc, flags=flags, device=device, group=group, scorer=scorer)
+    try:
+        sb.run()
+        return sb.gather()
+    finally:
+        sb.close()
 
 
 def estimate_cells_2d(region, reads, cell_read, cell_k1, cell_k2):
@@ -120,25 +278,36 @@ def joint_2d_sharded(region, reads, cell_read, cell_k1, cell_k2, read_strand=Non
     st_in = None if read_strand is None else np.asarray(read_strand, np.int8)[mine]
     if device is None:
         device = rank if not torch.cuda.is_available() else torch.cuda.current_device()
-    local = scorer(region, [reads[i] for i in mine], new_index[cr][keep][order].astype(np.int32), k1[keep][order],
-                   k2[keep][order], read_strand=st_in, sc=sc, flags=flags, device=device)
     cols = ("read_strand", "best_wscore", "sum_k1", "sum_k2", "n_ties", "status")
-    packed = np.stack([mine.astype(np.int64)] + [np.asarray(local[c]).astype(np.int64) for c in cols], 1)
+    error, local = None, None
+    try:
+        local = scorer(region, [reads[i] for i in mine], new_index[cr][keep][order].astype(np.int32), k1[keep][order],
+                       k2[keep][order], read_strand=st_in, sc=sc, flags=flags, device=device)
+    except Exception as e:              # still take part in the collective; raised on all ranks below
+        error = e
+    cap = max(len(s) for s in shards)
+    rows = np.full((cap + 1, 1 + len(cols)), -1, np.int64)
+    rows[0, :2] = (len(mine), 0 if error is None else 1)
+    if local is not None and len(mine):
+        rows[1:len(mine) + 1, 0] = mine
+        for j, c in enumerate(cols):
+            rows[1:len(mine) + 1, 1 + j] = np.asarray(local[c]).astype(np.int64)
     if world == 1:
-        parts = [packed]
+        parts = [rows]
     else:
         backend = dist.get_backend(group)
         dev = torch.device("cuda", torch.cuda.current_device()) if backend == "nccl" else torch.device("cpu")
-        cap = max(len(s) for s in shards)
-        buf = torch.full((cap, 1 + len(cols)), -1, dtype=torch.int64, device=dev)
-        if len(mine):
-            buf[:len(mine)] = torch.from_numpy(packed).to(dev)
+        buf = torch.from_numpy(rows).to(dev)
         gathered = [torch.empty_like(buf) for _ in range(world)]
         dist.all_gather(gathered, buf, group=group)
-        parts = [g.cpu().numpy()[:len(shards[r])] for r, g in enumerate(gathered)]
+        parts = [g.cpu().numpy() for g in gathered]
+    failed = [r for r, p in enumerate(parts) if p[0, 1] != 0]
+    if failed:
+        raise RuntimeError(f"joint scoring failed on rank(s) {failed}" + (f"; this rank: {error}" if error is not None else ""))
     out = dict(read_strand=np.zeros(n, np.int8), best_wscore=np.zeros(n, np.int32), sum_k1=np.zeros(n, np.int64),
                sum_k2=np.zeros(n, np.int64), n_ties=np.zeros(n, np.int32), status=np.zeros(n, np.uint8))
     for p in parts:
+        k = int(p[0, 0])
         for j, c in enumerate(cols):
-            out[c][p[:, 0]] = p[:, 1 + j]
+            out[c][p[1:k + 1, 0]] = p[1:k + 1, 1 + j]
     return out

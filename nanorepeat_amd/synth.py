@@ -97,6 +97,47 @@ def make_1d(n_reads, unit, alleles, model="ont", kwin=None, flank=100, anchor=10
                 read_region=None, k_true=np.array(kt, np.int32))
 
 
+def apply_errors_batch(rng, seqs, model):
+    """apply_errors over many sequences in one vectorised pass (same channel, its own draw order)."""
+    sub, ins, dele = ERROR_MODELS[model] if isinstance(model, str) else model
+    lens = np.fromiter((len(x) for x in seqs), np.int64, len(seqs))
+    a = np.frombuffer("".join(seqs).encode(), dtype=np.uint8)
+    n = len(a)
+    owner = np.repeat(np.arange(len(seqs)), lens)
+    u = rng.random(n)
+    keep = u >= dele
+    do_sub = keep & (u < dele + sub)
+    b = a.copy()
+    if do_sub.any():
+        idx = np.searchsorted(_BASES, b[do_sub])
+        b[do_sub] = _BASES[(idx + rng.integers(1, 4, size=int(do_sub.sum()))) % 4]
+    do_ins = rng.random(n) < ins
+    out = np.empty(2 * n, dtype=np.uint8)
+    mask = np.zeros(2 * n, dtype=bool)
+    out[0::2] = b
+    mask[0::2] = keep
+    out[1::2] = _BASES[rng.integers(0, 4, size=n)]
+    mask[1::2] = do_ins
+    new_len = np.bincount(np.repeat(owner, 2)[mask], minlength=len(seqs))
+    text = out[mask].tobytes().decode()
+    off = np.r_[0, np.cumsum(new_len)]
+    return [text[off[i]:off[i + 1]] for i in range(len(seqs))]
+
+
+def make_1d_batch(n_reads, unit, alleles, model, rng, flank=100, anchor=1000, fast_mode=False):
+    """make_1d with the reference window rule, generated in one vectorised pass (config 4 needs a
+    million reads)."""
+    left, right = rand_seq(rng, anchor), rand_seq(rng, anchor)
+    kt = np.asarray(alleles, np.int32)[rng.integers(0, len(alleles), size=n_reads)]
+    cores = {int(k): left[len(left) - flank:] + unit * int(k) + right[:flank] for k in set(kt.tolist())}
+    reads = apply_errors_batch(rng, [cores[int(k)] for k in kt], model)
+    r2 = np.maximum(0.0, kt + rng.normal(0.0, 1.0, size=n_reads))
+    buf = np.full(n_reads, 15.0) if fast_mode else np.clip(np.floor(r2 * 0.05), 15, 150)    # reference_window, vectorised
+    kmin = np.maximum(np.trunc(r2 - buf), 0).astype(np.int32)
+    kmax = np.trunc(r2 + buf).astype(np.int32)
+    return dict(regions=[(left, unit, right)], reads=reads, kmin=kmin, kmax=kmax, read_region=None, k_true=kt)
+
+
 def config2(n_reads=10000, seed=SEED):
     """BASELINE config 2: 10k ONT-error reads, motif TATTG, k in [5,200], alleles 40/150."""
     return make_1d(n_reads, "TATTG", (40, 150), "ont", kwin=(5, 200), seed=seed)
@@ -107,22 +148,47 @@ def config5(n_reads=1000, seed=SEED):
     return make_1d(n_reads, "TATTG", (60, 420), "hifi", kwin=(5, 500), seed=seed)
 
 
-def config4(n_regions=1000, reads_per_region=1000, seed=SEED):
-    """BASELINE config 4: many regions, mixed 3-6 bp motifs, reference window rule."""
-    rng = np.random.default_rng(seed)
-    regions, reads, rr, kt = [], [], [], []
+def config4_region(g, seed=SEED):
+    """Descriptor of region g of config 4 (no reads): motif, the two alleles and the generator that
+    continues into the flanks and reads, so that any rank can materialise any subset of regions."""
+    rng = np.random.default_rng([seed, g])
+    m = int(rng.integers(3, 7))
+    unit = rand_unit(rng, m)
+    alleles = (int(rng.integers(10, 121)), int(rng.integers(10, 121)))
+    return dict(m=m, unit=unit, alleles=alleles, rng=rng)
+
+
+def config4_region_cost(desc, reads_per_region, flank=100, anchor=1000):
+    """Expected executed cells of a region (what a shard costs; see dist.executed_cells), from its
+    descriptor alone: error-free core length and the reference window around each allele."""
+    from .dist import padded_rows
+    cost = 0
+    for a in desc["alleles"]:
+        q = 2 * flank + desc["m"] * a
+        cost += int(padded_rows(q)) * (2 * anchor + desc["m"] * reference_window(float(a))[1] + 254)
+    return cost * reads_per_region // len(desc["alleles"])
+
+
+def config4(n_regions=1000, reads_per_region=1000, seed=SEED, only=None):
+    """BASELINE config 4: many regions, mixed 3-6 bp motifs, reference window rule.  `only`: the
+    region numbers to materialise (a rank's shard); read_region then indexes the returned list and
+    `region_id` / `read_id` give the global numbering (read_id = region * reads_per_region + i)."""
+    ids = range(n_regions) if only is None else sorted(int(g) for g in only)
+    regions, reads, rr, kt, gid, rid = [], [], [], [], [], []
     kmins, kmaxs = [], []
-    for g in range(n_regions):
-        m = int(rng.integers(3, 7))
-        unit = rand_unit(rng, m)
-        alleles = (int(rng.integers(10, 121)), int(rng.integers(10, 121)))
-        d = make_1d(reads_per_region, unit, alleles, "ont_q20", rng=rng)
+    for j, g in enumerate(ids):
+        desc = config4_region(g, seed)
+        d = make_1d_batch(reads_per_region, desc["unit"], desc["alleles"], "ont_q20", desc["rng"])
         regions.append(d["regions"][0])
         reads += d["reads"]
-        rr += [g] * reads_per_region
+        rr.append(np.full(reads_per_region, j, np.int32))
+        gid.append(g)
+        rid.append(g * reads_per_region + np.arange(reads_per_region, dtype=np.int64))
         kmins.append(d["kmin"]); kmaxs.append(d["kmax"]); kt.append(d["k_true"])
-    return dict(regions=regions, reads=reads, kmin=np.concatenate(kmins), kmax=np.concatenate(kmaxs),
-                read_region=np.array(rr, np.int32), k_true=np.concatenate(kt))
+    cat = lambda v, dt: np.concatenate(v) if v else np.zeros(0, dt)
+    return dict(regions=regions, reads=reads, kmin=cat(kmins, np.int32), kmax=cat(kmaxs, np.int32),
+                read_region=cat(rr, np.int32), k_true=cat(kt, np.int32),
+                region_id=np.array(gid, np.int64), read_id=cat(rid, np.int64))
 
 
 def make_joint(n_reads, unit1="CAG", unit2="CCG", mid="CAACAGCCGCCAC",

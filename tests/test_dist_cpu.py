@@ -101,6 +101,87 @@ def test_joint_sharded_equals_single_process(oracle):
         assert one[k].tolist() == want[k].tolist(), k
 
 
+def _worker_regions(rank, world, port, q, fail_rank):
+    sys.path.insert(0, ROOT)
+    import torch.distributed as dist
+    from nanorepeat_amd import dist as D, synth
+    from oracle import oracle as O
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        d = synth.config4(5, 6, seed=11)
+
+        def scorer(*a, **k):
+            if rank == fail_rank:
+                raise ValueError("boom")
+            return O.round3_1d(*a, threads=1, **k)
+        try:
+            out = D.round3_1d_sharded(d["regions"], d["reads"], d["kmin"], d["kmax"], read_region=d["read_region"],
+                                      scorer=scorer)
+            q.put((rank, {k: v.tolist() for k, v in out.items()}))
+        except RuntimeError as e:
+            q.put((rank, "error: " + str(e)))
+    finally:
+        dist.destroy_process_group()
+
+
+def _run_regions(fail_rank):
+    world, port = 2, 37500 + os.getpid() % 2000 + (0 if fail_rank < 0 else 7)
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker_regions, args=(r, world, port, q, fail_rank)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = dict(q.get(timeout=240) for _ in range(world))
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    return res
+
+
+@pytest.mark.timeout(300)
+def test_region_block_sharding_equals_single_process(oracle):
+    """Many regions: region blocks dealt by executed cells over two ranks (gloo) == one process."""
+    from nanorepeat_amd import synth
+    res = _run_regions(-1)
+    d = synth.config4(5, 6, seed=11)
+    want = oracle.round3_1d(d["regions"], d["reads"], d["kmin"], d["kmax"], read_region=d["read_region"])
+    for r in range(2):
+        for k in ("best_score", "sum_k", "n_ties", "status"):
+            assert res[r][k] == want[k].tolist(), (r, k)
+
+
+@pytest.mark.timeout(300)
+def test_scorer_failure_on_one_rank_raises_on_all_ranks():
+    """A rank whose scorer raises still joins the all_gather; every rank then raises (no hang)."""
+    res = _run_regions(1)
+    assert all(isinstance(v, str) and "rank(s) [1]" in v for v in res.values()), res
+
+
+def test_region_block_sharder_properties():
+    from nanorepeat_amd import dist as D
+    rng = np.random.default_rng(3)
+    # 40 regions of very different sizes, reads interleaved in the input
+    rr = rng.integers(0, 40, size=5000)
+    cost = rng.integers(1000, 9000, size=5000) * (1 + rr % 5)
+    for world in (1, 2, 4, 8):
+        owner = D.shard_region_blocks(cost, rr, world)
+        assert owner.shape == (5000,) and owner.min() >= 0 and owner.max() < world
+        loads = np.bincount(owner, weights=cost, minlength=world)
+        assert loads.max() <= 1.15 * loads.mean()
+        # a region is cut into few blocks: its reads land on few ranks, in input-order runs
+        for g in (0, 7, 39):
+            o = owner[rr == g]
+            assert (np.diff(o) != 0).sum() <= 2 * world
+    # one region, many ranks (config 2 strong scaling): still balanced
+    owner = D.shard_region_blocks(np.full(1000, 7), None, 8)
+    assert np.bincount(owner, minlength=8).min() >= 100
+    # executed-cell cost: padded rows x executed columns
+    cells = D.executed_cells([("A" * 10, "CAG", "T" * 7)], [5, 65, 3073], [4, 4, 4])
+    assert cells.tolist() == [64 * (17 + 12 + 254), 128 * (17 + 12 + 254), 3 * 1536 * (17 + 12 + 254)]
+
+
 def test_shard_reads_is_a_balanced_partition():
     from nanorepeat_amd import dist as D
     rng = np.random.default_rng(0)

@@ -269,8 +269,9 @@ def test_config2_full_size_properties(capi, oracle, config2_run):
     # extents were produced exactly for the top-score ties
     ties = sc == g["best_score"][:, None]
     assert np.array_equal(g["cand_tstart"].reshape(n, 196) >= 0, ties)
-    # a seeded sample of reads against the oracle at full problem size
-    pick = np.random.default_rng(1).choice(n, 12, replace=False)
+    # a seeded sample of reads -- 128 of either allele -- against the oracle at full problem size
+    rng = np.random.default_rng(1)
+    pick = np.concatenate([rng.choice(np.nonzero(d["k_true"] == a)[0], 128, replace=False) for a in (40, 150)])
     o = oracle.round3_1d(d["regions"], [d["reads"][i] for i in pick], d["kmin"][pick], d["kmax"][pick])
     for k in ("best_score", "sum_k", "n_ties", "status"):
         assert np.array_equal(g[k][pick], o[k]), k
