@@ -1471,6 +1471,8 @@ int nra_align_pairs_cigar(int device, int32_t n_seqs, const char* seqs, const in
 }
 
 // ---- common -------------------------------------------------------------------------
+static int account_run(nra_batch* b);
+
 int nra_batch_run(nra_batch_t* b)
 {
     if (!b) return fail(NRA_E_ARG, "batch is NULL");
