@@ -53,6 +53,8 @@ extern "C" {
                                  without it only ties whose flank verdict is ambiguous are re-run */
 #define NRA_F_TEST_CHAIN   8  /* testing only: sweep every read in chained 128-row blocks (the mechanism reads
                                  longer than 3072 bases use with 1536-row blocks) */
+#define NRA_F_DPP_SWEEP    16 /* testing / comparison: sweep unchained reads with k_sweep_pk16 (DPP hand-off, combine on
+                                 every step) instead of k_sweep_ring (LDS hand-off, combine on every m-th step) */
 #define NRA_F_BRUTE_FORCE  4  /* score the K candidates of a read as K independent alignments
                                  (k_score_pk16) instead of the junction decomposition (k_sweep_pk16) */
 

@@ -217,6 +217,7 @@ struct Bucket {
     size_t queue_cap = 0;      // capacity of this bucket's queue region
     int n_sweep = 0;           // junction-decomposition tasks (pairs of reads)
     size_t sweep_off = 0;
+    bool ring = false;         // k_sweep_ring (LDS hand-off) instead of k_sweep_pk16 (DPP hand-off)
     int n_jbwd = 0;            // 2D decomposition: reverse sweeps (one per read)
     size_t jbwd_off = 0;
     int64_t cells_pair = 0;    // executed cells per run, pk16
@@ -639,6 +640,11 @@ int nra_batch1d_create(int device, const nra_region_t* regions, int32_t n_region
                 return pr.reads[x].qlen > pr.reads[y].qlen;
             });
             bk.sweep_off = sweep_tasks.size();
+            // the LDS-ring sweeps hold unit lengths up to NRA_SWEEP_RING_MAX_M; a bucket with a longer unit
+            // (and chained reads) keeps the DPP sweeps
+            bk.ring = !bk.chain && (flags & NRA_F_DPP_SWEEP) == 0;
+            for (int32_t r : order)
+                if (dregs[pr.reads[r].region].m1 > NRA_SWEEP_RING_MAX_M) bk.ring = false;
             for (size_t i = 0; i < order.size();) {
                 NraSweepTask t{};
                 t.read_a = order[i]; t.read_b = -1;
@@ -656,8 +662,11 @@ int nra_batch1d_create(int device, const nra_region_t* regions, int32_t n_region
                 if (t.read_b >= 0) qmax = std::max(qmax, pr.reads[t.read_b].qlen);
                 const int nblk = bk.chain ? (qmax + 64 * bk.R - 1) / (64 * bk.R) : 1;
                 // chained reads sweep rev(unit)^kmax for A_k; the others stop at the end of rev(R)
-                bk.cells_sweep += (int64_t)nblk * 2 * (sweep128_cells(bk.R, d.l1 + d.m1 * t.kmax) +
-                                                       sweep128_cells(bk.R, d.l3 + (bk.chain ? d.m1 * t.kmax : 0)));
+                if (bk.ring)    // pipelines 64*m (forward) and 64 (reverse) columns deep
+                    bk.cells_sweep += 2 * (int64_t)64 * bk.R * ((d.l1 + d.m1 * t.kmax + 63 * d.m1) + (d.l3 + 63));
+                else
+                    bk.cells_sweep += (int64_t)nblk * 2 * (sweep128_cells(bk.R, d.l1 + d.m1 * t.kmax) +
+                                                           sweep128_cells(bk.R, d.l3 + (bk.chain ? d.m1 * t.kmax : 0)));
                 t.snap_off = snap_total;
                 snap_total += (uint64_t)nblk * 3 * bk.R * 64;
                 sweep_tasks.push_back(t);
@@ -762,17 +771,28 @@ static int run_1d(nra_batch* b)
             hipStream_t q = b->bstreams[i];
             HIP_TRY(hipStreamWaitEvent(q, b->fork_ev, 0));
             HIP_TRY(hipEventRecord(b->ev[ev++], q));
-            LAUNCH_TRY(nra_launch_sweep_bwd(bk.R, b->has_n, bk.chain ? 1 : 0, q, bk.n_sweep, b->sweep_tasks.p + bk.sweep_off,
-                                            b->reads.p, b->regions.p, b->pool.p, b->q2bit.p, b->qnmask.p, b->sp,
-                                            b->kmin.p, b->kmax.p, b->coff.p, b->snap.p,
-                                            b->arr_a.p, b->read_a1d.p, b->chain_sweep.p, b->chain_cap));
+            if (bk.ring)
+                LAUNCH_TRY(nra_launch_sweep_ring_bwd(bk.R, b->has_n, q, bk.n_sweep, b->sweep_tasks.p + bk.sweep_off,
+                                                     b->reads.p, b->regions.p, b->pool.p, b->q2bit.p, b->qnmask.p, b->sp,
+                                                     b->kmin.p, b->kmax.p, b->coff.p, b->snap.p, b->read_a1d.p));
+            else
+                LAUNCH_TRY(nra_launch_sweep_bwd(bk.R, b->has_n, bk.chain ? 1 : 0, q, bk.n_sweep, b->sweep_tasks.p + bk.sweep_off,
+                                                b->reads.p, b->regions.p, b->pool.p, b->q2bit.p, b->qnmask.p, b->sp,
+                                                b->kmin.p, b->kmax.p, b->coff.p, b->snap.p,
+                                                b->arr_a.p, b->read_a1d.p, b->chain_sweep.p, b->chain_cap));
             HIP_TRY(hipEventRecord(b->ev[ev++], q));
             HIP_TRY(hipEventRecord(b->ev[ev++], q));
-            LAUNCH_TRY(nra_launch_sweep_fwd(bk.R, b->has_n, bk.chain ? 1 : 0, q, bk.n_sweep, b->sweep_tasks.p + bk.sweep_off,
-                                            b->reads.p, b->regions.p, b->pool.p, b->q2bit.p, b->qnmask.p, b->sp,
-                                            b->kmin.p, b->kmax.p, b->coff.p, b->snap.p,
-                                            b->arr_a.p, b->read_a1d.p, b->cand_score.p, b->cand_flag.p,
-                                            b->chain_sweep.p, b->chain_cap));
+            if (bk.ring)
+                LAUNCH_TRY(nra_launch_sweep_ring_fwd(bk.R, b->has_n, q, bk.n_sweep, b->sweep_tasks.p + bk.sweep_off,
+                                                     b->reads.p, b->regions.p, b->pool.p, b->q2bit.p, b->qnmask.p, b->sp,
+                                                     b->kmin.p, b->kmax.p, b->coff.p, b->snap.p, b->read_a1d.p,
+                                                     b->cand_score.p, b->cand_flag.p));
+            else
+                LAUNCH_TRY(nra_launch_sweep_fwd(bk.R, b->has_n, bk.chain ? 1 : 0, q, bk.n_sweep, b->sweep_tasks.p + bk.sweep_off,
+                                                b->reads.p, b->regions.p, b->pool.p, b->q2bit.p, b->qnmask.p, b->sp,
+                                                b->kmin.p, b->kmax.p, b->coff.p, b->snap.p,
+                                                b->arr_a.p, b->read_a1d.p, b->cand_score.p, b->cand_flag.p,
+                                                b->chain_sweep.p, b->chain_cap));
             HIP_TRY(hipEventRecord(b->ev[ev++], q));
             b->n_score_ev += 2;
             HIP_TRY(hipEventRecord(b->bdone[i], q));

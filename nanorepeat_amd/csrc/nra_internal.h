@@ -152,6 +152,21 @@ int nra_launch_sweep_fwd(int R, int has_n, int chain, hipStream_t st, int n_task
                          int32_t* read_a, int32_t* cand_score, uint8_t* cand_flag, int32_t* chain_buf,
                          int chain_cap);
 
+// the same sweeps with the lane-to-lane hand-off through an LDS ring (k_sweep_ring: one read block per wave,
+// forward sweep skewed by the unit length so that the junction combine runs on every m-th step only);
+// unchained reads, unit length <= NRA_SWEEP_RING_MAX_M
+#define NRA_SWEEP_RING_MAX_M 8
+int nra_launch_sweep_ring_bwd(int R, int has_n, hipStream_t st, int n_tasks, const NraSweepTask* tasks,
+                              const NraDevRead* reads, const NraDevRegion* regions, const uint8_t* pool,
+                              const uint32_t* q2bit, const uint32_t* qnmask, NraScoreParams sp,
+                              const int32_t* kmin, const int32_t* kmax, const uint32_t* coff,
+                              int32_t* snap, int32_t* read_a);
+int nra_launch_sweep_ring_fwd(int R, int has_n, hipStream_t st, int n_tasks, const NraSweepTask* tasks,
+                              const NraDevRead* reads, const NraDevRegion* regions, const uint8_t* pool,
+                              const uint32_t* q2bit, const uint32_t* qnmask, NraScoreParams sp,
+                              const int32_t* kmin, const int32_t* kmax, const uint32_t* coff,
+                              int32_t* snap, int32_t* read_a, int32_t* cand_score, uint8_t* cand_flag);
+
 // 2D junction decomposition (nra_joint.hip)
 int nra_launch_joint_bwd(int R, int has_n, hipStream_t st, int n_tasks, const NraJointTask* tasks,
                          const NraDevRead* reads, const NraDevRegion* regions, const uint8_t* pool,

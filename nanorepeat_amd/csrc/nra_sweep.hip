@@ -453,6 +453,216 @@ __global__ __launch_bounds__(WAVE) void k_sweep_pk16(int n_tasks, const NraSweep
 }
 
 // ------------------------------------------------------------------------------------
+// k_sweep_ring: the same sweep with the lane-to-lane hand-off through an LDS ring.
+//
+// Lane l owns all R rows of its row block as ONE systolic cell and works on column t - skew*l at step t.
+// What a cell leaves for the cell below -- H of its last row, the two vertical-gap states and the template
+// column itself (its substitution table) -- is one 16-byte LDS write into the next lane's place of slot
+// (t mod skew); the lane below reads it `skew` steps later (a wave's LDS operations execute in order, and
+// every lane reads its place of a slot before any lane writes it again: no barrier).  Lane 63 also writes
+// lane 0's place: the constants that enter row 0 and the next template column.
+//
+// skew = 1 for the reverse sweep.  The forward sweep uses skew = m, the unit length: then ALL lanes sit on
+// a unit boundary in the same steps -- every m-th -- and the junction combine, the only work that is not
+// the DP recurrence, runs under a wave-uniform branch 1/m of the time instead of on every step (with the
+// 128 columns in flight of k_sweep_pk16 some lane is always on a boundary).  The per-boundary accumulators
+// S and B travel through a second, one-slot LDS array on those steps only.  Price: the pipeline is 64*m
+// columns deep instead of 128.  No DPP moves, one cell per lane: ~12 instead of ~35 instructions of
+// per-step overhead.  (m <= SWEEP_RING_D; other regions and chained reads use k_sweep_pk16.)
+#define SWEEP_RING_D NRA_SWEEP_RING_MAX_M
+
+template <int R, bool HAS_N, int DIR>
+__global__ __launch_bounds__(WAVE) void k_sweep_ring(int n_tasks, const NraSweepTask* __restrict__ tasks,
+                                                     const NraDevRead* __restrict__ reads,
+                                                     const NraDevRegion* __restrict__ regions,
+                                                     const uint8_t* __restrict__ pool,
+                                                     const uint32_t* __restrict__ q2bit,
+                                                     const uint32_t* __restrict__ qnmask,
+                                                     NraScoreParams sp,
+                                                     const int32_t* __restrict__ kmin_arr,
+                                                     const int32_t* __restrict__ kmax_arr,
+                                                     const uint32_t* __restrict__ coff,
+                                                     int32_t* __restrict__ snap,
+                                                     int32_t* __restrict__ read_a,
+                                                     int32_t* __restrict__ cand_score,
+                                                     uint8_t* __restrict__ cand_flag)
+{
+    constexpr int SC = 2;                 // origin-bit scheme: doubled scores
+    __shared__ int4 ring[SWEEP_RING_D * 64];
+    __shared__ int2 racc[64];
+    const int task = blockIdx.x;
+    if (task >= n_tasks) return;
+    const int lane = threadIdx.x;
+    const NraSweepTask tk = tasks[task];
+    const bool has_b = tk.read_b >= 0;
+    const int ra = tk.read_a, rb = has_b ? tk.read_b : tk.read_a;
+    const NraDevRead rda = reads[ra], rdb = reads[rb];
+    const NraDevRegion rg = regions[rda.region];
+    const int m = rg.m1;
+    const int flank = DIR ? rg.l1 : rg.l3;
+    const uint8_t* __restrict__ piece = pool + (DIR ? rg.p1_off : rg.pr_off);
+    const int ncols = DIR ? flank + m * tk.kmax : flank;
+    const int jfirst = DIR ? flank + m * tk.kmin - 1 : flank - 1;     // boundary column of k = kmin
+    const int skew = DIR ? m : 1;
+    const int kmin_a = kmin_arr[ra], kmax_a = kmax_arr[ra];
+    const int kmin_b = kmin_arr[rb], kmax_b = kmax_arr[rb];
+    const uint32_t coff_a = coff[ra], coff_b = coff[rb];
+    int32_t* __restrict__ snap_task = snap + tk.snap_off;
+
+    const int o1 = SC * sp.open1, o2 = SC * sp.open2;
+    const int P1 = 0x00010001;
+    const int v_floor = (BIAS - o1) * P1;
+    const int v_o1 = o1 * P1, v_e1 = SC * sp.ext1 * P1, v_o2 = o2 * P1, v_e2 = SC * sp.ext2 * P1;
+    const int NEG1 = NEGB * P1, NEG2 = 2 * NEGB * P1;
+    const int s_match = SC * sp.match + o1, s_mis = o1 - SC * sp.mismatch, s_ambi = o1 - SC * sp.ambi;
+    const int tbl_hi = s_mis | (s_ambi << 8);
+    const int tbl_mis4 = s_mis * 0x01010101, tbl_ambi4 = s_ambi * 0x01010101;
+
+    // the substitution table (+ flags) of template column `col`; padding outside the template
+    auto column_table = [&](int col) {
+        int t = tbl_mis4;
+        if (col >= 0 && col < ncols) {
+            const int code = piece[col];
+            t = code < 4 ? tbl_mis4 + ((s_match - s_mis) << (8 * code)) : tbl_ambi4;
+            if (DIR == 0 && col == flank - 1) t |= FLAG_SNAPSHOT;
+            if (DIR == 1 && col >= flank) t |= FLAG_INREP;
+        }
+        return t;
+    };
+
+    int out_a = 0, out_b = 0;
+    int n_out = 0, kcur = tk.kmin;                          // wave-uniform
+    auto flush = [&](int n_valid) {
+        const int k = kcur - 64 + lane;
+        if (lane < 64 - n_valid) return;
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2) {
+            if (s2 == 1 && !has_b) break;
+            const int lo_k = s2 ? kmin_b : kmin_a, hi_k = s2 ? kmax_b : kmax_a;
+            if (k < lo_k || k > hi_k) continue;
+            const uint32_t idx = (s2 ? coff_b : coff_a) + (uint32_t)(k - lo_k);
+            const int v = s2 ? out_b : out_a;
+            cand_score[idx] = v >> 2;
+            cand_flag[idx] = (uint8_t)(v & 3);
+        }
+    };
+
+    int qc[R];
+#pragma unroll
+    for (int i = 0; i < R; ++i) {
+        const int gi = lane * R + i;
+        const int ca = sweep_query_sel<HAS_N>(rda, q2bit, qnmask, gi, DIR == 0);
+        const int cb = sweep_query_sel<HAS_N>(rdb, q2bit, qnmask, gi, DIR == 0);
+        qc[i] = ca | (0x0c << 8) | (cb << 16) | (0x0c << 24);
+    }
+    int Hbo[DIR ? R : 1], Ebo[DIR ? R : 1], E2bo[DIR ? R : 1];
+    if (DIR) {
+        const int q1 = SC * (sp.open1 - sp.ext1), q2 = SC * (sp.open2 - sp.ext2);
+#pragma unroll
+        for (int i = 0; i < R; ++i) {
+            const int r = lane * R + i;
+            int h[2], e[2], e2[2];
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+                const int a = (s ? rdb.qlen : rda.qlen) - 2 - r;
+                if (a >= 0) {
+                    const int al = a / R, ai = a - al * R;
+                    const int32_t* __restrict__ p = snap_task + (size_t)ai * 64 + al;
+                    const int vh = p[0], ve = p[R * 64], ve2 = p[2 * R * 64];
+                    h[s] = (s ? half_hi(vh) : half_lo(vh)) + 2 * o1;
+                    e[s] = (s ? half_hi(ve) : half_lo(ve)) + q1;
+                    e2[s] = (s ? half_hi(ve2) : half_lo(ve2)) + q2;
+                } else { h[s] = BIAS + o1 - SC; e[s] = BIAS - SC; e2[s] = BIAS - SC; }
+            }
+            Hbo[i] = pack2(h[0], h[1]);
+            Ebo[i] = pack2(e[0], e[1]);
+            E2bo[i] = pack2(e2[0], e2[1]);
+        }
+    }
+    int Hq[R], Hq2[R], E[R], E2[R];
+#pragma unroll
+    for (int i = 0; i < R; ++i) { Hq[i] = v_floor; Hq2[i] = NEG1; E[i] = NEG1; E2[i] = NEG1; }
+
+    // ring: padding columns everywhere, then lane 0's first `skew` columns
+#pragma unroll
+    for (int s = 0; s < SWEEP_RING_D; ++s) ring[s * 64 + lane] = make_int4(v_floor, NEG1, NEG1, tbl_mis4);
+    racc[lane] = make_int2(NEG2, NEG1);
+    if (lane < skew) ring[lane * 64] = make_int4(v_floor, NEG1, NEG1, column_table(lane));
+
+    int Hup_prev = v_floor, M = BIAS * P1;
+    int feed = tbl_mis4;
+    const int nsteps = ncols + 63 * skew;                   // lane 63 finishes the last column at step ncols - 1 + 63*skew
+    const int wr = (lane + 1) & 63;
+    int slot = 0;                                           // step mod skew
+    int phase = jfirst % m;                                 // boundary steps: step mod m == phase, step >= jfirst
+    int pcnt = 0;                                           // step mod m
+    int bidx = 0;                                           // boundary steps so far
+#pragma unroll 1
+    for (int step = 0; step < nsteps; ++step) {
+        if ((step & 63) == 0) feed = column_table(step + skew + wr);      // lane 63 hands out column step + skew
+        const int4 in = ring[slot * 64 + lane];
+        int F = in.y, F2 = in.z;
+        const int tt = in.w;
+        const int floor_c = DIR == 1 ? (int)((((unsigned)tt >> 15) & (unsigned)P1) | (unsigned)v_floor) : v_floor;
+        sweep_cell<0, R, R>(Hq, Hq2, E, E2, qc, Hup_prev, F, F2, M, tt & 0x7f7f7f7f, tbl_hi, floor_c, v_e1, v_e2, v_o1, v_o2);
+        Hup_prev = in.x;
+        ring[slot * 64 + wr] = make_int4(Hq[R - 1], F, F2, tt);
+        if (lane == 63) ring[slot * 64] = make_int4(v_floor, NEG1, NEG1, feed);
+        feed = dpp_rol1(feed);
+        if (++slot == skew) slot = 0;
+
+        if constexpr (DIR == 0) {
+            if (tt & FLAG_SNAPSHOT) sweep_snapshot<0, R, R>(Hq, E, E2, snap_task, lane);
+        } else {
+            if (pcnt == phase && step >= jfirst) {          // every lane is on a unit boundary: wave-uniform
+                const int tS = sweep_combine<0, R, R>(Hq, E, E2, Hbo, Ebo, E2bo, NEG2);
+                const int2 acc = racc[lane];
+                const int accS = pmaxi(acc.x, tS), accB = pmaxi(acc.y, M);
+                racc[wr] = make_int2(accS, accB);
+                if (lane == 63) racc[0] = make_int2(NEG2, NEG1);
+                if (bidx >= 63 && kcur <= tk.kmax) {        // lane 63 is on the boundary of k = kcur
+                    int va = 0, vb = 0;
+                    if (lane == 63) {
+#pragma unroll
+                        for (int s2 = 0; s2 < 2; ++s2) {
+                            const int B = (s2 ? half_hi(accB) : half_lo(accB)) - BIAS;
+                            const int S = (s2 ? half_hi(accS) : half_lo(accS)) - 2 * BIAS;
+                            const int lo = sp.min_score > 1 ? sp.min_score : 1;
+                            // packed 2*score + origin bit; an alignment inside R starts at a column >= |L|
+                            const int V = imax(imax(S, B), read_a[s2 ? rb : ra] + 1);
+                            const int best = V >> 1;
+                            int flag = 1;
+                            if (V & 1) flag = 0;                                  // an optimal alignment starts at >= |L|
+                            else if ((B >> 1) >= best) flag = ((S >> 1) >= best) ? 2 : 0;
+                            const int v = ((best >= lo ? best : -1) << 2) | flag;
+                            if (s2) vb = v; else va = v;
+                        }
+                    }
+                    out_a = dpp_rol1(out_a); out_b = dpp_rol1(out_b);
+                    if (lane == 63) { out_a = va; out_b = vb; }
+                    ++kcur; ++n_out;
+                    if (n_out == 64) { flush(64); n_out = 0; }
+                }
+                ++bidx;
+            }
+            if (++pcnt == m) pcnt = 0;
+        }
+    }
+    if (DIR == 0) {
+        // the short reverse sweep ends on its one boundary, R[0]: A = best alignment inside R (doubled)
+        // = the maximum over every cell of the sweep
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) M = pmaxi(M, __shfl_xor(M, off, 64));
+        if (lane == 0) {
+            read_a[ra] = half_lo(M) - BIAS;
+            if (has_b) read_a[rb] = half_hi(M) - BIAS;
+        }
+    } else if (n_out > 0) {
+        flush(n_out);
+    }
+}
+
+// ------------------------------------------------------------------------------------
 // launchers
 // ------------------------------------------------------------------------------------
 template <int DIR>
@@ -488,6 +698,52 @@ static int launch_sweep(int R, int has_n, int chain, hipStream_t st, int n_tasks
 #undef ARGS
     return (int)hipGetLastError();
 }
+
+template <int DIR>
+static int launch_sweep_ring(int R, int has_n, hipStream_t st, int n_tasks, const NraSweepTask* tasks,
+                             const NraDevRead* reads, const NraDevRegion* regions, const uint8_t* pool,
+                             const uint32_t* q2bit, const uint32_t* qnmask, NraScoreParams sp,
+                             const int32_t* kmin, const int32_t* kmax, const uint32_t* coff,
+                             int32_t* snap, int32_t* read_a, int32_t* cand_score, uint8_t* cand_flag)
+{
+    if (n_tasks <= 0) return 0;
+#define ARGS n_tasks, tasks, reads, regions, pool, q2bit, qnmask, sp, kmin, kmax, coff, snap, read_a, cand_score, cand_flag
+#define CASE(r)                                                                          \
+    case r:                                                                              \
+        if (has_n) k_sweep_ring<r, true, DIR><<<n_tasks, WAVE, 0, st>>>(ARGS);           \
+        else k_sweep_ring<r, false, DIR><<<n_tasks, WAVE, 0, st>>>(ARGS);                \
+        break;
+    switch (R) {
+        NRA_R_LIST(CASE)
+    default: return (int)hipErrorInvalidValue;
+    }
+#undef CASE
+#undef ARGS
+    return (int)hipGetLastError();
+}
+
+#if NRA_HAS_PART(11)
+extern "C" int nra_launch_sweep_ring_bwd(int R, int has_n, hipStream_t st, int n_tasks, const NraSweepTask* tasks,
+                                         const NraDevRead* reads, const NraDevRegion* regions, const uint8_t* pool,
+                                         const uint32_t* q2bit, const uint32_t* qnmask, NraScoreParams sp,
+                                         const int32_t* kmin, const int32_t* kmax, const uint32_t* coff,
+                                         int32_t* snap, int32_t* read_a)
+{
+    return launch_sweep_ring<0>(R, has_n, st, n_tasks, tasks, reads, regions, pool, q2bit, qnmask, sp, kmin, kmax,
+                                coff, snap, read_a, nullptr, nullptr);
+}
+#endif
+#if NRA_HAS_PART(12)
+extern "C" int nra_launch_sweep_ring_fwd(int R, int has_n, hipStream_t st, int n_tasks, const NraSweepTask* tasks,
+                                         const NraDevRead* reads, const NraDevRegion* regions, const uint8_t* pool,
+                                         const uint32_t* q2bit, const uint32_t* qnmask, NraScoreParams sp,
+                                         const int32_t* kmin, const int32_t* kmax, const uint32_t* coff,
+                                         int32_t* snap, int32_t* read_a, int32_t* cand_score, uint8_t* cand_flag)
+{
+    return launch_sweep_ring<1>(R, has_n, st, n_tasks, tasks, reads, regions, pool, q2bit, qnmask, sp, kmin, kmax,
+                                coff, snap, read_a, cand_score, cand_flag);
+}
+#endif
 
 #if NRA_HAS_PART(5)
 extern "C" int nra_launch_sweep_bwd(int R, int has_n, int chain, hipStream_t st, int n_tasks, const NraSweepTask* tasks,

@@ -298,7 +298,7 @@ def _modes_agree(capi, oracle, d, sc_over=None):
     o = oracle.round3_1d(d["regions"], d["reads"], d["kmin"], d["kmax"], read_region=d.get("read_region"),
                          sc=oracle.default_scoring(**(sc_over or {})))
     res = {}
-    for flags in (0, capi.F_TIE_EXTENTS, capi.F_BRUTE_FORCE, capi.F_ALL_EXTENTS):
+    for flags in (0, capi.F_TIE_EXTENTS, capi.F_BRUTE_FORCE, capi.F_ALL_EXTENTS, capi.F_DPP_SWEEP):
         with capi.Batch.create_1d(d["regions"], d["reads"], d["kmin"], d["kmax"],
                                   read_region=d.get("read_region"), sc=sc_g, flags=flags) as b:
             b.run(); b.sync()
@@ -319,7 +319,9 @@ def test_1d_decomposition_modes_agree(capi, oracle):
     assert st_fast["executed_cells"] * 5 < st_brute["executed_cells"]
     assert st_fast["algorithmic_cells"] == st_brute["algorithmic_cells"]
     # different windows per read (reference rule), odd read count, several motifs
-    for unit, seed in (("CAG", 102), ("AT", 103), ("GGCCCC", 104), ("A", 105)):
+    # unit lengths 1..8 run the LDS-ring sweeps (skew = m), longer units the DPP sweeps
+    for unit, seed in (("CAG", 102), ("AT", 103), ("GGCCCC", 104), ("A", 105), ("ACGGTCA", 107), ("ACGGTCAT", 108),
+                       ("ACGGTCATG", 109), ("ACGGTCATGCAT", 110)):
         _modes_agree(capi, oracle, synth.make_1d(15, unit, (4, 27), "ont_q20", kwin=None, anchor=200, flank=70, seed=seed))
     _modes_agree(capi, oracle, synth.make_1d(9, "TATTG", (12, 20), "hifi", kwin=(10, 22), anchor=150, flank=60, seed=106),
                  sc_over=dict(match=1, mismatch=3, gap_open1=5, gap_ext1=2, gap_open2=20, gap_ext2=1, min_dp_score=20))

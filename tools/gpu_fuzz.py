@@ -31,7 +31,7 @@ def mangle(rng, s):
 
 
 def fuzz_1d(rng):
-    m = int(rng.integers(1, 8)); unit = synth.rand_unit(rng, m)
+    m = int(rng.integers(1, 12)); unit = synth.rand_unit(rng, m)
     L = synth.rand_seq(rng, int(rng.choice([1, 2, 9, 40, 150, 400]))); R = synth.rand_seq(rng, int(rng.choice([1, 2, 11, 60, 150, 400])))
     if rng.random() < 0.1:
         L = mangle(rng, L)
@@ -52,7 +52,7 @@ def fuzz_1d(rng):
         kmin.append(lo); kmax.append(hi)
     sc = rand_scoring(rng)
     o = O.round3_1d([(L, unit, R)], reads, kmin, kmax, sc=O.default_scoring(**sc))
-    for flags in (0, A.F_TIE_EXTENTS, A.F_BRUTE_FORCE, A.F_TEST_CHAIN):
+    for flags in (0, A.F_TIE_EXTENTS, A.F_BRUTE_FORCE, A.F_TEST_CHAIN, A.F_DPP_SWEEP):
         if flags == A.F_TEST_CHAIN and (len(L) < 1 or len(R) < 1):
             continue
         try:
