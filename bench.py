@@ -274,7 +274,7 @@ def bench_1d(args):
         mine = out["status"][index] == 0
         est = out["sum_k"][index][mine] / np.maximum(out["n_ties"][index][mine], 1)
         exact = float(np.mean(est == data["k_true"][mine])) if mine.any() else 0.0
-        kern = "k_score_pk16<R>" if args.brute else "k_sweep_pk16<R,dir> (reverse + forward sweeps of all read-length buckets)"
+        kern = "k_score_pk16<R>" if args.brute else "k_sweep_ring<R,dir> (reverse + forward sweeps of all read-length buckets)"
         line = {
             "metric": "read-alignments/sec (reads x candidate-k)",
             "value": n_align * args.steps / dt, "unit": "read-alignments/s",

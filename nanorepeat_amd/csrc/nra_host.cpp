@@ -185,6 +185,28 @@ struct HandlePool {
         }
         return timing ? hipEventCreate(out) : hipEventCreateWithFlags(out, hipEventDisableTiming);
     }
+    // pinned staging buffers (hipHostMalloc costs ~0.2 ms): reused like the streams
+    std::vector<std::pair<void*, size_t>> pinned;
+    hipError_t pinned_get(size_t bytes, void** out, size_t* got)
+    {
+        {
+            std::lock_guard<std::mutex> lk(mu);
+            for (size_t i = 0; i < pinned.size(); ++i)
+                if (pinned[i].second >= bytes && pinned[i].second <= 4 * bytes + (1u << 20)) {
+                    *out = pinned[i].first; *got = pinned[i].second;
+                    pinned.erase(pinned.begin() + (long)i);
+                    return hipSuccess;
+                }
+        }
+        *got = bytes;
+        return hipHostMalloc(out, bytes, hipHostMallocDefault);
+    }
+    void pinned_put(void* p, size_t bytes)
+    {
+        std::lock_guard<std::mutex> lk(mu);
+        if (pinned.size() < 8) pinned.push_back({p, bytes});
+        else (void)hipHostFree(p);
+    }
     void put_stream(int device, hipStream_t q)
     {
         std::lock_guard<std::mutex> lk(mu);
@@ -315,6 +337,11 @@ struct nra_batch {
     DevBuf<int32_t> cand_score, cand_tstart, cand_tend, best_score, n_ties;
     DevBuf<int64_t> sum_k, sum_k2;
     DevBuf<uint8_t> status;
+    // the per-read results above are views into ONE block [sum_k | sum_k2 | best_score | n_ties | status(+strand)],
+    // so that a fetch is one D2H copy into a pinned staging buffer instead of four or six pageable ones
+    DevBuf<uint8_t> result_block;
+    void* result_stage = nullptr;      // pinned host mirror (from the handle pool)
+    size_t result_bytes = 0, result_stage_bytes = 0;
     // 2D
     DevBuf<int32_t> probe_score, cell_k1, cell_k2;
     DevBuf<uint32_t> cell_first, cell_cnt;
@@ -342,6 +369,7 @@ struct nra_batch {
         if (fork2_ev) g_handles.put_event(device, false, fork2_ev);
         for (hipStream_t q : bstreams) if (q) g_handles.put_stream(device, q);
         if (stream) g_handles.put_stream(device, stream);
+        if (result_stage) g_handles.pinned_put(result_stage, result_stage_bytes);
     }
 };
 
@@ -437,6 +465,40 @@ int common_init(nra_batch* b, int device, const nra_scoring_t* sc, int flags)
     b->sp = to_params(*sc);
     HIP_TRY(g_handles.stream(device, &b->stream));
     return NRA_OK;
+}
+
+// one device block (+ pinned host mirror) for the per-read results; n8 = int64 arrays, strand: 2D only
+int alloc_results(nra_batch* b, size_t n, bool two_d)
+{
+    const size_t n8 = two_d ? 2 : 1;
+    const size_t np = (n + 7) & ~(size_t)7;                 // keeps every sub-array 8-byte aligned
+    b->result_bytes = np * (8 * n8 + 4 + 4 + 1 + (two_d ? 1 : 0));
+    HIP_TRY(b->result_block.alloc(b->result_bytes));
+    HIP_TRY(g_handles.pinned_get(std::max<size_t>(b->result_bytes, 8), &b->result_stage, &b->result_stage_bytes));
+    uint8_t* p = b->result_block.p;
+    auto view = [&](auto& buf, size_t bytes) {
+        buf.p = reinterpret_cast<decltype(buf.p)>(p); buf.n = n; buf.owned = false; p += bytes;
+    };
+    view(b->sum_k, np * 8);
+    if (two_d) view(b->sum_k2, np * 8);
+    view(b->best_score, np * 4);
+    view(b->n_ties, np * 4);
+    view(b->status, np);
+    if (two_d) view(b->strand_out, np);
+    return NRA_OK;
+}
+
+// the results block -> the pinned mirror (one copy); returns host pointers through `at`
+int fetch_results(nra_batch* b)
+{
+    if (b->result_bytes)
+        HIP_TRY(hipMemcpy(b->result_stage, b->result_block.p, b->result_bytes, hipMemcpyDeviceToHost));
+    return NRA_OK;
+}
+template <class T> const T* staged(const nra_batch* b, const DevBuf<T>& buf)
+{
+    return reinterpret_cast<const T*>(static_cast<const uint8_t*>(b->result_stage) +
+                                      (reinterpret_cast<const uint8_t*>(buf.p) - b->result_block.p));
 }
 
 int make_events(nra_batch* b, int n)
@@ -718,10 +780,8 @@ int nra_batch1d_create(int device, const nra_region_t* regions, int32_t n_region
     HIP_TRY(b->cand_score.alloc((size_t)total));
     HIP_TRY(b->cand_tstart.alloc((size_t)total));
     HIP_TRY(b->cand_tend.alloc((size_t)total));
-    HIP_TRY(b->best_score.alloc((size_t)n_reads));
-    HIP_TRY(b->n_ties.alloc((size_t)n_reads));
-    HIP_TRY(b->sum_k.alloc((size_t)n_reads));
-    HIP_TRY(b->status.alloc((size_t)n_reads));
+    rc = alloc_results(b, (size_t)n_reads, false);
+    if (rc) return rc;
     clk.mark("device buffers, H2D");
     rc = make_events(b, 2 + 6 * (int)nb + 2);
     if (rc) return rc;
@@ -854,10 +914,12 @@ int nra_batch1d_fetch(nra_batch_t* b, int32_t* best_score, int64_t* sum_k, int32
     HIP_TRY(hipStreamSynchronize(b->stream));
     const size_t n = (size_t)b->n_reads, nc = (size_t)b->n_cands;
     if (n) {
-        if (best_score) HIP_TRY(hipMemcpy(best_score, b->best_score.p, n * 4, hipMemcpyDeviceToHost));
-        if (sum_k) HIP_TRY(hipMemcpy(sum_k, b->sum_k.p, n * 8, hipMemcpyDeviceToHost));
-        if (n_ties) HIP_TRY(hipMemcpy(n_ties, b->n_ties.p, n * 4, hipMemcpyDeviceToHost));
-        if (status) HIP_TRY(hipMemcpy(status, b->status.p, n, hipMemcpyDeviceToHost));
+        int rc = fetch_results(b);
+        if (rc) return rc;
+        if (best_score) memcpy(best_score, staged(b, b->best_score), n * 4);
+        if (sum_k) memcpy(sum_k, staged(b, b->sum_k), n * 8);
+        if (n_ties) memcpy(n_ties, staged(b, b->n_ties), n * 4);
+        if (status) memcpy(status, staged(b, b->status), n);
         if (best_score)
             for (size_t i = 0; i < n; ++i) if (best_score[i] < 0) best_score[i] = 0;
     }
@@ -1091,14 +1153,10 @@ int nra_batch2d_create(int device, const nra_joint_region_t* reg, int32_t n_read
         HIP_TRY(b->strand_in.upload(v));
         b->have_strand_in = true;
     }
-    HIP_TRY(b->strand_out.alloc((size_t)n_reads));
     HIP_TRY(b->cand_score.alloc((size_t)n_cells));     // cell_score
     HIP_TRY(b->cand_tstart.alloc((size_t)n_cells));    // cell_wscore
-    HIP_TRY(b->best_score.alloc((size_t)n_reads));     // best_wscore
-    HIP_TRY(b->n_ties.alloc((size_t)n_reads));
-    HIP_TRY(b->sum_k.alloc((size_t)n_reads));
-    HIP_TRY(b->sum_k2.alloc((size_t)n_reads));
-    HIP_TRY(b->status.alloc((size_t)n_reads));
+    rc = alloc_results(b, (size_t)n_reads, true);      // best_wscore, n_ties, sum_k, sum_k2, status, strand_out
+    if (rc) return rc;
     rc = make_events(b, 2 + 6 * (int)nb + 4 * (int)b->jgroups.size() + 2);
     if (rc) return rc;
     // two streams per bucket: the buckets' chains overlap, and so do a bucket's reverse and prefix sweeps
@@ -1219,12 +1277,14 @@ int nra_batch2d_fetch(nra_batch_t* b, int8_t* read_strand, int32_t* cell_score, 
     HIP_TRY(hipStreamSynchronize(b->stream));
     const size_t n = (size_t)b->n_reads, nc = (size_t)b->n_cands;
     if (n) {
-        if (read_strand) HIP_TRY(hipMemcpy(read_strand, b->strand_out.p, n, hipMemcpyDeviceToHost));
-        if (best_wscore) HIP_TRY(hipMemcpy(best_wscore, b->best_score.p, n * 4, hipMemcpyDeviceToHost));
-        if (sum_k1) HIP_TRY(hipMemcpy(sum_k1, b->sum_k.p, n * 8, hipMemcpyDeviceToHost));
-        if (sum_k2) HIP_TRY(hipMemcpy(sum_k2, b->sum_k2.p, n * 8, hipMemcpyDeviceToHost));
-        if (n_ties) HIP_TRY(hipMemcpy(n_ties, b->n_ties.p, n * 4, hipMemcpyDeviceToHost));
-        if (status) HIP_TRY(hipMemcpy(status, b->status.p, n, hipMemcpyDeviceToHost));
+        int rc = fetch_results(b);
+        if (rc) return rc;
+        if (read_strand) memcpy(read_strand, staged(b, b->strand_out), n);
+        if (best_wscore) memcpy(best_wscore, staged(b, b->best_score), n * 4);
+        if (sum_k1) memcpy(sum_k1, staged(b, b->sum_k), n * 8);
+        if (sum_k2) memcpy(sum_k2, staged(b, b->sum_k2), n * 8);
+        if (n_ties) memcpy(n_ties, staged(b, b->n_ties), n * 4);
+        if (status) memcpy(status, staged(b, b->status), n);
     }
     if (nc) {
         if (cell_score) HIP_TRY(hipMemcpy(cell_score, b->cand_score.p, nc * 4, hipMemcpyDeviceToHost));

@@ -29,7 +29,7 @@ def main():
     opts = {a.split("=")[0]: a.split("=")[1] for a in sys.argv[1:] if a.startswith("--") and "=" in a}
     tag, stats_dir, pmc_dirs = args[0], args[1], args[2:]
     steps = int(opts.get("--steps", 1))
-    kern = opts.get("--kernel", "k_sweep_pk16")
+    kern = opts.get("--kernel", "k_sweep_")
     out_dir = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles")
     st = find(stats_dir, "kernel_stats.csv")
     if st:
@@ -52,6 +52,29 @@ def main():
         w.writerow(["kernel", "counter", "sum_over_dispatches", "rows"])
         for (name, c), v in sorted(total.items()):
             w.writerow([name, c, v, ndisp[(name, c)]])
+    # per kernel: duration of its dispatches in the counter passes (launches are serialised there) and the
+    # shader clock GRBM_GUI_ACTIVE / 8 XCDs / duration (MI355X_MICROARCH.md, DVFS)
+    per_kernel = {}
+    for d in pmc_dirs:
+        for f in find(d, "counter_collection.csv"):
+            rows = [r for r in csv.DictReader(open(f)) if r["Counter_Name"] == "GRBM_GUI_ACTIVE"]
+            for r in rows:
+                name = r["Kernel_Name"].split("(")[0].replace("void ", "")
+                if kern not in name:
+                    continue
+                e = per_kernel.setdefault(name, {"dispatches": 0, "ns": 0.0, "gui_active": 0.0})
+                e["dispatches"] += 1
+                e["ns"] += float(r["End_Timestamp"]) - float(r["Start_Timestamp"])
+                e["gui_active"] += float(r["Counter_Value"])
+    for name, e in per_kernel.items():
+        e["ms_per_dispatch_serialised"] = e["ns"] / e["dispatches"] / 1e6
+        e["clock_GHz"] = e["gui_active"] / 8.0 / e["ns"]
+        for c in ("SQ_INSTS_VALU", "SQ_WAVE_CYCLES", "SQ_ACTIVE_INST_VALU", "SQ_WAIT_INST_ANY", "SQ_WAIT_ANY"):
+            if (name, c) in total:
+                e[c + "_per_dispatch"] = total[(name, c)] / e["dispatches"]
+        if e.get("SQ_INSTS_VALU_per_dispatch"):
+            # SIMD-cycles the chip had per VALU wave-instruction while this kernel ran alone
+            e["simd_cycles_per_valu_instruction"] = (e["gui_active"] / 8.0 / e["dispatches"]) * 1024.0 / e["SQ_INSTS_VALU_per_dispatch"]
     sweep = defaultdict(float)
     for (name, c), v in total.items():
         if kern in name:
@@ -65,6 +88,7 @@ def main():
            "sweep_kernels": {"fetch_bytes": fetch, "fetch_bytes_x2_upper_bound": 2 * fetch, "write_bytes": write,
                              "valu_wave_instructions_per_step": valu,
                              "counters_per_step": {c: v / steps for c, v in sorted(sweep.items())}}}
+    res["per_kernel_serialised"] = per_kernel
     if sweep.get("SQ_ACTIVE_INST_VALU") and valu:
         # quad-cycles of VALU activity per wave instruction (MI355X_MICROARCH.md: SQ_ACTIVE_INST_* count quad-cycles)
         res["simd_cycles_per_valu_instruction_active"] = 4.0 * sweep["SQ_ACTIVE_INST_VALU"] / sweep["SQ_INSTS_VALU"]
