@@ -19,11 +19,24 @@ __device__ __forceinline__ int dpp_rol1(int src)            // lane l <- lane l+
 {
     return __builtin_amdgcn_update_dpp(src, src, 0x134 /*wave_rol:1*/, 0xf, 0xf, false);
 }
+// the same moves for 64-bit cells (two 32-bit DPP moves)
+__device__ __forceinline__ long long dpp_shr1(long long old, long long src)
+{
+    const int lo = dpp_shr1((int)(unsigned)(old & 0xffffffffll), (int)(unsigned)(src & 0xffffffffll));
+    const int hi = dpp_shr1((int)(old >> 32), (int)(src >> 32));
+    return ((long long)hi << 32) | (unsigned)lo;
+}
+__device__ __forceinline__ long long dpp_rol1(long long src)
+{
+    const int lo = dpp_rol1((int)(unsigned)(src & 0xffffffffll)), hi = dpp_rol1((int)(src >> 32));
+    return ((long long)hi << 32) | (unsigned)lo;
+}
 __device__ __forceinline__ s16x2 as_s(int v) { return __builtin_bit_cast(s16x2, v); }
 __device__ __forceinline__ int as_i(s16x2 v) { return __builtin_bit_cast(int, v); }
 __device__ __forceinline__ s16x2 pmax(s16x2 a, s16x2 b) { return __builtin_elementwise_max(a, b); }
 __device__ __forceinline__ s16x2 splat(int v) { s16x2 r; r.x = (short)v; r.y = (short)v; return r; }
 __device__ __forceinline__ int imax(int a, int b) { return a > b ? a : b; }
+__device__ __forceinline__ long long imax(long long a, long long b) { return a > b ? a : b; }
 __device__ __forceinline__ int imin(int a, int b) { return a < b ? a : b; }
 
 // ------------------------------------------------------------------------------------

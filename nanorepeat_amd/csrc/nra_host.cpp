@@ -242,6 +242,8 @@ struct Bucket {
     bool ring = false;         // k_sweep_ring (LDS hand-off) instead of k_sweep_pk16 (DPP hand-off)
     int n_jbwd = 0;            // 2D decomposition: reverse sweeps (one per read)
     size_t jbwd_off = 0;
+    int n_probe = 0;           // 2D, chained reads: strand-probe payload tasks (two per read)
+    size_t probe_off = 0;
     int64_t cells_pair = 0;    // executed cells per run, pk16
     int64_t cells_queue = 0;   // executed cells per run, prebuilt payload queue
     int64_t cells_sweep = 0;   // executed cells per run, both sweeps
@@ -271,7 +273,7 @@ bool scoring_ok(const nra_scoring_t* sc)
 // int32 cells keep the score in their upper 16 bits; the packed int16 kernels keep value + 8192
 // (brute force), two biased values added (chained sweep: 2 x 8192 + score), or the same with
 // doubled scores (origin-bit sweep).
-const int64_t kScoreCapI32 = 32000, kScoreCapPk16 = 24000, kScoreCapChain = 16000, kScoreCapBit = 8000;
+const int64_t kScoreCapI32 = 32000, kScoreCapPk16 = 24000, kScoreCapBit = 8000;
 inline int64_t max_score(const nra_scoring_t* sc, int64_t qlen) { return (int64_t)sc->match * qlen; }
 
 // A rows-per-lane bucket with few reads would run as its own under-filled launches: fold it into the
@@ -316,11 +318,11 @@ struct nra_batch {
     DevBuf<NraPairTask> pair_tasks;
     DevBuf<NraSweepTask> sweep_tasks;
     DevBuf<int32_t> snap;                      // R side of the junction: per sweep task 3 planes of R x 64 (both reads packed)
-    DevBuf<int32_t> arr_a;                     // A_k per candidate (chained reads only)
     DevBuf<int32_t> read_a1d;                  // A per read: best alignment inside R (origin-bit scheme)
     DevBuf<uint8_t> cand_flag;                 // flank verdict per candidate
     bool brute = false;                        // K independent alignments instead of the sweeps
-    DevBuf<int32_t> chain_sweep, chain_payload; // scratch strips of the chained row blocks
+    DevBuf<int32_t> chain_sweep;                // scratch strips of the chained row blocks (int32 sweep cells)
+    DevBuf<int64_t> chain_payload;              // ... and of the chained payload kernels (int32 or int64 cells)
     DevBuf<NraJointTask> jbwd_tasks, jpre_tasks, jtail_tasks; // 2D decomposition: per read / per read / per (read, k1) run
     DevBuf<int32_t> jsnap, jread_a;             // R side of the junction (3 x int32 per base), A per read
     DevBuf<int32_t> jk1list, jstate;            // k1 values per read; wave states of the prefix sweeps
@@ -343,7 +345,9 @@ struct nra_batch {
     void* result_stage = nullptr;      // pinned host mirror (from the handle pool)
     size_t result_bytes = 0, result_stage_bytes = 0;
     // 2D
-    DevBuf<int32_t> probe_score, cell_k1, cell_k2;
+    DevBuf<int32_t> probe_score, probe_dummy, cell_k1, cell_k2;
+    DevBuf<NraTask> probe_tasks;                // chained 2D reads: (read, first cell) in both orientations
+    DevBuf<int32_t> probe_count;
     DevBuf<uint32_t> cell_first, cell_cnt;
     DevBuf<int8_t> strand_in, strand_out;
     bool have_strand_in = false;
@@ -579,7 +583,7 @@ int nra_batch1d_create(int device, const nra_region_t* regions, int32_t n_region
         if (kmin[r] < 0) return fail(NRA_E_ARG, "kmin < 0");
         const int g = pr.reads[r].region;
         const int64_t tl = (int64_t)regions[g].left_len + (int64_t)regions[g].unit_len * kmax[r] + regions[g].right_len;
-        if (tl > NRA_MAX_TLEN) return fail(NRA_E_RANGE, "template longer than " + std::to_string(NRA_MAX_TLEN));
+        if (tl > NRA_MAX_TLEN_WIDE) return fail(NRA_E_RANGE, "template longer than " + std::to_string(NRA_MAX_TLEN_WIDE));
         region_kmax[g] = std::max(region_kmax[g], kmax[r]);
         total += (int64_t)kmax[r] - kmin[r] + 1;
         if (total > 0x7ff00000ll) return fail(NRA_E_RANGE, "more than 2^31 candidates in one batch");
@@ -623,24 +627,36 @@ int nra_batch1d_create(int device, const nra_region_t* regions, int32_t n_region
         const int o2 = sc->gap_open2 + sc->gap_ext2;
         if (2 * sc->gap_ext1 > 256 || 2 * sc->gap_ext2 > 256 || 2 * o2 > 2048) brute = true;
     }
-    for (int32_t r = 0; r < n_reads; ++r) {       // unusual scoring: do the scores fit the 16-bit cells?
+    // Which reads leave the packed int16 sweeps for the chained int32 ones (one read per wave, any length):
+    // more rows than one register block, scores beyond the doubled int16 range, or a template whose
+    // extents do not fit the 16-bit payload of the int32 extents kernel.
+    const bool test_chain = (flags & NRA_F_TEST_CHAIN) != 0;
+    std::vector<uint8_t> chained((size_t)n_reads, 0);
+    for (int32_t r = 0; r < n_reads; ++r) {
         if (kmin[r] > kmax[r]) continue;
+        const nra_region_t& rg = regions[pr.reads[r].region];
         const int64_t ms = max_score(sc, pr.reads[r].qlen);
-        const bool chained = pr.reads[r].qlen > NRA_MAX_QLEN_1BLOCK;
-        if (ms > (chained ? kScoreCapChain : kScoreCapPk16))
-            return fail(NRA_E_RANGE, "read " + std::to_string(r) + ": match score x read length does not fit the 16-bit cells");
-        if (!chained && ms > kScoreCapBit) brute = true;
+        const int64_t tl = (int64_t)rg.left_len + (int64_t)rg.unit_len * kmax[r] + rg.right_len;
+        chained[r] = test_chain || pr.reads[r].qlen > NRA_MAX_QLEN_1BLOCK || ms > kScoreCapBit || tl > NRA_MAX_TLEN;
+        if (brute && chained[r] && !test_chain) {
+            // without the sweeps (flank-less region, unusual scoring, brute force on request) only what the
+            // packed brute-force kernel holds can be scored
+            if (pr.reads[r].qlen > NRA_MAX_QLEN_1BLOCK || ms > kScoreCapPk16 || tl > NRA_MAX_TLEN)
+                return fail(NRA_E_RANGE, "read " + std::to_string(r) + " (" + std::to_string(pr.reads[r].qlen) +
+                                             " bases) needs the junction decomposition: no brute force / ALL_EXTENTS, "
+                                             "flanks >= 1, default-like scoring");
+            chained[r] = 0;
+        }
     }
     b->brute = brute;
     std::vector<NraSweepTask> sweep_tasks;
     uint64_t snap_total = 0;
-    // bucket kNumR = reads longer than one register block (or every read with NRA_F_TEST_CHAIN)
+    // bucket kNumR = the chained reads (every read with NRA_F_TEST_CHAIN)
     std::vector<std::vector<int32_t>> by_bucket((size_t)kNumR + 1);
-    const bool test_chain = (flags & NRA_F_TEST_CHAIN) != 0;
     int chain_cols = 0;
     for (int32_t r = 0; r < n_reads; ++r) {
         if (kmin[r] > kmax[r] || pr.reads[r].qlen == 0) continue;
-        int bi = (test_chain || pr.reads[r].qlen > NRA_MAX_QLEN_1BLOCK) ? kNumR : rows_for_qlen(pr.reads[r].qlen);
+        int bi = chained[r] ? kNumR : rows_for_qlen(pr.reads[r].qlen);
         read_bucket[r] = bi;
         by_bucket[bi].push_back(r);
         if (bi == kNumR) {
@@ -649,8 +665,7 @@ int nra_batch1d_create(int device, const nra_region_t* regions, int32_t n_region
         }
     }
     if (!by_bucket[kNumR].empty() && brute)
-        return fail(NRA_E_RANGE, "reads longer than " + std::to_string(NRA_MAX_QLEN_1BLOCK) +
-                                     " bases need the junction decomposition (no brute force / ALL_EXTENTS, flanks >= 1)");
+        return fail(NRA_E_RANGE, "NRA_F_TEST_CHAIN needs the junction decomposition (no brute force / ALL_EXTENTS, flanks >= 1)");
     b->chain_cap = (chain_cols + 127) / 64 * 64 + 64;
     fold_small_buckets(by_bucket, 1024, 2);    // wider folding (up to 16384 reads / 4 rows) changes nothing in 1D
     std::vector<NraPairTask> pair_tasks;
@@ -711,7 +726,8 @@ int nra_batch1d_create(int device, const nra_region_t* regions, int32_t n_region
                 NraSweepTask t{};
                 t.read_a = order[i]; t.read_b = -1;
                 t.kmin = kmin[t.read_a]; t.kmax = kmax[t.read_a];
-                if (i + 1 < order.size() && pr.reads[order[i + 1]].region == pr.reads[order[i]].region) {
+                // (the chained sweeps take one read per wave)
+                if (!bk.chain && i + 1 < order.size() && pr.reads[order[i + 1]].region == pr.reads[order[i]].region) {
                     t.read_b = order[i + 1];
                     t.kmin = std::min(t.kmin, kmin[t.read_b]);
                     t.kmax = std::max(t.kmax, kmax[t.read_b]);
@@ -727,8 +743,8 @@ int nra_batch1d_create(int device, const nra_region_t* regions, int32_t n_region
                 if (bk.ring)    // pipelines 64*m (forward) and 64 (reverse) columns deep
                     bk.cells_sweep += 2 * (int64_t)64 * bk.R * ((d.l1 + d.m1 * t.kmax + 63 * d.m1) + (d.l3 + 63));
                 else
-                    bk.cells_sweep += (int64_t)nblk * 2 * (sweep128_cells(bk.R, d.l1 + d.m1 * t.kmax) +
-                                                           sweep128_cells(bk.R, d.l3 + (bk.chain ? d.m1 * t.kmax : 0)));
+                    bk.cells_sweep += (int64_t)nblk * (bk.chain ? 1 : 2) * (sweep128_cells(bk.R, d.l1 + d.m1 * t.kmax) +
+                                                                            sweep128_cells(bk.R, d.l3));
                 t.snap_off = snap_total;
                 snap_total += (uint64_t)nblk * 3 * bk.R * 64;
                 sweep_tasks.push_back(t);
@@ -757,14 +773,13 @@ int nra_batch1d_create(int device, const nra_region_t* regions, int32_t n_region
     HIP_TRY(b->sweep_tasks.upload(sweep_tasks));
     if (!brute) {
         HIP_TRY(b->snap.alloc((size_t)snap_total));
-        HIP_TRY(b->arr_a.alloc(by_bucket[kNumR].empty() ? 1 : (size_t)total));   // A_k: chained reads only
         HIP_TRY(b->read_a1d.alloc((size_t)n_reads));
     }
     HIP_TRY(b->cand_flag.alloc((size_t)total));
     for (const Bucket& bk : b->buckets) {
         if (!bk.chain) continue;
-        HIP_TRY(b->chain_sweep.alloc((size_t)bk.n_sweep * 10 * (size_t)b->chain_cap));
-        HIP_TRY(b->chain_payload.alloc((size_t)512 * 6 * (size_t)b->chain_cap));
+        HIP_TRY(b->chain_sweep.alloc((size_t)std::min(bk.n_sweep, NRA_CHAIN_STRIPS) * 10 * (size_t)b->chain_cap));
+        HIP_TRY(b->chain_payload.alloc(std::min<size_t>(bk.queue_cap, NRA_CHAIN_STRIPS) * 6 * (size_t)b->chain_cap));
     }
     if (all_ext) HIP_TRY(b->queue_tasks.upload(queue_tasks));
     else HIP_TRY(b->queue_tasks.alloc(queue_total));
@@ -839,7 +854,7 @@ static int run_1d(nra_batch* b)
                 LAUNCH_TRY(nra_launch_sweep_bwd(bk.R, b->has_n, bk.chain ? 1 : 0, q, bk.n_sweep, b->sweep_tasks.p + bk.sweep_off,
                                                 b->reads.p, b->regions.p, b->pool.p, b->q2bit.p, b->qnmask.p, b->sp,
                                                 b->kmin.p, b->kmax.p, b->coff.p, b->snap.p,
-                                                b->arr_a.p, b->read_a1d.p, b->chain_sweep.p, b->chain_cap));
+                                                b->read_a1d.p, b->chain_sweep.p, b->chain_cap));
             HIP_TRY(hipEventRecord(b->ev[ev++], q));
             HIP_TRY(hipEventRecord(b->ev[ev++], q));
             if (bk.ring)
@@ -851,7 +866,7 @@ static int run_1d(nra_batch* b)
                 LAUNCH_TRY(nra_launch_sweep_fwd(bk.R, b->has_n, bk.chain ? 1 : 0, q, bk.n_sweep, b->sweep_tasks.p + bk.sweep_off,
                                                 b->reads.p, b->regions.p, b->pool.p, b->q2bit.p, b->qnmask.p, b->sp,
                                                 b->kmin.p, b->kmax.p, b->coff.p, b->snap.p,
-                                                b->arr_a.p, b->read_a1d.p, b->cand_score.p, b->cand_flag.p,
+                                                b->read_a1d.p, b->cand_score.p, b->cand_flag.p,
                                                 b->chain_sweep.p, b->chain_cap));
             HIP_TRY(hipEventRecord(b->ev[ev++], q));
             b->n_score_ev += 2;
@@ -871,7 +886,7 @@ static int run_1d(nra_batch* b)
                                                   b->queue_tasks.p + bk.queue_off, b->queue_count.p + i,
                                                   b->reads.p, b->regions.p, b->pool.p,
                                                   b->q2bit.p, b->qnmask.p, b->sp, b->cand_score.p,
-                                                  b->cand_tstart.p, b->cand_tend.p, nullptr, 0));
+                                                  b->cand_tstart.p, b->cand_tend.p, nullptr, 0, 0));
             }
             HIP_TRY(hipEventRecord(b->ev[ev++], st));
             b->n_score_ev++;
@@ -888,13 +903,14 @@ static int run_1d(nra_batch* b)
         for (size_t i = 0; i < nb; ++i) {
             const Bucket& bk = b->buckets[i];
             HIP_TRY(hipEventRecord(b->ev[ev++], st));
+            // chained reads: int64 cells (scores and extents of any size)
             LAUNCH_TRY(nra_launch_payload_origin(bk.R, b->has_n, st,
-                                              (int)std::min<size_t>(bk.queue_cap, bk.chain ? 512 : max_waves),
+                                              (int)std::min<size_t>(bk.queue_cap, bk.chain ? NRA_CHAIN_STRIPS : max_waves),
                                               b->queue_tasks.p + bk.queue_off, b->tie_count.p + i,
                                               b->reads.p, b->regions.p, b->pool.p,
                                               b->q2bit.p, b->qnmask.p, b->sp, b->cand_score.p,
                                               b->cand_tstart.p, b->cand_tend.p,
-                                              bk.chain ? b->chain_payload.p : nullptr, b->chain_cap));
+                                              bk.chain ? b->chain_payload.p : nullptr, b->chain_cap, bk.chain ? 1 : 0));
             HIP_TRY(hipEventRecord(b->ev[ev++], st));
             b->n_ext_ev++;
         }
@@ -975,11 +991,13 @@ int nra_batch2d_create(int device, const nra_joint_region_t* reg, int32_t n_read
     if (rc) return rc;
 
     PackedReads pr;
-    rc = pack_reads(n_reads, seqs, seq_off, nullptr, 1, pr);
+    rc = pack_reads(n_reads, seqs, seq_off, nullptr, 1, pr, NRA_MAX_QLEN);
     if (rc) return rc;
+    // Reads longer than one register block (3072 bases), or whose scores do not fit the int32 cells of the
+    // joint sweeps, are scored cell by cell in chained row blocks with int64 cells (rare: a long amplicon).
+    std::vector<uint8_t> chained((size_t)n_reads, 0);
     for (int32_t r = 0; r < n_reads; ++r)
-        if (max_score(sc, pr.reads[r].qlen) > kScoreCapPk16)
-            return fail(NRA_E_RANGE, "read " + std::to_string(r) + ": match score x read length does not fit the 16-bit cells");
+        chained[r] = pr.reads[r].qlen > NRA_MAX_QLEN_1BLOCK || max_score(sc, pr.reads[r].qlen) > kScoreCapPk16;
 
     std::vector<uint32_t> first((size_t)n_reads, 0), cnt((size_t)n_reads, 0);
     int32_t k1max = 0, k2max = 0;
@@ -1013,16 +1031,19 @@ int nra_batch2d_create(int device, const nra_joint_region_t* reg, int32_t n_read
     b->has_n = has_n ? 1 : 0;
     std::vector<NraDevRegion> dregs(1, d);
 
-    std::vector<std::vector<int32_t>> by_bucket((size_t)kNumR);
+    std::vector<std::vector<int32_t>> by_bucket((size_t)kNumR + 1);
     for (int32_t r = 0; r < n_reads; ++r) {
         if (cnt[r] == 0 || pr.reads[r].qlen == 0) continue;
-        by_bucket[rows_for_qlen(pr.reads[r].qlen)].push_back(r);
+        by_bucket[chained[r] ? kNumR : rows_for_qlen(pr.reads[r].qlen)].push_back(r);
     }
+    const std::vector<int32_t> chain_reads = by_bucket[kNumR];
+    by_bucket[kNumR].clear();
     // measured on config 3 (5000 reads, R = 13..28): (2048, 4) beats (1024, 2) and wider spans
     fold_small_buckets(by_bucket, 2048, 4);
+    by_bucket[kNumR] = chain_reads;            // (not folded)
     std::vector<NraPairTask> pair_tasks;
-    std::vector<NraTask> queue_tasks;
-    std::vector<int32_t> queue_count;
+    std::vector<NraTask> queue_tasks, probe_tasks;
+    std::vector<int32_t> queue_count, probe_count;
     std::vector<NraJointTask> jbwd, jpre, jtail;
     std::vector<int32_t> k1list;
     // junction decomposition needs a base left of the window and two bases of R
@@ -1037,18 +1058,22 @@ int nra_batch2d_create(int device, const nra_joint_region_t* reg, int32_t n_read
     if (read_strand)
         for (int32_t r = 0; r < n_reads; ++r) if (cnt[r] > 0 && read_strand[r] == 0) b->all_strands_given = false;
     int64_t alg_cells = 0;
-    for (int bi = kNumR - 1; bi >= 0; --bi) {
+    for (int bi = kNumR; bi >= 0; --bi) {
         if (by_bucket[bi].empty()) continue;
-        Bucket bk; bk.R = kRList[bi];
+        Bucket bk;
+        bk.chain = bi == kNumR;
+        bk.R = bk.chain ? NRA_CHAIN_R : kRList[bi];
         bk.pair_off = pair_tasks.size();
         bk.queue_off = queue_tasks.size();
         bk.jbwd_off = jbwd.size();
+        bk.probe_off = probe_tasks.size();
+        const bool per_cell = b->brute || bk.chain;      // one DP per (read, cell) instead of the joint sweeps
         const uint64_t slot = (uint64_t)NRA_JOINT_NSTATE(bk.R) * 64;
         JointGroup g; g.R = bk.R; g.bucket = (int)b->buckets.size(); g.pre_off = jpre.size(); g.tail_off = jtail.size();
         uint64_t used = 0, state_max = 0;
         const size_t bucket_pre0 = jpre.size(), bucket_tail0 = jtail.size();
         for (int32_t r : by_bucket[bi]) {
-            if (!b->brute) {
+            if (!per_cell) {
                 // one reverse sweep over R per read; one prefix sweep over L + u1^k1max per read that
                 // leaves the wave state at each of the read's k1 values; one tail sweep per run of cells
                 // with the same k1 and k2 in arithmetic progression (how the grid rounds list them)
@@ -1088,22 +1113,32 @@ int nra_batch2d_create(int device, const nra_joint_region_t* reg, int32_t n_read
                 state_max = std::max(state_max, used);
             }
             // strand probe against the read's first listed cell: half A = template, half B = its revcomp
-            NraPairTask t{};
-            t.read = r; t.k1a = t.k1b = cell_k1[first[r]]; t.k2a = t.k2b = cell_k2[first[r]];
-            t.out_a = 2 * r; t.out_b = 2 * r + 1; t.flags = 3;     // B = reverse complement; raw scores
-            pair_tasks.push_back(t);
-            if (!b->all_strands_given)
-                bk.cells_pair += 2 * sweep_cells(bk.R, d.l1 + d.m1 * t.k1a + d.l2 + d.m2 * t.k2a + d.l3);
+            if (!bk.chain) {
+                NraPairTask t{};
+                t.read = r; t.k1a = t.k1b = cell_k1[first[r]]; t.k2a = t.k2b = cell_k2[first[r]];
+                t.out_a = 2 * r; t.out_b = 2 * r + 1; t.flags = 3;     // B = reverse complement; raw scores
+                pair_tasks.push_back(t);
+                if (!b->all_strands_given)
+                    bk.cells_pair += 2 * sweep_cells(bk.R, d.l1 + d.m1 * t.k1a + d.l2 + d.m2 * t.k2a + d.l3);
+            } else {
+                // chained: the read and a reverse-complemented shadow of it against the same template
+                NraDevRead shadow = pr.reads[r];
+                shadow.rc = 1;
+                const int32_t sh = (int32_t)pr.reads.size();
+                pr.reads.push_back(shadow);
+                probe_tasks.push_back(NraTask{r, cell_k1[first[r]], cell_k2[first[r]], 2 * r});
+                probe_tasks.push_back(NraTask{sh, cell_k1[first[r]], cell_k2[first[r]], 2 * r + 1});
+            }
             for (uint32_t c = first[r]; c < first[r] + cnt[r]; ++c) {
                 const int tl = d.l1 + d.m1 * cell_k1[c] + d.l2 + d.m2 * cell_k2[c] + d.l3;
                 alg_cells += (int64_t)pr.reads[r].qlen * tl;
-                if (b->brute) {
+                if (per_cell) {
                     queue_tasks.push_back(NraTask{r, cell_k1[c], cell_k2[c], (int32_t)c});
                     bk.cells_queue += sweep_cells(bk.R, tl);
                 }
             }
         }
-        if (!b->brute) {
+        if (!per_cell) {
             g.n_pre = (int)(jpre.size() - g.pre_off); g.n_tail = (int)(jtail.size() - g.tail_off);
             if (g.n_pre > 0) b->jgroups.push_back(g);
             for (size_t i = bucket_pre0; i < jpre.size(); ++i) jpre[i].state += state_base;
@@ -1113,8 +1148,10 @@ int nra_batch2d_create(int device, const nra_joint_region_t* reg, int32_t n_read
         bk.n_pair = (int)(pair_tasks.size() - bk.pair_off);
         bk.n_queue = (int)(queue_tasks.size() - bk.queue_off);
         bk.n_jbwd = (int)(jbwd.size() - bk.jbwd_off);
+        bk.n_probe = (int)(probe_tasks.size() - bk.probe_off);
         bk.queue_cap = (size_t)bk.n_queue;
         queue_count.push_back(bk.n_queue);
+        probe_count.push_back(bk.n_probe);
         b->buckets.push_back(bk);
     }
     const size_t nb = b->buckets.size();
@@ -1132,6 +1169,13 @@ int nra_batch2d_create(int device, const nra_joint_region_t* reg, int32_t n_read
     HIP_TRY(b->pair_tasks.upload(pair_tasks));
     HIP_TRY(b->queue_tasks.upload(queue_tasks));
     HIP_TRY(b->queue_count.upload(queue_count));
+    HIP_TRY(b->probe_tasks.upload(probe_tasks));
+    HIP_TRY(b->probe_count.upload(probe_count));
+    HIP_TRY(b->probe_dummy.alloc(2 * (size_t)n_reads));
+    if (!chain_reads.empty()) {
+        b->chain_cap = (int)((tlmax + 127) / 64 * 64 + 64);
+        HIP_TRY(b->chain_payload.alloc((size_t)NRA_CHAIN_STRIPS * 6 * (size_t)b->chain_cap));
+    }
     if (!b->brute) {
         HIP_TRY(b->jbwd_tasks.upload(jbwd));
         HIP_TRY(b->jpre_tasks.upload(jpre));
@@ -1196,6 +1240,15 @@ static int run_2d(nra_batch* b)
             hipStream_t q = b->bstreams[2 * i];
             HIP_TRY(hipStreamWaitEvent(q, b->fork_ev, 0));
             HIP_TRY(hipEventRecord(b->ev[ev++], q));
+            if (bk.chain) {
+                NraScoreParams raw = b->sp;
+                raw.min_score = 0;               // the probe compares raw scores
+                LAUNCH_TRY(nra_launch_payload_origin(bk.R, b->has_n, q, std::min(bk.n_probe, NRA_CHAIN_STRIPS),
+                                                     b->probe_tasks.p + bk.probe_off, b->probe_count.p + i,
+                                                     b->reads.p, b->regions.p, b->pool.p, b->q2bit.p, b->qnmask.p,
+                                                     raw, b->probe_score.p, b->probe_dummy.p, nullptr,
+                                                     b->chain_payload.p, b->chain_cap, 1));
+            } else
             LAUNCH_TRY(nra_launch_score_pk16(bk.R, b->has_n, q, bk.n_pair, b->pair_tasks.p + bk.pair_off,
                                              b->reads.p, b->regions.p, b->pool.p, b->q2bit.p, b->qnmask.p,
                                              b->sp, b->probe_score.p));
@@ -1208,25 +1261,28 @@ static int run_2d(nra_batch* b)
     LAUNCH_TRY(nra_launch_pick_strand(st, b->n_reads, b->probe_score.p,
                                       b->have_strand_in ? b->strand_in.p : nullptr, b->strand_out.p, b->reads.p));
     HIP_TRY(hipEventRecord(b->phase_ev[0], st));
-    if (b->brute) {
-        for (size_t i = 0; i < nb; ++i) {
-            const Bucket& bk = b->buckets[i];
-            HIP_TRY(hipEventRecord(b->ev[ev++], st));
-            LAUNCH_TRY(nra_launch_payload_window(bk.R, b->has_n, st, std::min(bk.n_queue, max_waves),
-                                              b->queue_tasks.p + bk.queue_off, b->queue_count.p + i,
-                                              b->reads.p, b->regions.p, b->pool.p,
-                                              b->q2bit.p, b->qnmask.p, b->sp, b->cand_score.p,
-                                              b->cand_tstart.p, nullptr));
-            HIP_TRY(hipEventRecord(b->ev[ev++], st));
-            b->n_score_ev++;
-        }
-    } else {
+    // buckets scored cell by cell: all of them in brute-force mode, else the chained (long) reads only
+    for (size_t i = 0; i < nb; ++i) {
+        const Bucket& bk = b->buckets[i];
+        if (!b->brute && !bk.chain) continue;
+        HIP_TRY(hipEventRecord(b->ev[ev++], st));
+        LAUNCH_TRY(nra_launch_payload_window(bk.R, b->has_n, st, std::min(bk.n_queue, bk.chain ? NRA_CHAIN_STRIPS : max_waves),
+                                          b->queue_tasks.p + bk.queue_off, b->queue_count.p + i,
+                                          b->reads.p, b->regions.p, b->pool.p,
+                                          b->q2bit.p, b->qnmask.p, b->sp, b->cand_score.p,
+                                          b->cand_tstart.p, nullptr, bk.chain ? b->chain_payload.p : nullptr,
+                                          bk.chain ? b->chain_cap : 0, bk.chain ? 1 : 0));
+        HIP_TRY(hipEventRecord(b->ev[ev++], st));
+        b->n_score_ev++;
+    }
+    if (!b->brute) {
         // junction decomposition: reverse sweeps over R (one per read); then, group by group, the
         // prefix sweeps (one per read) that leave the wave states and the tail sweeps (one per
         // (read, k1) run of cells) that resume from them
         HIP_TRY(hipEventRecord(b->fork2_ev, st));
         for (size_t i = 0; i < nb; ++i) {
             const Bucket& bk = b->buckets[i];
+            if (bk.chain) continue;
             hipStream_t qa = b->bstreams[2 * i], qb = b->bstreams[2 * i + 1];
             HIP_TRY(hipStreamWaitEvent(qa, b->fork2_ev, 0));
             HIP_TRY(hipStreamWaitEvent(qb, b->fork2_ev, 0));
@@ -1325,7 +1381,7 @@ struct PairSetup {
 
 int prepare_pairs(int device, int32_t n_seqs, const char* seqs, const int64_t* seq_off, int64_t n_pairs,
                   const int32_t* pair_query, const int32_t* pair_target, const nra_scoring_t* sc, PairSetup& ps,
-                  int64_t max_query = NRA_MAX_QLEN_1BLOCK)
+                  int64_t max_query, int64_t max_target, int64_t max_query_score)
 {
     if (n_seqs < 0 || n_pairs < 0) return fail(NRA_E_ARG, "negative count");
     if (n_seqs > 0 && (!seqs || !seq_off)) return fail(NRA_E_ARG, "NULL sequence array");
@@ -1350,7 +1406,7 @@ int prepare_pairs(int device, int32_t n_seqs, const char* seqs, const int64_t* s
         const int64_t len = seq_off[s + 1] - seq_off[s];
         if (len < 0) return fail(NRA_E_ARG, "seq_off must be non-decreasing");
         if (ps.as_target[s] == 0) {
-            if (len > NRA_MAX_TLEN) return fail(NRA_E_RANGE, "target longer than " + std::to_string(NRA_MAX_TLEN));
+            if (len > max_target) return fail(NRA_E_RANGE, "target longer than " + std::to_string(max_target));
             NraDevRegion d{};
             d.p1_off = pool_append(ps.pool, seqs + seq_off[s], (int32_t)len, nullptr, 0, 0, ps.has_n);
             d.p2_off = d.p3_off = d.pr_off = (uint32_t)ps.pool.size();
@@ -1361,7 +1417,7 @@ int prepare_pairs(int device, int32_t n_seqs, const char* seqs, const int64_t* s
         }
         if (ps.as_query[s] == 0) {
             if (len > max_query) return fail(NRA_E_RANGE, "query longer than " + std::to_string(max_query));
-            if (max_score(sc, len) > kScoreCapI32)
+            if (max_score(sc, len) > max_query_score)
                 return fail(NRA_E_RANGE, "query " + std::to_string(s) + ": match score x length does not fit 16 bits");
             NraDevRead r{};
             r.qoff = (uint32_t)base; r.qlen = (int32_t)len; r.region = 0; r.rc = 0;
@@ -1397,52 +1453,68 @@ int nra_align_pairs(int device, int32_t n_seqs, const char* seqs, const int64_t*
     (void)flags;
     if (n_pairs > 0 && (!score || !tstart || !tend)) return fail(NRA_E_ARG, "NULL output array");
     PairSetup ps;
-    int rc = prepare_pairs(device, n_seqs, seqs, seq_off, n_pairs, pair_query, pair_target, sc, ps, NRA_MAX_QLEN);
+    int rc = prepare_pairs(device, n_seqs, seqs, seq_off, n_pairs, pair_query, pair_target, sc, ps, NRA_MAX_QLEN,
+                           NRA_MAX_TLEN_WIDE, (int64_t)1 << 30);
     if (rc || n_pairs == 0) return rc;
-    // tasks by rows-per-lane bucket of the query; bucket kNumR = queries longer than one register
-    // block, swept as chained row blocks (scratch strip per wave)
-    std::vector<std::vector<NraTask>> by_bucket((size_t)kNumR + 1);
+    // Launch groups: int32 cells (score < 32768, target <= 65000 columns) in the rows-per-lane bucket of the
+    // query, or -- queries longer than one register block -- chained row blocks; everything beyond that
+    // (a long core's score, a whole long read as the target) in int64 cells, three row counts.
+    struct Group { int R; bool chain, wide; std::vector<NraTask> tasks; };
+    std::vector<Group> groups;
+    auto group_of = [&](int R, bool chain, bool wide) -> Group& {
+        for (Group& g : groups) if (g.R == R && g.chain == chain && g.wide == wide) return g;
+        groups.push_back(Group{R, chain, wide, {}});
+        return groups.back();
+    };
     int chain_cols = 0;
     for (int64_t i = 0; i < n_pairs; ++i) {
         const int32_t qi = ps.as_query[pair_query[i]];
         const int32_t ti = ps.as_target[pair_target[i]];
-        if (ps.dreads[qi].qlen == 0) continue;
-        const bool lng = ps.dreads[qi].qlen > NRA_MAX_QLEN_1BLOCK;
-        if (lng) chain_cols = std::max(chain_cols, ps.dregs[ti].l1);
-        by_bucket[lng ? kNumR : rows_for_qlen(ps.dreads[qi].qlen)].push_back(NraTask{qi, ti, -1, (int32_t)i});
+        const int qlen = ps.dreads[qi].qlen, tlen = ps.dregs[ti].l1;
+        if (qlen == 0) continue;
+        const bool wide = tlen > NRA_MAX_TLEN || max_score(sc, qlen) > kScoreCapI32;
+        const bool chain = qlen > NRA_MAX_QLEN_1BLOCK;
+        if (chain) chain_cols = std::max(chain_cols, tlen);
+        const int R = chain ? NRA_CHAIN_R
+                            : wide ? (qlen <= 64 * NRA_WIDE_R_SMALL ? NRA_WIDE_R_SMALL : NRA_WIDE_R_LARGE)
+                                   : kRList[rows_for_qlen(qlen)];
+        group_of(R, chain, wide).tasks.push_back(NraTask{qi, ti, -1, (int32_t)i});
     }
+    std::sort(groups.begin(), groups.end(), [](const Group& a, const Group& b) {      // longest first
+        return (int64_t)a.R * (a.chain ? 1000 : 1) > (int64_t)b.R * (b.chain ? 1000 : 1);
+    });
     const int chain_cap = (chain_cols + 127) / 64 * 64 + 64;
-    const int chain_waves = 512;
     std::vector<NraTask> tasks;
     std::vector<int32_t> counts;
-    std::vector<std::pair<int, size_t>> launches;     // (R, offset); R = 0 marks the chained bucket
-    for (int bi = kNumR; bi >= 0; --bi) {
-        if (by_bucket[bi].empty()) continue;
-        launches.push_back({bi == kNumR ? 0 : kRList[bi], tasks.size()});
-        counts.push_back((int32_t)by_bucket[bi].size());
-        tasks.insert(tasks.end(), by_bucket[bi].begin(), by_bucket[bi].end());
+    std::vector<size_t> offs;
+    bool any_chain = false;
+    for (const Group& g : groups) {
+        offs.push_back(tasks.size());
+        counts.push_back((int32_t)g.tasks.size());
+        tasks.insert(tasks.end(), g.tasks.begin(), g.tasks.end());
+        any_chain |= g.chain;
     }
     Arena arena;                       // before the buffers: released after them
     ArenaScope arena_scope(&arena);
     arena.expect(ps.pool.size() + ps.q2bit.size() * 6 + (size_t)n_pairs * 32 + (2u << 20));
     DevBuf<uint8_t> d_pool; DevBuf<uint32_t> d_q2, d_nm; DevBuf<NraDevRegion> d_regs; DevBuf<NraDevRead> d_reads;
-    DevBuf<NraTask> d_tasks; DevBuf<int32_t> d_counts, d_score, d_ts, d_te, d_chain;
+    DevBuf<NraTask> d_tasks; DevBuf<int32_t> d_counts, d_score, d_ts, d_te; DevBuf<int64_t> d_chain;
     HIP_TRY(d_pool.upload(ps.pool)); HIP_TRY(d_q2.upload(ps.q2bit)); HIP_TRY(d_nm.upload(ps.nmask));
     HIP_TRY(d_regs.upload(ps.dregs)); HIP_TRY(d_reads.upload(ps.dreads)); HIP_TRY(d_tasks.upload(tasks));
     HIP_TRY(d_counts.upload(counts));
     HIP_TRY(d_score.alloc((size_t)n_pairs)); HIP_TRY(d_ts.alloc((size_t)n_pairs)); HIP_TRY(d_te.alloc((size_t)n_pairs));
-    if (!by_bucket[kNumR].empty()) HIP_TRY(d_chain.alloc((size_t)chain_waves * 6 * (size_t)chain_cap));
+    if (any_chain) HIP_TRY(d_chain.alloc((size_t)NRA_CHAIN_STRIPS * 6 * (size_t)chain_cap));
     HIP_TRY(hipMemset(d_score.p, 0xff, (size_t)n_pairs * 4));
     HIP_TRY(hipMemset(d_ts.p, 0xff, (size_t)n_pairs * 4));
     HIP_TRY(hipMemset(d_te.p, 0xff, (size_t)n_pairs * 4));
     const NraScoreParams sp = to_params(*sc);
-    for (size_t i = 0; i < launches.size(); ++i) {
-        const bool chained = launches[i].first == 0;
-        LAUNCH_TRY(nra_launch_payload_origin(chained ? NRA_CHAIN_R : launches[i].first, ps.has_n ? 1 : 0, nullptr,
-                                             std::min(counts[i], chained ? chain_waves : 256 * 16),
-                                             d_tasks.p + launches[i].second, d_counts.p + i, d_reads.p, d_regs.p,
+    for (size_t i = 0; i < groups.size(); ++i) {
+        const Group& g = groups[i];
+        LAUNCH_TRY(nra_launch_payload_origin(g.R, ps.has_n ? 1 : 0, nullptr,
+                                             std::min(counts[i], g.chain ? NRA_CHAIN_STRIPS : 256 * 16),
+                                             d_tasks.p + offs[i], d_counts.p + i, d_reads.p, d_regs.p,
                                              d_pool.p, d_q2.p, d_nm.p, sp, d_score.p, d_ts.p, d_te.p,
-                                             chained ? d_chain.p : nullptr, chained ? chain_cap : 0));
+                                             g.chain ? d_chain.p : nullptr, g.chain ? chain_cap : 0, g.wide ? 1 : 0));
     }
     HIP_TRY(hipDeviceSynchronize());
     HIP_TRY(hipMemcpy(score, d_score.p, (size_t)n_pairs * 4, hipMemcpyDeviceToHost));
@@ -1460,7 +1532,8 @@ int nra_align_pairs_cigar(int device, int32_t n_seqs, const char* seqs, const in
     if (n_pairs > 0 && (!score || !tstart || !tend || !qstart || !qend || !cigar || !cigar_off || cigar_cap < 1))
         return fail(NRA_E_ARG, "NULL output array");
     PairSetup ps;
-    int rc = prepare_pairs(device, n_seqs, seqs, seq_off, n_pairs, pair_query, pair_target, sc, ps);
+    int rc = prepare_pairs(device, n_seqs, seqs, seq_off, n_pairs, pair_query, pair_target, sc, ps,
+                           NRA_MAX_QLEN_1BLOCK, NRA_MAX_TLEN, kScoreCapI32);
     if (rc) return rc;
     if (cigar_off) cigar_off[0] = 0;
     if (n_pairs == 0) return NRA_OK;

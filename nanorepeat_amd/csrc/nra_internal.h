@@ -97,17 +97,22 @@ struct NraScoreParams {
 #endif
 #define NRA_MAX_R 48
 #define NRA_MAX_QLEN_1BLOCK (64 * NRA_MAX_R)   // rows one wave holds in registers
-// longer reads are swept in row blocks of 64*NRA_CHAIN_R rows chained through a scratch strip;
-// the int16 cells (biased twice in the junction combine) hold scores up to 2 * 8000
+// longer reads are swept in row blocks of 64*NRA_CHAIN_R rows chained through a scratch strip, one read
+// per wave in int32 cells (1D sweeps) or int32 / int64 payload cells (extents, windows, free pairs)
 #define NRA_CHAIN_R 24
 #define NRA_CHAIN_R_TEST 2                     // tiny row blocks, for the tests (NRA_F_TEST_CHAIN)
-#define NRA_MAX_QLEN 8000
+#define NRA_CHAIN_STRIPS 512                   // waves of a chained launch = scratch strips
+#define NRA_MAX_QLEN 200000                    // read bases (chained row blocks above NRA_MAX_QLEN_1BLOCK)
 // int32 values per lane in one dumped wave state of the 2D prefix sweep (3 per row + 7), shared by
 // the kernel and the host so that the two cannot disagree
 #define NRA_JOINT_NSTATE(R) (3 * (R) + 7)
 // wave states of one group of 2D prefix sweeps: at most this many int32 (16 GiB)
 #define NRA_JOINT_STATE_CAP_INTS (4ull << 30)
-#define NRA_MAX_TLEN 65000     // payload (tstart) is 16 bits; + 64 pipeline columns
+#define NRA_MAX_TLEN 65000     // int32 payload cells: tstart is 16 bits; + 64 pipeline columns
+#define NRA_MAX_TLEN_WIDE 4000000   // int64 payload cells (score << 32 | payload)
+// rows per lane of the int64 payload kernels' unchained instantiations (a rare path: three sizes suffice)
+#define NRA_WIDE_R_SMALL 16
+#define NRA_WIDE_R_LARGE 48
 
 #ifdef __cplusplus
 extern "C" {
@@ -120,35 +125,38 @@ int nra_launch_score_pk16(int R, int has_n, hipStream_t st, int n_tasks,
                           const uint32_t* q2bit, const uint32_t* qnmask,
                           NraScoreParams sp, int32_t* out_score);
 
-// payload kernels walk a device-side queue of *count tasks with a grid stride.  ORIGIN outputs (score, tstart, tend); WINDOW outputs (score, wscore).
+// payload kernels walk a device-side queue of *count tasks with a grid stride.  ORIGIN outputs (score, tstart,
+// tend); WINDOW outputs (score, wscore).  chain_buf != NULL: row-block chaining (n_waves <= NRA_CHAIN_STRIPS
+// strips of 6 * chain_cap cells); wide: int64 cells (R = NRA_WIDE_R_SMALL / NRA_WIDE_R_LARGE, or chained)
 int nra_launch_payload_origin(int R, int has_n, hipStream_t st, int n_waves,
                               const NraTask* tasks, const int32_t* count,
                               const NraDevRead* reads, const NraDevRegion* regions,
                               const uint8_t* pool, const uint32_t* q2bit, const uint32_t* qnmask,
                               NraScoreParams sp,
                               int32_t* out_score, int32_t* out_p, int32_t* out_tend,
-                              int32_t* chain_buf, int chain_cap);   // chain_buf != NULL: row-block chaining
+                              void* chain_buf, int chain_cap, int wide);
 int nra_launch_payload_window(int R, int has_n, hipStream_t st, int n_waves,
                               const NraTask* tasks, const int32_t* count,
                               const NraDevRead* reads, const NraDevRegion* regions,
                               const uint8_t* pool, const uint32_t* q2bit, const uint32_t* qnmask,
                               NraScoreParams sp,
-                              int32_t* out_score, int32_t* out_p, int32_t* out_tend);
+                              int32_t* out_score, int32_t* out_p, int32_t* out_tend,
+                              void* chain_buf, int chain_cap, int wide);
 
-// junction decomposition (nra_sweep.hip): the reverse sweep writes the R-side snapshot and A (per read:
-// read_a, origin-bit scheme) or A_k (per candidate: arr_a, chained reads); the forward sweep combines and
-// writes Score(k) + the flank-test verdict (0 fail, 1 pass, 2 ambiguous)
+// junction decomposition (nra_sweep.hip): the reverse sweep over rev(R) writes the R-side snapshot and A
+// (per read: read_a); the forward sweep combines and writes Score(k) + the flank-test verdict (0 fail,
+// 1 pass, 2 ambiguous).  chain: int32 cells, one read per task, at most NRA_CHAIN_STRIPS waves
 int nra_launch_sweep_bwd(int R, int has_n, int chain, hipStream_t st, int n_tasks, const NraSweepTask* tasks,
                          const NraDevRead* reads, const NraDevRegion* regions, const uint8_t* pool,
                          const uint32_t* q2bit, const uint32_t* qnmask, NraScoreParams sp,
                          const int32_t* kmin, const int32_t* kmax, const uint32_t* coff,
-                         int32_t* snap, int32_t* arr_a,
+                         int32_t* snap,
                          int32_t* read_a, int32_t* chain_buf, int chain_cap);
 int nra_launch_sweep_fwd(int R, int has_n, int chain, hipStream_t st, int n_tasks, const NraSweepTask* tasks,
                          const NraDevRead* reads, const NraDevRegion* regions, const uint8_t* pool,
                          const uint32_t* q2bit, const uint32_t* qnmask, NraScoreParams sp,
                          const int32_t* kmin, const int32_t* kmax, const uint32_t* coff,
-                         int32_t* snap, int32_t* arr_a,
+                         int32_t* snap,
                          int32_t* read_a, int32_t* cand_score, uint8_t* cand_flag, int32_t* chain_buf,
                          int chain_cap);
 

@@ -157,25 +157,29 @@ __global__ __launch_bounds__(WAVE) void k_score_pk16(int n_tasks, const NraPairT
 
 #if NRA_HAS_PART(2) || NRA_HAS_PART(3)
 // ------------------------------------------------------------------------------------
-// k_payload_i32: one candidate per wave, int32 cells = (score << 16) | payload
+// k_payload: one candidate per wave, cells = (score << SH) | payload with the oracle's lexicographic max.
+//   CELL = int32: SH 16 (score < 32768, template <= 65000 columns) -- the common case
+//   CELL = int64: SH 32 -- long cores (scores beyond 32767), long targets (a whole ONT read as the
+//                 target of an anchor), long joint reads; instantiated for three row counts only
 // ------------------------------------------------------------------------------------
-#define NEG32 (-(1 << 29))
-#define WBIAS 0x8000
-
-template <int R, bool HAS_N, int MODE, bool CHAIN>
-__global__ __launch_bounds__(WAVE) void k_payload_i32(const NraTask* __restrict__ tasks,
-                                                      const int32_t* __restrict__ count,
-                                                      const NraDevRead* __restrict__ reads,
-                                                      const NraDevRegion* __restrict__ regions,
-                                                      const uint8_t* __restrict__ pool,
-                                                      const uint32_t* __restrict__ q2bit,
-                                                      const uint32_t* __restrict__ qnmask,
-                                                      NraScoreParams sp,
-                                                      int32_t* __restrict__ out_score,
-                                                      int32_t* __restrict__ out_p,
-                                                      int32_t* __restrict__ out_tend,
-                                                      int32_t* chain_buf, int chain_cap)
+template <typename CELL, int R, bool HAS_N, int MODE, bool CHAIN>
+__global__ __launch_bounds__(WAVE) void k_payload(const NraTask* __restrict__ tasks,
+                                                  const int32_t* __restrict__ count,
+                                                  const NraDevRead* __restrict__ reads,
+                                                  const NraDevRegion* __restrict__ regions,
+                                                  const uint8_t* __restrict__ pool,
+                                                  const uint32_t* __restrict__ q2bit,
+                                                  const uint32_t* __restrict__ qnmask,
+                                                  NraScoreParams sp,
+                                                  int32_t* __restrict__ out_score,
+                                                  int32_t* __restrict__ out_p,
+                                                  int32_t* __restrict__ out_tend,
+                                                  void* chain_buf, int chain_cap)
 {
+    constexpr int SH = sizeof(CELL) == 8 ? 32 : 16;
+    constexpr CELL NEGC = -((CELL)1 << (SH + 13));
+    constexpr CELL PMASK = ((CELL)1 << SH) - 1;
+    constexpr CELL WB = (CELL)1 << (SH - 1);             // bias of the window-score payload
     const int lane = threadIdx.x;
     const int n_tasks = *count;       // written by an earlier kernel on the same stream (or the host)
     // grid-stride over the queue: the trip count is wave-uniform and bounded by n_tasks, so
@@ -192,54 +196,55 @@ __global__ __launch_bounds__(WAVE) void k_payload_i32(const NraTask* __restrict_
         const int wa = imax(0, rg.l1 - 10);
         const int wb = imin(tm.tlen, tm.len1 + tm.len2 + 10);
 
-        int best = 0xffff, bestj = -1;     // (0, max payload): only cells with score >= 1 can beat it
+        CELL best = PMASK;                 // (0, max payload): only cells with score >= 1 can beat it
+        int bestj = -1;
         // CHAIN: a read longer than 64*R rows is swept in row blocks, one after the other in this wave;
         // lane 63 leaves its per-column hand-off (H, F, F2) in a wave-private strip for the next block
         const int n_blk = CHAIN ? (rd.qlen + 64 * R - 1) / (64 * R) : 1;
-        volatile int32_t* strip = CHAIN ? chain_buf + (size_t)blockIdx.x * 6 * chain_cap : nullptr;
+        volatile CELL* strip = CHAIN ? (CELL*)chain_buf + (size_t)blockIdx.x * 6 * chain_cap : nullptr;
       for (int blk = 0; blk < n_blk; ++blk) {
         const int row_base = blk * 64 * R;
         const bool first_blk = blk == 0, last_blk = blk == n_blk - 1;
-        volatile int32_t* cin = CHAIN ? strip + ((blk + 1) & 1) * 3 * chain_cap : nullptr;
-        volatile int32_t* cout = CHAIN ? strip + (blk & 1) * 3 * chain_cap : nullptr;
+        volatile CELL* cin = CHAIN ? strip + ((blk + 1) & 1) * 3 * chain_cap : nullptr;
+        volatile CELL* cout = CHAIN ? strip + (blk & 1) * 3 * chain_cap : nullptr;
 
         int qc[R];
 #pragma unroll
         for (int i = 0; i < R; ++i) qc[i] = query_code<HAS_N>(rd, q2bit, qnmask, row_base + lane * R + i);
 
-        int Hprev[R], E[R], E2[R];
+        CELL Hprev[R], E[R], E2[R];
 #pragma unroll
-        for (int i = 0; i < R; ++i) { Hprev[i] = NEG32; E[i] = NEG32; E2[i] = NEG32; }
-        int Hbot = NEG32, Fout = NEG32, F2out = NEG32, Hup_prev = NEG32;
+        for (int i = 0; i < R; ++i) { Hprev[i] = NEGC; E[i] = NEGC; E2[i] = NEGC; }
+        CELL Hbot = NEGC, Fout = NEGC, F2out = NEGC, Hup_prev = NEGC;
         int tt = NRA_PAD_T;
         int j = -lane;
 
-        const int sA = sp.match << 16, sB = -(sp.mismatch << 16), sN = -(sp.ambi << 16);
-        const int o1 = -(sp.open1 << 16), x1 = -(sp.ext1 << 16);
-        const int o2 = -(sp.open2 << 16), x2 = -(sp.ext2 << 16);
+        const CELL sA = (CELL)sp.match << SH, sB = -((CELL)sp.mismatch << SH), sN = -((CELL)sp.ambi << SH);
+        const CELL o1 = -((CELL)sp.open1 << SH), x1 = -((CELL)sp.ext1 << SH);
+        const CELL o2 = -((CELL)sp.open2 << SH), x2 = -((CELL)sp.ext2 << SH);
 
         const int nchunks = (ncols + 63 + 63) >> 6;
         for (int c = 0; c < nchunks; ++c) {
             int feed = tmpl_code(tm, c * 64 + lane);
-            int inH = NEG32, inF = NEG32, inF2 = NEG32;      // what enters lane 0 at each column
+            CELL inH = NEGC, inF = NEGC, inF2 = NEGC;      // what enters lane 0 at each column
             if (CHAIN) {
                 const int col = c * 64 + lane;
                 if (!first_blk && col < ncols) { inH = cin[col]; inF = cin[chain_cap + col]; inF2 = cin[2 * chain_cap + col]; }
             }
 #pragma unroll 2
             for (int s = 0; s < 64; ++s) {
-                int F = dpp_shr1(CHAIN ? inF : NEG32, Fout);
-                int F2 = dpp_shr1(CHAIN ? inF2 : NEG32, F2out);
+                CELL F = dpp_shr1(CHAIN ? inF : NEGC, Fout);
+                CELL F2 = dpp_shr1(CHAIN ? inF2 : NEGC, F2out);
                 tt = dpp_shr1(feed, tt);
                 feed = dpp_rol1(feed);
 
-                int fresh, s_eq, s_ne, n_eq, n_ne, eo1, ex1, eo2, ex2, fo1, fx1, fo2, fx2;
+                CELL fresh, s_eq, s_ne, n_eq, n_ne, eo1, ex1, eo2, ex2, fo1, fx1, fo2, fx2;
                 if (MODE == 0) {
-                    fresh = j;                               // (0, origin = this column)
+                    fresh = (CELL)j;                         // (0, origin = this column)
                     s_eq = sA; s_ne = sB; n_eq = sN; n_ne = sN;
                     eo1 = fo1 = o1; ex1 = fx1 = x1; eo2 = fo2 = o2; ex2 = fx2 = x2;
                 } else {
-                    fresh = WBIAS;
+                    fresh = WB;
                     const bool inw = (j >= wa) && (j < wb);
                     const int pe = inw ? 2 : 0, pn = inw ? -4 : 0;          // tk.py:464-475
                     s_eq = sA + pe; s_ne = sB + pn; n_eq = sN + pe; n_ne = sN + pn;
@@ -260,15 +265,15 @@ __global__ __launch_bounds__(WAVE) void k_payload_i32(const NraTask* __restrict_
                         if ((qc[i] | tt) & 4) out = eq_ ? n_eq : n_ne;                             \
                     }                                                                              \
                 }
-                int sc;
+                CELL sc;
                 NRA_SUBST(0, sc);
-                int d = imax(Hup_prev, fresh) + sc;   // diagonal of my first row came in one step ago
-                Hup_prev = dpp_shr1(CHAIN ? inH : NEG32, Hbot);
+                CELL d = imax(Hup_prev, fresh) + sc;   // diagonal of my first row came in one step ago
+                Hup_prev = dpp_shr1(CHAIN ? inH : NEGC, Hbot);
                 if (CHAIN) { inH = dpp_rol1(inH); inF = dpp_rol1(inF); inF2 = dpp_rol1(inF2); }
-                int colmax = NEG32, h = NEG32;
+                CELL colmax = NEGC, h = NEGC;
 #pragma unroll
                 for (int i = 0; i < R; ++i) {
-                    int d_next = d;
+                    CELL d_next = d;
                     if (i + 1 < R) {                  // read H(i, j-1) before it is overwritten below
                         NRA_SUBST(i + 1, sc);
                         d_next = imax(Hprev[i], fresh) + sc;
@@ -296,18 +301,18 @@ __global__ __launch_bounds__(WAVE) void k_payload_i32(const NraTask* __restrict_
         }
       }   // row blocks
         // wave reduce: max packed value, then the smallest column holding it
-        int vmax = best;
+        CELL vmax = best;
 #pragma unroll
-        for (int off = 32; off > 0; off >>= 1) vmax = imax(vmax, __shfl_xor(vmax, off, WAVE));
+        for (int off = 32; off > 0; off >>= 1) vmax = imax(vmax, (CELL)__shfl_xor(vmax, off, WAVE));
         int jm = (best == vmax) ? bestj : 0x7fffffff;
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1) jm = imin(jm, __shfl_xor(jm, off, WAVE));
         if (lane == 0) {
-            const int sc = vmax >> 16;
+            const long long sc = (long long)(vmax >> SH);
             const int lo = sp.min_score > 1 ? sp.min_score : 1;
             if (sc >= lo && jm >= 0 && jm != 0x7fffffff) {
-                out_score[tk.out] = sc;
-                out_p[tk.out] = (MODE == 0) ? (vmax & 0xffff) : ((vmax & 0xffff) - WBIAS);
+                out_score[tk.out] = (int32_t)sc;
+                out_p[tk.out] = (MODE == 0) ? (int32_t)(vmax & PMASK) : (int32_t)((vmax & PMASK) - WB);
                 if (out_tend) out_tend[tk.out] = jm + 1;
             } else {
                 out_score[tk.out] = -1;
@@ -483,35 +488,40 @@ extern "C" int nra_launch_score_pk16(int R, int has_n, hipStream_t st, int n_tas
 #endif  // part 1
 
 #if NRA_HAS_PART(2) || NRA_HAS_PART(3)
+// wide = int64 cells: instantiated for NRA_WIDE_R_SMALL / NRA_WIDE_R_LARGE rows per lane (unchained) and
+// NRA_CHAIN_R / NRA_CHAIN_R_TEST (chained); int32 cells: every R unchained, chained as above
 template <int MODE>
-static int launch_payload(int R, int has_n, hipStream_t st, int n_waves, const NraTask* tasks,
+static int launch_payload(int R, int has_n, int wide, hipStream_t st, int n_waves, const NraTask* tasks,
                           const int32_t* count, const NraDevRead* reads,
                           const NraDevRegion* regions, const uint8_t* pool, const uint32_t* q2bit,
                           const uint32_t* qnmask, NraScoreParams sp, int32_t* out_score,
-                          int32_t* out_p, int32_t* out_tend, int32_t* chain_buf = nullptr, int chain_cap = 0)
+                          int32_t* out_p, int32_t* out_tend, void* chain_buf = nullptr, int chain_cap = 0)
 {
 #define PARGS tasks, count, reads, regions, pool, q2bit, qnmask, sp, out_score, out_p, out_tend, chain_buf, chain_cap
-    if (chain_buf) {   // row-block chaining (ORIGIN only): the instantiations long reads and the tests use
-        if (MODE != 0) return (int)hipErrorInvalidValue;
-        if (R == NRA_CHAIN_R) {
-            if (has_n) k_payload_i32<NRA_CHAIN_R, true, 0, true><<<n_waves, WAVE, 0, st>>>(PARGS);
-            else k_payload_i32<NRA_CHAIN_R, false, 0, true><<<n_waves, WAVE, 0, st>>>(PARGS);
-        } else if (R == NRA_CHAIN_R_TEST) {
-            if (has_n) k_payload_i32<NRA_CHAIN_R_TEST, true, 0, true><<<n_waves, WAVE, 0, st>>>(PARGS);
-            else k_payload_i32<NRA_CHAIN_R_TEST, false, 0, true><<<n_waves, WAVE, 0, st>>>(PARGS);
-        } else return (int)hipErrorInvalidValue;
+#define LAUNCH(CELL, r, chain)                                                                      \
+    do {                                                                                            \
+        if (has_n) k_payload<CELL, r, true, MODE, chain><<<n_waves, WAVE, 0, st>>>(PARGS);          \
+        else k_payload<CELL, r, false, MODE, chain><<<n_waves, WAVE, 0, st>>>(PARGS);               \
+    } while (0)
+    if (chain_buf) {   // row-block chaining: the instantiations long reads and the tests use
+        if (R == NRA_CHAIN_R) { if (wide) LAUNCH(long long, NRA_CHAIN_R, true); else LAUNCH(int, NRA_CHAIN_R, true); }
+        else if (R == NRA_CHAIN_R_TEST) { if (wide) LAUNCH(long long, NRA_CHAIN_R_TEST, true); else LAUNCH(int, NRA_CHAIN_R_TEST, true); }
+        else return (int)hipErrorInvalidValue;
         return (int)hipGetLastError();
     }
-#define CASE(r)                                                                                     \
-    case r:                                                                                         \
-        if (has_n) k_payload_i32<r, true, MODE, false><<<n_waves, WAVE, 0, st>>>(PARGS); \
-        else k_payload_i32<r, false, MODE, false><<<n_waves, WAVE, 0, st>>>(PARGS);       \
-        break;
+    if (wide) {
+        if (R == NRA_WIDE_R_SMALL) LAUNCH(long long, NRA_WIDE_R_SMALL, false);
+        else if (R == NRA_WIDE_R_LARGE) LAUNCH(long long, NRA_WIDE_R_LARGE, false);
+        else return (int)hipErrorInvalidValue;
+        return (int)hipGetLastError();
+    }
+#define CASE(r) case r: LAUNCH(int, r, false); break;
     switch (R) {
         NRA_R_LIST(CASE)
     default: return (int)hipErrorInvalidValue;
     }
 #undef CASE
+#undef LAUNCH
 #undef PARGS
     return (int)hipGetLastError();
 }
@@ -522,10 +532,10 @@ extern "C" int nra_launch_payload_origin(int R, int has_n, hipStream_t st, int n
                                          const NraDevRead* reads, const NraDevRegion* regions,
                                          const uint8_t* pool, const uint32_t* q2bit, const uint32_t* qnmask,
                                          NraScoreParams sp, int32_t* out_score, int32_t* out_p,
-                                         int32_t* out_tend, int32_t* chain_buf, int chain_cap)
+                                         int32_t* out_tend, void* chain_buf, int chain_cap, int wide)
 {
     if (n_waves <= 0) return 0;
-    return launch_payload<0>(R, has_n, st, n_waves, tasks, count, reads, regions, pool, q2bit, qnmask, sp, out_score, out_p, out_tend, chain_buf, chain_cap);
+    return launch_payload<0>(R, has_n, wide, st, n_waves, tasks, count, reads, regions, pool, q2bit, qnmask, sp, out_score, out_p, out_tend, chain_buf, chain_cap);
 }
 #endif
 #if NRA_HAS_PART(3)
@@ -534,10 +544,10 @@ extern "C" int nra_launch_payload_window(int R, int has_n, hipStream_t st, int n
                                          const NraDevRead* reads, const NraDevRegion* regions,
                                          const uint8_t* pool, const uint32_t* q2bit, const uint32_t* qnmask,
                                          NraScoreParams sp, int32_t* out_score, int32_t* out_p,
-                                         int32_t* out_tend)
+                                         int32_t* out_tend, void* chain_buf, int chain_cap, int wide)
 {
     if (n_waves <= 0) return 0;
-    return launch_payload<1>(R, has_n, st, n_waves, tasks, count, reads, regions, pool, q2bit, qnmask, sp, out_score, out_p, out_tend);
+    return launch_payload<1>(R, has_n, wide, st, n_waves, tasks, count, reads, regions, pool, q2bit, qnmask, sp, out_score, out_p, out_tend, chain_buf, chain_cap);
 }
 #endif
 #endif  // parts 2, 3

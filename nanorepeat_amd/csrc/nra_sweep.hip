@@ -80,6 +80,11 @@ __device__ __forceinline__ int pmax3(int a, int b, int c)
     return __builtin_bit_cast(int, __builtin_elementwise_maximum(__builtin_elementwise_maximum(x, y), z));
 }
 
+// cell arithmetic of the sweeps: packed int16 pairs (two reads per wave, biased), or -- WIDE, the chained
+// sweeps of reads longer than one register block -- plain int32 (one read per wave, no bias, no range limit)
+template <bool W> __device__ __forceinline__ int mx2(int a, int b) { return W ? imax(a, b) : pmaxi(a, b); }
+template <bool W> __device__ __forceinline__ int mx3(int a, int b, int c) { return W ? imax(imax(a, b), c) : pmax3(a, b, c); }
+
 // selector byte of one query row for v_perm_b32: 0..3 base, 4 padding row, 5 N
 template <bool HAS_N>
 __device__ __forceinline__ int sweep_query_sel(const NraDevRead& rd, const uint32_t* q2bit,
@@ -97,26 +102,26 @@ __device__ __forceinline__ int sweep_query_sel(const NraDevRead& rd, const uint3
 // One virtual systolic cell: rows [OFF, OFF+N) of the lane's arrays, one template column.
 // diag = H(row above, j-1) - o1; F/F2 enter from the row above at this column and leave for the
 // row below.  Returns nothing; the cell's last-row Hq is Hq[OFF+N-1].
-template <int OFF, int N, int R>
+template <int OFF, int N, int R, bool W = false>
 __device__ __forceinline__ void sweep_cell(int (&Hq)[R], int (&Hq2)[R], int (&E)[R], int (&E2)[R],
                                            const int (&qc)[R], int diag, int& F, int& F2, int& M,
                                            int tbl, int tbl_hi, int v_floor, int v_e1, int v_e2,
                                            int v_o1, int v_o2)
 {
     if (N == 0) return;
-    int d = pmaxi(diag, v_floor) + (int)__builtin_amdgcn_perm(tbl_hi, tbl, qc[OFF]);
+    int d = mx2<W>(diag, v_floor) + (int)__builtin_amdgcn_perm(tbl_hi, tbl, qc[OFF]);
     int h_prev = 0;
 #pragma unroll
     for (int n = 0; n < N; ++n) {
         const int i = OFF + n;
         int d_next = d;
         if (n + 1 < N)                         // uses H(i, j-1) before it is overwritten below
-            d_next = pmaxi(Hq[i], v_floor) + (int)__builtin_amdgcn_perm(tbl_hi, tbl, qc[i + 1]);
-        const int ein = pmaxi(E[i] - v_e1, Hq[i]);            // E(i,j) from column j-1, lazily
-        const int e2in = pmaxi(E2[i] - v_e2, Hq2[i]);
-        const int h = pmax3(pmax3(d, ein, F), e2in, F2);      // H(i,j)
-        if (n & 1) M = pmax3(M, h_prev, h);                   // running maximum, two rows per instruction
-        else if (n == N - 1) M = pmaxi(M, h);
+            d_next = mx2<W>(Hq[i], v_floor) + (int)__builtin_amdgcn_perm(tbl_hi, tbl, qc[i + 1]);
+        const int ein = mx2<W>(E[i] - v_e1, Hq[i]);           // E(i,j) from column j-1, lazily
+        const int e2in = mx2<W>(E2[i] - v_e2, Hq2[i]);
+        const int h = mx3<W>(mx3<W>(d, ein, F), e2in, F2);    // H(i,j)
+        if (n & 1) M = mx3<W>(M, h_prev, h);                  // running maximum, two rows per instruction
+        else if (n == N - 1) M = mx2<W>(M, h);
         else h_prev = h;
         E[i] = ein;
         E2[i] = e2in;
@@ -124,8 +129,8 @@ __device__ __forceinline__ void sweep_cell(int (&Hq)[R], int (&Hq2)[R], int (&E)
         Hq[i] = hq;
         const int hq2 = h - v_o2;
         Hq2[i] = hq2;
-        F = pmaxi(F - v_e1, hq);
-        F2 = pmaxi(F2 - v_e2, hq2);
+        F = mx2<W>(F - v_e1, hq);
+        F2 = mx2<W>(F2 - v_e2, hq2);
         d = d_next;
     }
 }
@@ -133,7 +138,7 @@ __device__ __forceinline__ void sweep_cell(int (&Hq)[R], int (&Hq2)[R], int (&E)
 // junction combine of one cell's rows at a boundary column (values biased twice).  The forward H is
 // taken as it is, not as max(H, 0): a term with H < 0 is below Hb alone, an alignment inside R, and
 // that is in the final maximum anyway (A, or A_k for chained reads).
-template <int OFF, int N, int R>
+template <int OFF, int N, int R, bool W = false>
 __device__ __forceinline__ int sweep_combine(const int (&Hq)[R], const int (&E)[R], const int (&E2)[R],
                                              const int (&Hbo)[R], const int (&Ebo)[R],
                                              const int (&E2bo)[R], int tS)
@@ -145,9 +150,9 @@ __device__ __forceinline__ int sweep_combine(const int (&Hq)[R], const int (&E)[
         const int t1 = Hq[i] + Hbo[i];
         const int t2 = E[i] + Ebo[i];
         const int t3 = E2[i] + E2bo[i];
-        tS = pmax3(tS, t1, t2);
-        if (n & 1) tS = pmax3(tS, t3_prev, t3);
-        else if (n == N - 1) tS = pmaxi(tS, t3);
+        tS = mx3<W>(tS, t1, t2);
+        if (n & 1) tS = mx3<W>(tS, t3_prev, t3);
+        else if (n == N - 1) tS = mx2<W>(tS, t3);
         else t3_prev = t3;
     }
     return tS;
@@ -171,28 +176,31 @@ __device__ __forceinline__ void sweep_snapshot(const int (&Hq)[R], const int (&E
     }
 }
 
+// CHAIN = the WIDE sweeps: reads longer than one register block (3072 bases) are swept as consecutive row
+// blocks of 64*R rows by one wave, ONE read per wave in plain int32 cells (2*score + origin bit: no range
+// limit worth naming), the last cell of a block leaving its per-column hand-off in a scratch strip that
+// the next block's first cell picks up.  A launch has at most as many waves as there are strips and walks
+// its tasks with a grid stride.
 template <int R, bool HAS_N, int DIR, bool CHAIN>
-__global__ __launch_bounds__(WAVE) void k_sweep_pk16(int n_tasks, const NraSweepTask* __restrict__ tasks,
-                                                     const NraDevRead* __restrict__ reads,
-                                                     const NraDevRegion* __restrict__ regions,
-                                                     const uint8_t* __restrict__ pool,
-                                                     const uint32_t* __restrict__ q2bit,
-                                                     const uint32_t* __restrict__ qnmask,
-                                                     NraScoreParams sp,
-                                                     const int32_t* __restrict__ kmin_arr,
-                                                     const int32_t* __restrict__ kmax_arr,
-                                                     const uint32_t* __restrict__ coff,
-                                                     int32_t* __restrict__ snap,
-                                                     int32_t* __restrict__ arr_a,
-                                                     int32_t* __restrict__ read_a,
-                                                     int32_t* __restrict__ cand_score,
-                                                     uint8_t* __restrict__ cand_flag,
-                                                     int32_t* chain_buf, int chain_cap)
+__device__ __forceinline__ void sweep_dpp_task(int task, const NraSweepTask* __restrict__ tasks,
+                                               const NraDevRead* __restrict__ reads,
+                                               const NraDevRegion* __restrict__ regions,
+                                               const uint8_t* __restrict__ pool,
+                                               const uint32_t* __restrict__ q2bit,
+                                               const uint32_t* __restrict__ qnmask,
+                                               const NraScoreParams& sp,
+                                               const int32_t* __restrict__ kmin_arr,
+                                               const int32_t* __restrict__ kmax_arr,
+                                               const uint32_t* __restrict__ coff,
+                                               int32_t* __restrict__ snap,
+                                               int32_t* __restrict__ read_a,
+                                               int32_t* __restrict__ cand_score,
+                                               uint8_t* __restrict__ cand_flag,
+                                               int32_t* chain_buf, int chain_cap)
 {
-    constexpr bool BIT = !CHAIN;          // origin-bit scheme: doubled scores, short reverse sweep
-    constexpr int SC = BIT ? 2 : 1;
-    const int task = blockIdx.x;
-    if (task >= n_tasks) return;
+    constexpr bool W = CHAIN;             // wide cells
+    constexpr int SC = 2;                 // origin-bit scheme: doubled scores, reverse sweep over rev(R) only
+    constexpr int BIASW = W ? 0 : BIAS;
     const int lane = threadIdx.x;
     const NraSweepTask tk = tasks[task];
     const bool has_b = tk.read_b >= 0;
@@ -202,25 +210,26 @@ __global__ __launch_bounds__(WAVE) void k_sweep_pk16(int n_tasks, const NraSweep
     const int m = rg.m1;
     const int flank = DIR ? rg.l1 : rg.l3;
     const uint8_t* __restrict__ piece = pool + (DIR ? rg.p1_off : rg.pr_off);
-    const int ncols = (BIT && DIR == 0) ? flank : flank + m * tk.kmax;
-    // boundary column of k = kmin (>= 0: flank >= 1); the short reverse sweep has one: R[0]
-    const int jfirst = (BIT && DIR == 0) ? flank - 1 : flank + m * tk.kmin - 1;
+    const int ncols = DIR == 0 ? flank : flank + m * tk.kmax;
+    // boundary column of k = kmin (>= 0: flank >= 1); the reverse sweep has one: R[0]
+    const int jfirst = DIR == 0 ? flank - 1 : flank + m * tk.kmin - 1;
     const int kmin_a = kmin_arr[ra], kmax_a = kmax_arr[ra];
     const int kmin_b = kmin_arr[rb], kmax_b = kmax_arr[rb];
     const uint32_t coff_a = coff[ra], coff_b = coff[rb];
     int32_t* __restrict__ snap_task = snap + tk.snap_off;
 
     const int o1 = SC * sp.open1, o2 = SC * sp.open2;
-    const int P1 = 0x00010001;
-    const int v_floor = (BIAS - o1) * P1;                   // max(H,0) - o1 (even: the origin bit is free)
+    const int P1 = W ? 1 : 0x00010001;
+    const int v_floor = (BIASW - o1) * P1;                  // max(H,0) - o1 (even: the origin bit is free)
     const int v_o1 = o1 * P1, v_e1 = SC * sp.ext1 * P1, v_o2 = o2 * P1, v_e2 = SC * sp.ext2 * P1;
-    const int NEG1 = NEGB * P1, NEG2 = 2 * NEGB * P1;       // "minus infinity", biased once / twice
+    const int NEG1 = W ? -(1 << 28) : NEGB * P1;            // "minus infinity", biased once / twice
+    const int NEG2 = W ? -(1 << 28) : 2 * NEGB * P1;
     // substitution scores + o1 (the diagonal is read from Hq = H - o1): all in [0, 127]
     const int s_match = SC * sp.match + o1, s_mis = o1 - SC * sp.mismatch, s_ambi = o1 - SC * sp.ambi;
     const int tbl_hi = s_mis | (s_ambi << 8);               // selector 4: padding row, 5: N in the read
     const int tbl_mis4 = s_mis * 0x01010101, tbl_ambi4 = s_ambi * 0x01010101;
 
-    // Score(k) and the flank verdict (or A_k) leave through lane 63, one boundary column at a time.  They
+    // Score(k) and the flank verdict leave through lane 63, one boundary column at a time.  They
     // are collected in a lane-indexed register -- rotated one lane down per boundary, the newest value in
     // lane 63 -- and written 64 candidates at a time, one coalesced line per read.
     int out_a = 0, out_b = 0;
@@ -237,20 +246,14 @@ __global__ __launch_bounds__(WAVE) void k_sweep_pk16(int n_tasks, const NraSweep
             if (k < lo_k || k > hi_k) continue;
             const uint32_t idx = (s2 ? coff_b : coff_a) + (uint32_t)(k - lo_k);
             const int v = s2 ? out_b : out_a;
-            if (DIR == 0) {
-                arr_a[idx] = v;                             // running max of the reverse sweep = A_k
-            } else {
-                cand_score[idx] = v >> 2;                   // (score << 2) | verdict; -1: below min_dp_score
-                cand_flag[idx] = (uint8_t)(v & 3);
-            }
+            cand_score[idx] = v >> 2;                       // (score << 2) | verdict; -1: below min_dp_score
+            cand_flag[idx] = (uint8_t)(v & 3);
         }
     };
 
-    // CHAIN: reads longer than 64*R rows are swept in row blocks of 64*R, one after the other in this
-    // wave; the last virtual cell of block b leaves its per-column hand-off (H, F, F2 and the two
-    // travelling accumulators) in a wave-private scratch strip that block b+1's first cell picks up.
+    // CHAIN: row blocks of 64*R, one after the other in this wave; the strip belongs to the wave (blockIdx)
     const int n_blk = CHAIN ? (imax(rda.qlen, rdb.qlen) + 64 * R - 1) / (64 * R) : 1;
-    volatile int32_t* strip = CHAIN ? chain_buf + (size_t)task * 10 * chain_cap : nullptr;
+    volatile int32_t* strip = CHAIN ? chain_buf + (size_t)blockIdx.x * 10 * chain_cap : nullptr;
   for (int blk = 0; blk < n_blk; ++blk) {
     const int row_base = blk * 64 * R;
     const bool first_blk = blk == 0, last_blk = blk == n_blk - 1;
@@ -262,7 +265,7 @@ __global__ __launch_bounds__(WAVE) void k_sweep_pk16(int n_tasks, const NraSweep
     for (int i = 0; i < R; ++i) {
         const int gi = row_base + lane * R + i;
         const int ca = sweep_query_sel<HAS_N>(rda, q2bit, qnmask, gi, DIR == 0);
-        const int cb = sweep_query_sel<HAS_N>(rdb, q2bit, qnmask, gi, DIR == 0);
+        const int cb = W ? 0x0c : sweep_query_sel<HAS_N>(rdb, q2bit, qnmask, gi, DIR == 0);
         qc[i] = ca | (0x0c << 8) | (cb << 16) | (0x0c << 24);
     }
 
@@ -285,14 +288,14 @@ __global__ __launch_bounds__(WAVE) void k_sweep_pk16(int n_tasks, const NraSweep
                     const int al = w / R, ai = w - al * R;
                     const int32_t* __restrict__ p = snap_task + ((size_t)ablk * 3 * R + ai) * 64 + al;
                     const int vh = p[0], ve = p[R * 64], ve2 = p[2 * R * 64];
-                    h[s] = (s ? half_hi(vh) : half_lo(vh)) + 2 * o1;    // Hq carries -o1 on either side
-                    e[s] = (s ? half_hi(ve) : half_lo(ve)) + q1;
-                    e2[s] = (s ? half_hi(ve2) : half_lo(ve2)) + q2;
-                } else { h[s] = BIAS + o1 - SC; e[s] = BIAS - SC; e2[s] = BIAS - SC; }
+                    h[s] = (W ? vh : (s ? half_hi(vh) : half_lo(vh))) + 2 * o1;    // Hq carries -o1 on either side
+                    e[s] = (W ? ve : (s ? half_hi(ve) : half_lo(ve))) + q1;
+                    e2[s] = (W ? ve2 : (s ? half_hi(ve2) : half_lo(ve2))) + q2;
+                } else { h[s] = BIASW + o1 - SC; e[s] = BIASW - SC; e2[s] = BIASW - SC; }
             }
-            Hbo[i] = pack2(h[0], h[1]);
-            Ebo[i] = pack2(e[0], e[1]);
-            E2bo[i] = pack2(e2[0], e2[1]);
+            Hbo[i] = W ? h[0] : pack2(h[0], h[1]);
+            Ebo[i] = W ? e[0] : pack2(e[0], e[1]);
+            E2bo[i] = W ? e2[0] : pack2(e2[0], e2[1]);
         }
     }
 
@@ -306,8 +309,8 @@ __global__ __launch_bounds__(WAVE) void k_sweep_pk16(int n_tasks, const NraSweep
     // step carries two independent dependency chains per wave: the sweeps run with only a few
     // waves per SIMD and need the instruction-level parallelism.
     constexpr int RA = (R + 1) / 2, RB = R - RA;
-    int HbotA = v_floor, FoutA = NEG1, F2outA = NEG1, HupA_prev = v_floor, MA = BIAS * P1;
-    int HbotB = v_floor, FoutB = NEG1, F2outB = NEG1, HupB_prev = v_floor, MB = BIAS * P1;
+    int HbotA = v_floor, FoutA = NEG1, F2outA = NEG1, HupA_prev = v_floor, MA = BIASW * P1;
+    int HbotB = v_floor, FoutB = NEG1, F2outB = NEG1, HupB_prev = v_floor, MB = BIASW * P1;
     int accS_A = NEG2, accB_A = NEG1, accS_B = NEG2, accB_B = NEG1;
     int ttA = tbl_mis4, ttB = tbl_mis4;                   // padding column: everything mismatches
     n_out = 0; kcur = tk.kmin;
@@ -329,7 +332,7 @@ __global__ __launch_bounds__(WAVE) void k_sweep_pk16(int n_tasks, const NraSweep
                     feed = code < 4 ? tbl_mis4 + ((s_match - s_mis) << (8 * code)) : tbl_ambi4;
                     if (col >= jfirst && (col - jfirst) % m == 0) feed |= FLAG_BOUNDARY;
                     if (DIR == 0 && col == flank - 1) feed |= FLAG_SNAPSHOT;
-                    if (BIT && DIR == 1 && col >= flank) feed |= FLAG_INREP;
+                    if (DIR == 1 && col >= flank) feed |= FLAG_INREP;
                 }
                 if (CHAIN) {
                     inH = v_floor; inF = NEG1; inF2 = NEG1; inS = NEG2; inB = NEG1;
@@ -358,14 +361,14 @@ __global__ __launch_bounds__(WAVE) void k_sweep_pk16(int n_tasks, const NraSweep
             const int accS_Bin = accS_A, accB_Bin = accB_A;
 
             // the empty alignment a path may start from at this column: score 0, origin bit from the flag
-            const int floorA = (BIT && DIR == 1) ? (int)((((unsigned)ttA_new >> 15) & (unsigned)P1) | (unsigned)v_floor) : v_floor;
-            const int floorB = (BIT && DIR == 1) ? (int)((((unsigned)ttB_new >> 15) & (unsigned)P1) | (unsigned)v_floor) : v_floor;
-            sweep_cell<0, RA, R>(Hq, Hq2, E, E2, qc, HupA_prev, FA, F2A, MA, ttA_new & 0x7f7f7f7f, tbl_hi,
-                                 floorA, v_e1, v_e2, v_o1, v_o2);
+            const int floorA = DIR == 1 ? (int)((((unsigned)ttA_new >> 15) & (unsigned)P1) | (unsigned)v_floor) : v_floor;
+            const int floorB = DIR == 1 ? (int)((((unsigned)ttB_new >> 15) & (unsigned)P1) | (unsigned)v_floor) : v_floor;
+            sweep_cell<0, RA, R, W>(Hq, Hq2, E, E2, qc, HupA_prev, FA, F2A, MA, ttA_new & 0x7f7f7f7f, tbl_hi,
+                                    floorA, v_e1, v_e2, v_o1, v_o2);
             HupA_prev = hupA; HbotA = Hq[RA - 1]; FoutA = FA; F2outA = F2A;
             if (RB > 0) {
-                sweep_cell<RA, RB, R>(Hq, Hq2, E, E2, qc, HupB_prev, FB, F2B, MB, ttB_new & 0x7f7f7f7f, tbl_hi,
-                                      floorB, v_e1, v_e2, v_o1, v_o2);
+                sweep_cell<RA, RB, R, W>(Hq, Hq2, E, E2, qc, HupB_prev, FB, F2B, MB, ttB_new & 0x7f7f7f7f, tbl_hi,
+                                         floorB, v_e1, v_e2, v_o1, v_o2);
                 HbotB = Hq[R - 1];
             } else {
                 HbotB = hupB;                             // empty cell: hand everything through
@@ -378,14 +381,14 @@ __global__ __launch_bounds__(WAVE) void k_sweep_pk16(int n_tasks, const NraSweep
             int tSA = NEG2, tSB = NEG2;
             if constexpr (DIR != 0) {
                 if (at_mask != 0) {
-                    tSA = sweep_combine<0, RA, R>(Hq, E, E2, Hbo, Ebo, E2bo, tSA);
-                    tSB = sweep_combine<RA, RB, R>(Hq, E, E2, Hbo, Ebo, E2bo, tSB);
+                    tSA = sweep_combine<0, RA, R, W>(Hq, E, E2, Hbo, Ebo, E2bo, tSA);
+                    tSB = sweep_combine<RA, RB, R, W>(Hq, E, E2, Hbo, Ebo, E2bo, tSB);
                 }
             }
-            accS_A = pmaxi(accS_Ain, tSA);
-            accB_A = pmaxi(accB_Ain, MA);
-            accS_B = pmaxi(accS_Bin, tSB);
-            accB_B = RB > 0 ? pmaxi(accB_Bin, MB) : accB_Bin;   // an empty cell adds nothing of its own
+            accS_A = mx2<W>(accS_Ain, tSA);
+            accB_A = mx2<W>(accB_Ain, MA);
+            accS_B = mx2<W>(accS_Bin, tSB);
+            accB_B = RB > 0 ? mx2<W>(accB_Bin, MB) : accB_Bin;  // an empty cell adds nothing of its own
 
             if (DIR == 0) {
                 int32_t* __restrict__ snap_blk = snap_task + (size_t)blk * 3 * R * 64;
@@ -401,42 +404,27 @@ __global__ __launch_bounds__(WAVE) void k_sweep_pk16(int n_tasks, const NraSweep
             }
             // cell 127 (lane 63, cell B) has finished a boundary column: wave-uniform branch
             if (last_blk && (__builtin_amdgcn_ballot_w64(atB) >> 63) != 0) {
-                if (BIT && DIR == 0) {
-                    // the one boundary of the short reverse sweep: A = best alignment inside R (doubled)
+                if (DIR == 0) {
+                    // the one boundary of the reverse sweep: A = best alignment inside R (doubled)
                     if (lane == 63) {
-                        read_a[ra] = half_lo(accB_B) - BIAS;
-                        if (has_b) read_a[rb] = half_hi(accB_B) - BIAS;
+                        read_a[ra] = (W ? accB_B : half_lo(accB_B)) - BIASW;
+                        if (has_b) read_a[rb] = half_hi(accB_B) - BIASW;
                     }
                 } else {
-                    const int k = kcur;
                     int va = 0, vb = 0;
                     if (lane == 63) {
 #pragma unroll
-                        for (int s2 = 0; s2 < 2; ++s2) {
-                            const int B = (s2 ? half_hi(accB_B) : half_lo(accB_B)) - BIAS;
-                            int v;
-                            if (DIR == 0) {
-                                v = B;
-                            } else {
-                                const int lo_k = s2 ? kmin_b : kmin_a, hi_k = s2 ? kmax_b : kmax_a;
-                                const int S = (s2 ? half_hi(accS_B) : half_lo(accS_B)) - 2 * BIAS;
-                                const int lo = sp.min_score > 1 ? sp.min_score : 1;
-                                int best, flag = 1;
-                                if (BIT) {
-                                    // packed 2*score + origin bit; an alignment inside R starts at a column >= |L|
-                                    const int V = imax(imax(S, B), read_a[s2 ? rb : ra] + 1);
-                                    best = V >> 1;
-                                    if (V & 1) flag = 0;                                  // an optimal alignment starts at >= |L|
-                                    else if ((B >> 1) >= best) flag = ((S >> 1) >= best) ? 2 : 0;
-                                } else {
-                                    int A = 0;
-                                    if (k >= lo_k && k <= hi_k) A = arr_a[(s2 ? coff_b : coff_a) + (uint32_t)(k - lo_k)];
-                                    best = imax(imax(S, B), A);
-                                    if (A >= best) flag = 0;                          // an optimal alignment starts in unit^k+R
-                                    else if (B >= best) flag = (S >= best) ? 2 : 0;   // one ends inside L+unit^k
-                                }
-                                v = ((best >= lo ? best : -1) << 2) | flag;
-                            }
+                        for (int s2 = 0; s2 < (W ? 1 : 2); ++s2) {
+                            const int B = (W ? accB_B : (s2 ? half_hi(accB_B) : half_lo(accB_B))) - BIASW;
+                            const int S = (W ? accS_B : (s2 ? half_hi(accS_B) : half_lo(accS_B))) - 2 * BIASW;
+                            const int lo = sp.min_score > 1 ? sp.min_score : 1;
+                            // packed 2*score + origin bit; an alignment inside R starts at a column >= |L|
+                            const int V = imax(imax(S, B), read_a[s2 ? rb : ra] + 1);
+                            const int best = V >> 1;
+                            int flag = 1;
+                            if (V & 1) flag = 0;                                  // an optimal alignment starts at >= |L|
+                            else if ((B >> 1) >= best) flag = ((S >> 1) >= best) ? 2 : 0;   // one ends inside L+unit^k
+                            const int v = ((best >= lo ? best : -1) << 2) | flag;
                             if (s2) vb = v; else va = v;
                         }
                     }
@@ -448,8 +436,31 @@ __global__ __launch_bounds__(WAVE) void k_sweep_pk16(int n_tasks, const NraSweep
             }
         }
     }
-    if (last_blk && n_out > 0) flush(n_out);
+    if (DIR == 1 && last_blk && n_out > 0) flush(n_out);
   }   // row blocks
+}
+
+template <int R, bool HAS_N, int DIR, bool CHAIN>
+__global__ __launch_bounds__(WAVE) void k_sweep_pk16(int n_tasks, const NraSweepTask* __restrict__ tasks,
+                                                     const NraDevRead* __restrict__ reads,
+                                                     const NraDevRegion* __restrict__ regions,
+                                                     const uint8_t* __restrict__ pool,
+                                                     const uint32_t* __restrict__ q2bit,
+                                                     const uint32_t* __restrict__ qnmask,
+                                                     NraScoreParams sp,
+                                                     const int32_t* __restrict__ kmin_arr,
+                                                     const int32_t* __restrict__ kmax_arr,
+                                                     const uint32_t* __restrict__ coff,
+                                                     int32_t* __restrict__ snap,
+                                                     int32_t* __restrict__ read_a,
+                                                     int32_t* __restrict__ cand_score,
+                                                     uint8_t* __restrict__ cand_flag,
+                                                     int32_t* chain_buf, int chain_cap)
+{
+    // unchained: one task per wave; chained: the launch has one wave per scratch strip (trip count wave-uniform)
+    for (int task = blockIdx.x; task < n_tasks; task += gridDim.x)
+        sweep_dpp_task<R, HAS_N, DIR, CHAIN>(task, tasks, reads, regions, pool, q2bit, qnmask, sp, kmin_arr, kmax_arr,
+                                             coff, snap, read_a, cand_score, cand_flag, chain_buf, chain_cap);
 }
 
 // ------------------------------------------------------------------------------------
@@ -670,18 +681,19 @@ static int launch_sweep(int R, int has_n, int chain, hipStream_t st, int n_tasks
                         const NraDevRead* reads, const NraDevRegion* regions, const uint8_t* pool,
                         const uint32_t* q2bit, const uint32_t* qnmask, NraScoreParams sp,
                         const int32_t* kmin, const int32_t* kmax, const uint32_t* coff,
-                        int32_t* snap, int32_t* arr_a, int32_t* read_a,
+                        int32_t* snap, int32_t* read_a,
                         int32_t* cand_score, uint8_t* cand_flag, int32_t* chain_buf, int chain_cap)
 {
     if (n_tasks <= 0) return 0;
-#define ARGS n_tasks, tasks, reads, regions, pool, q2bit, qnmask, sp, kmin, kmax, coff, snap, arr_a, read_a, cand_score, cand_flag, chain_buf, chain_cap
+#define ARGS n_tasks, tasks, reads, regions, pool, q2bit, qnmask, sp, kmin, kmax, coff, snap, read_a, cand_score, cand_flag, chain_buf, chain_cap
     if (chain) {      // row-block chaining: only the instantiations long reads (and the tests) use
+        const int n_waves = n_tasks < NRA_CHAIN_STRIPS ? n_tasks : NRA_CHAIN_STRIPS;
         if (R == NRA_CHAIN_R) {
-            if (has_n) k_sweep_pk16<NRA_CHAIN_R, true, DIR, true><<<n_tasks, WAVE, 0, st>>>(ARGS);
-            else k_sweep_pk16<NRA_CHAIN_R, false, DIR, true><<<n_tasks, WAVE, 0, st>>>(ARGS);
+            if (has_n) k_sweep_pk16<NRA_CHAIN_R, true, DIR, true><<<n_waves, WAVE, 0, st>>>(ARGS);
+            else k_sweep_pk16<NRA_CHAIN_R, false, DIR, true><<<n_waves, WAVE, 0, st>>>(ARGS);
         } else if (R == NRA_CHAIN_R_TEST) {
-            if (has_n) k_sweep_pk16<NRA_CHAIN_R_TEST, true, DIR, true><<<n_tasks, WAVE, 0, st>>>(ARGS);
-            else k_sweep_pk16<NRA_CHAIN_R_TEST, false, DIR, true><<<n_tasks, WAVE, 0, st>>>(ARGS);
+            if (has_n) k_sweep_pk16<NRA_CHAIN_R_TEST, true, DIR, true><<<n_waves, WAVE, 0, st>>>(ARGS);
+            else k_sweep_pk16<NRA_CHAIN_R_TEST, false, DIR, true><<<n_waves, WAVE, 0, st>>>(ARGS);
         } else return (int)hipErrorInvalidValue;
         return (int)hipGetLastError();
     }
@@ -750,11 +762,11 @@ extern "C" int nra_launch_sweep_bwd(int R, int has_n, int chain, hipStream_t st,
                                     const NraDevRead* reads, const NraDevRegion* regions, const uint8_t* pool,
                                     const uint32_t* q2bit, const uint32_t* qnmask, NraScoreParams sp,
                                     const int32_t* kmin, const int32_t* kmax, const uint32_t* coff,
-                                    int32_t* snap, int32_t* arr_a,
+                                    int32_t* snap,
                                     int32_t* read_a, int32_t* chain_buf, int chain_cap)
 {
     return launch_sweep<0>(R, has_n, chain, st, n_tasks, tasks, reads, regions, pool, q2bit, qnmask, sp, kmin, kmax,
-                           coff, snap, arr_a, read_a, nullptr, nullptr, chain_buf, chain_cap);
+                           coff, snap, read_a, nullptr, nullptr, chain_buf, chain_cap);
 }
 #endif
 #if NRA_HAS_PART(6)
@@ -762,11 +774,11 @@ extern "C" int nra_launch_sweep_fwd(int R, int has_n, int chain, hipStream_t st,
                                     const NraDevRead* reads, const NraDevRegion* regions, const uint8_t* pool,
                                     const uint32_t* q2bit, const uint32_t* qnmask, NraScoreParams sp,
                                     const int32_t* kmin, const int32_t* kmax, const uint32_t* coff,
-                                    int32_t* snap, int32_t* arr_a,
+                                    int32_t* snap,
                                     int32_t* read_a, int32_t* cand_score, uint8_t* cand_flag, int32_t* chain_buf,
                                     int chain_cap)
 {
     return launch_sweep<1>(R, has_n, chain, st, n_tasks, tasks, reads, regions, pool, q2bit, qnmask, sp, kmin, kmax,
-                           coff, snap, arr_a, read_a, cand_score, cand_flag, chain_buf, chain_cap);
+                           coff, snap, read_a, cand_score, cand_flag, chain_buf, chain_cap);
 }
 #endif

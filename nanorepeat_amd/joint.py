@@ -256,25 +256,9 @@ def _read_seq(fastq_record):
     return fastq_record.split("\n")[1].strip()
 
 
-MAX_READ_2D = 3072          # rows one wave holds in the joint kernels (NRA_MAX_QLEN_1BLOCK)
-TRIM_MARGIN = 50
-
-
-def cut_long_read(seq, candidate, limit=MAX_READ_2D, margin=TRIM_MARGIN):
-    """A read longer than the joint kernels take is cut to the part round 1 found to hold the
-    anchors and both repeats (`potential_repeat_region_dict`, nanoRepeat_joint.py:639-648 -- the
-    reference computes it and never uses it) plus a margin; if that is still too long, both
-    flanks lose the same number of bases.  Coordinates are on the read as given (either strand)."""
-    if len(seq) <= limit:
-        return seq
-    if candidate is None:
-        raise ValueError(f"read of {len(seq)} bases without a round-1 region: joint scoring takes <= {limit} bases")
-    lo, hi = max(0, candidate[0] - margin), min(len(seq), candidate[1] + margin)
-    if hi - lo > limit:
-        cut = hi - lo - limit
-        lo += cut // 2
-        hi -= cut - cut // 2
-    return seq[lo:hi]
+MAX_READ_2D = 3072          # rows one wave holds (NRA_MAX_QLEN_1BLOCK): the limit of nra_align_pairs_cigar queries.
+                            # The grid rounds take reads of any length: nra_joint_2d scores longer ones cell by
+                            # cell in chained row blocks, the full read like the reference (nanoRepeat_joint.py:332,408)
 
 
 def _grid_product(k1_values, k2_values):
@@ -286,7 +270,7 @@ def _score_cells(region, readnames, fastq_dict, cells_by_read, device, scoring, 
     """One C-ABI call for every (read, k1, k2) cell; returns (RepeatSize, raw outputs)."""
     scorer = scorer or _capi.joint_2d
     names = [n for n in readnames if n in cells_by_read and len(cells_by_read[n][0])]
-    reads = [cut_long_read(_read_seq(fastq_dict[n]), (candidates or {}).get(n)) for n in names]
+    reads = [_read_seq(fastq_dict[n]) for n in names]
     # cells of a read: (k1 array, k2 array), k1-major like the reference's nested grid loops
     per_read = [cells_by_read[n] for n in names]
     counts = [len(c[0]) for c in per_read]

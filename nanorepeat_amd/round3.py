@@ -12,9 +12,9 @@ import numpy as np
 from . import _capi
 
 DATA_TYPES = ("ont", "ont_sup", "ont_q20", "clr", "hifi")   # all map to `-x map-ont` (tk.py:502-517)
-MAX_CORE_LEN = 8000       # NRA_MAX_QLEN: the longest core sequence the 1D kernels score (int16 cells)
-MAX_TEMPLATE_LEN = 65000  # NRA_MAX_TLEN
-READ_TOO_LONG = 4         # round3_status of a read left at its round-2 size because of those limits
+MAX_CORE_LEN = 200000       # NRA_MAX_QLEN: cores above 3072 bases run as chained row blocks in int32 cells
+MAX_TEMPLATE_LEN = 4000000  # NRA_MAX_TLEN_WIDE
+READ_TOO_LONG = 4           # round3_status of a read left at its round-2 size because of those limits
 
 
 class Read:
@@ -102,9 +102,9 @@ def round3_estimation_regions(data_type, fast_mode, repeat_regions, num_cpu=1, d
                 template_len = (len(region.left_anchor_seq) + len(region.repeat_unit_seq) * hi +
                                 len(region.right_anchor_seq))
                 if len(seq) > MAX_CORE_LEN or template_len > MAX_TEMPLATE_LEN:
-                    # beyond what the kernels hold (an expansion of > 7.8 kb): one such read must not
-                    # fail the whole batch -- it keeps its round-2 size, like a read whose best records
-                    # fail the flank test (nanoRepeat_bam.py:432-433)
+                    # beyond what the C ABI takes (a core of > 200 kb): one such read must not fail the
+                    # whole batch -- it keeps its round-2 size, like a read whose best records fail the
+                    # flank test (nanoRepeat_bam.py:432-433), and is reported by the pipeline
                     read.round3_repeat_size = r2
                     read.round3_status = READ_TOO_LONG
                     continue

@@ -413,39 +413,58 @@ int nro_round3_1d(const nro_region_t* regions, int32_t n_regions,
     const int all_ext = flags & 1;
     int bad = 0;
 
+    /* phase 1: every (read, k) candidate is an independent alignment -- K full DPs per read, exactly what
+     * the reference hands its aligner (nanoRepeat_bam.py:478-497).  Parallel over candidates, so that a
+     * single long read with a wide window still uses every core. */
+    const int64_t total = coff[n_reads];
+    int32_t* S_all = (int32_t*)malloc(sizeof(int32_t) * 3 * (size_t)(total > 0 ? total : 1));
+    int32_t* TS_all = S_all + (total > 0 ? total : 1);
+    int32_t* TE_all = TS_all + (total > 0 ? total : 1);
+    int32_t* owner = (int32_t*)malloc(sizeof(int32_t) * (size_t)(total > 0 ? total : 1));
+    uint8_t** Q = (uint8_t**)calloc((size_t)(n_reads > 0 ? n_reads : 1), sizeof(uint8_t*));
+    for (int32_t r = 0; r < n_reads; ++r) {
+        best_score[r] = 0; sum_k[r] = 0; n_ties[r] = 0;
+        if (kmin[r] > kmax[r]) { status[r] = 3; continue; }
+        const int32_t g = read_region ? read_region[r] : 0;
+        if (g < 0 || g >= n_regions || kmin[r] < 0) { status[r] = 3; bad = 1; continue; }
+        status[r] = 0;
+        const int32_t ql = (int32_t)(seq_off[r + 1] - seq_off[r]);
+        Q[r] = (uint8_t*)malloc((size_t)ql + 1);
+        nro_encode(seqs + seq_off[r], ql, Q[r]);
+        for (int64_t c = coff[r]; c < coff[r + 1]; ++c) owner[c] = r;
+    }
 #ifdef _OPENMP
 #pragma omp parallel for schedule(dynamic, 1) num_threads(nro_get_threads())
 #endif
-    for (int32_t r = 0; r < n_reads; ++r) {
-        best_score[r] = 0; sum_k[r] = 0; n_ties[r] = 0;
-        const int32_t k0 = kmin[r], k1 = kmax[r];
-        if (k0 > k1) { status[r] = 3; continue; }
+    for (int64_t c = 0; c < total; ++c) {
+        const int32_t r = owner[c];
+        if (!Q[r]) continue;                                 /* skipped / invalid read */
         const int32_t g = read_region ? read_region[r] : 0;
-        if (g < 0 || g >= n_regions || k0 < 0) { status[r] = 3; bad = 1; continue; }
         const int32_t ll = regions[g].left_len, ul = regions[g].unit_len, rl = regions[g].right_len;
         const int32_t ql = (int32_t)(seq_off[r + 1] - seq_off[r]);
+        const int32_t k = kmin[r] + (int32_t)(c - coff[r]);
+        /* template k: left + unit*k + right (nanoRepeat_bam.py:479) */
+        const int32_t tl = ll + ul * k + rl;
+        uint8_t* tgt = (uint8_t*)malloc((size_t)tl + 1);
+        memcpy(tgt, Lc[g], (size_t)ll);
+        for (int32_t i = 0; i < k; ++i) memcpy(tgt + ll + (size_t)i * ul, Uc[g], (size_t)ul);
+        memcpy(tgt + ll + (size_t)ul * k, Rc[g], (size_t)rl);
+        int32_t ts = 0, te = 0;
+        int32_t sc1 = nro_align(Q[r], ql, tgt, tl, sc, NRO_MODE_ORIGIN, 0, 0, &ts, &te);
+        if (sc1 < sc->min_dp_score || sc1 <= 0) { S_all[c] = -1; TS_all[c] = -1; TE_all[c] = -1; }
+        else { S_all[c] = sc1; TS_all[c] = ts; TE_all[c] = te; }
+        free(tgt);
+    }
+    /* phase 2: the selector, nanoRepeat_bam.py:423-433 */
+    for (int32_t r = 0; r < n_reads; ++r) {
+        if (!Q[r]) continue;
+        const int32_t g = read_region ? read_region[r] : 0;
+        const int32_t ll = regions[g].left_len, ul = regions[g].unit_len, rl = regions[g].right_len;
+        const int32_t k0 = kmin[r], k1 = kmax[r];
         const int32_t K = k1 - k0 + 1;
-        uint8_t* q = (uint8_t*)malloc((size_t)ql + 1);
-        nro_encode(seqs + seq_off[r], ql, q);
-        const size_t plen = (size_t)ll + (size_t)ul * k1;
-        uint8_t* pre = (uint8_t*)malloc(plen + 1);           /* left + unit*kmax */
-        uint8_t* tgt = (uint8_t*)malloc(plen + rl + 1);
-        int32_t* S = (int32_t*)malloc(sizeof(int32_t) * 3 * (size_t)K);
-        int32_t* TS = S + K; int32_t* TE = TS + K;
-        memcpy(pre, Lc[g], (size_t)ll);
-        for (int32_t k = 0; k < k1; ++k) memcpy(pre + ll + (size_t)k * ul, Uc[g], (size_t)ul);
+        const int32_t* S = S_all + coff[r]; const int32_t* TS = TS_all + coff[r]; const int32_t* TE = TE_all + coff[r];
         int32_t smax = -1;
-        for (int32_t k = k0; k <= k1; ++k) {
-            /* template k: left + unit*k + right (nanoRepeat_bam.py:479) */
-            const int32_t tl = ll + ul * k + rl;
-            memcpy(tgt, pre, (size_t)ll + (size_t)ul * k);
-            memcpy(tgt + ll + (size_t)ul * k, Rc[g], (size_t)rl);
-            int32_t ts = 0, te = 0;
-            int32_t s = nro_align(q, ql, tgt, tl, sc, NRO_MODE_ORIGIN, 0, 0, &ts, &te);
-            if (s < sc->min_dp_score || s <= 0) { S[k - k0] = -1; TS[k - k0] = -1; TE[k - k0] = -1; }
-            else { S[k - k0] = s; TS[k - k0] = ts; TE[k - k0] = te; if (s > smax) smax = s; }
-        }
-        /* selector, nanoRepeat_bam.py:423-433 */
+        for (int32_t c = 0; c < K; ++c) if (S[c] > smax) smax = S[c];
         int64_t sk = 0; int32_t nt = 0;
         for (int32_t k = k0; k <= k1; ++k) {
             const int32_t c = k - k0;
@@ -462,8 +481,9 @@ int nro_round3_1d(const nro_region_t* regions, int32_t n_regions,
             if (cand_tstart) cand_tstart[coff[r] + c] = keep ? TS[c] : -1;
             if (cand_tend) cand_tend[coff[r] + c] = keep ? TE[c] : -1;
         }
-        free(S); free(tgt); free(pre); free(q);
+        free(Q[r]);
     }
+    free(Q); free(owner); free(S_all);
     for (int32_t g = 0; g < n_regions; ++g) { free(Lc[g]); free(Uc[g]); free(Rc[g]); }
     free(Lc); free(Uc); free(Rc); free(coff);
     return bad ? -1 : 0;

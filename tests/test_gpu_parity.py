@@ -278,6 +278,55 @@ def test_config2_full_size_properties(capi, oracle, config2_run):
     assert np.array_equal(sc[pick].ravel(), o["cand_score"])
 
 
+def test_long_cores_chained_int32_sweeps_equal_oracle(capi, oracle):
+    """Cores beyond the packed int16 sweeps (3072 rows / doubled scores of 8000): 10 kb, 16 kb and 20 kb
+    expansions of a 5 bp motif run as chained row blocks in int32 cells, one read per wave.  The 16 kb
+    read gets the reference's full window for r2 = 3000 (buffer capped at 150: K = 301,
+    nanoRepeat_bam.py:463-472); the others a narrow window (the oracle is K full DPs of 10^8 cells)."""
+    from nanorepeat_amd.round3 import round3_window
+    rng = np.random.default_rng(77)
+    L, R = synth.rand_seq(rng, 1000), synth.rand_seq(rng, 1000)
+    reads, kmin, kmax = [], [], []
+    for k_true, win in ((2000, (1997, 2003)), (3000, round3_window(3000.4, False)), (4000, (3998, 4001)),
+                        (30, (20, 40)), (700, (690, 712))):
+        reads.append(synth.apply_errors(rng, L[-100:] + "TATTG" * k_true + R[:100], "ont_q20"))
+        kmin.append(win[0]); kmax.append(win[1])
+    assert (kmin[1], kmax[1]) == (2850, 3150) and len(reads[2]) > 19000
+    o = oracle.round3_1d([(L, "TATTG", R)], reads, kmin, kmax)
+    for flags in (0, capi.F_TIE_EXTENTS):
+        g = capi.round3_1d([(L, "TATTG", R)], reads, kmin, kmax, flags=flags)
+        for k in ("best_score", "sum_k", "n_ties", "status", "cand_score"):
+            assert np.array_equal(g[k], o[k]), (flags, k, g[k][:8], o[k][:8])
+        if flags:
+            ties = o["cand_tstart"] >= 0
+            assert np.array_equal(g["cand_tstart"][ties], o["cand_tstart"][ties])
+            assert np.array_equal(g["cand_tend"][ties], o["cand_tend"][ties])
+    assert (g["status"] == 0).all() and g["best_score"][2] > 32767
+
+
+def test_long_joint_reads_uncut_equal_oracle(capi, oracle):
+    """Joint reads of 5 kb (beyond one register block) are scored uncut, cell by cell in chained row
+    blocks with int64 cells; strands probed (0) or given; short reads of the same batch take the sweeps."""
+    j = synth.make_joint(6, alleles=((30, 8), (60, 5)), read_len=5200, read_sd=150, anchor=3000, seed=41)
+    k = synth.make_joint(4, alleles=((30, 8), (60, 5)), read_len=900, read_sd=40, anchor=3000, seed=41)
+    assert j["region"] == k["region"] and min(len(r) for r in j["reads"]) > 3072
+    reads = j["reads"] + k["reads"]
+    truth = np.concatenate([j["truth"], k["truth"]])
+    cr, k1, k2 = [], [], []
+    for r in range(len(reads)):
+        for a in range(int(truth[r][0]) - 4, int(truth[r][0]) + 5, 2):
+            for b in range(int(truth[r][1]) - 2, int(truth[r][1]) + 3, 2):
+                cr.append(r); k1.append(a); k2.append(b)
+    o = oracle.joint_2d(j["region"], reads, cr, k1, k2)
+    g = capi.joint_2d(j["region"], reads, cr, k1, k2)
+    for key in o:
+        assert np.array_equal(g[key], o[key]), (key, g[key][:10], o[key][:10])
+    g2 = capi.joint_2d(j["region"], reads, cr, k1, k2, read_strand=o["read_strand"])
+    for key in o:
+        assert np.array_equal(g2[key], o[key]), key
+    assert set(o["read_strand"][:6].tolist()) == {1, -1} and (o["status"] == 0).all()
+
+
 def test_config2_order_and_batching_invariance(capi, config2_run):
     d, g, _ = config2_run
     n = len(d["reads"])

@@ -135,19 +135,9 @@ def test_joint_command_from_files_gpu_equals_oracle(capi, oracle, tmp_path):
     assert gpu_text == (tmp_path / "o" / "out.repeat_size.txt").read_text()
 
 
-def test_cut_long_read():
-    seq = "A" * 1000 + "C" * 2000 + "G" * 1500
-    assert joint.cut_long_read(seq[:3000], None) == seq[:3000]
-    assert joint.cut_long_read(seq, (1000, 3000)) == seq[950:3050]
-    got = joint.cut_long_read(seq + "T" * 4000, (200, 4300), limit=3072)
-    assert len(got) == 3072 and got == (seq + "T" * 4000)[150 + 564:4350 - 564]
-    with pytest.raises(ValueError):
-        joint.cut_long_read(seq, None)
-
-
 def test_joint_command_long_reads_with_oracle(oracle, tmp_path):
-    """Reads longer than the joint kernels hold (3072 bases): round 1 aligns them as DP targets,
-    the grid rounds get the part round 1 located."""
+    """Reads longer than one register block (3072 bases): round 1 aligns them as DP targets, the grid
+    rounds score the full read (nanoRepeat_joint.py:332,408) cell by cell in chained row blocks."""
     from nanorepeat_amd import pipeline
     truth, rs1, rs2 = _joint_files(tmp_path, n=12, long_every=3)
     est, alleles = pipeline.quantify_joint(str(tmp_path / "reads.fastq"), str(tmp_path / "ref.fa"), rs1, rs2,

@@ -111,16 +111,38 @@ def test_align_pairs_matches_oracle(capi, oracle):
         o = oracle.align_pairs(seqs, pq, pt, sc=oracle.default_scoring(**over))
         for k in ("score", "tstart", "tend"):
             assert np.array_equal(g[k], o[k]), (k, g[k], o[k])
-    with pytest.raises(capi.NraError):                       # queries: <= 8000 bases (chained above 3072)
-        capi.align_pairs([synth.rand_seq(rng, 8001), "ACGT"], [0], [1])
+    with pytest.raises(capi.NraError):                       # queries: <= 200 000 bases (chained above 3072)
+        capi.align_pairs(["A" * 200001, "ACGT"], [0], [1])
     with pytest.raises(capi.NraError):                       # the traceback keeps one register block
         capi.align_pairs_cigar([synth.rand_seq(rng, 3073), "ACGT"], [0], [1])
 
 
-def test_round3_keeps_round2_size_for_cores_beyond_the_kernel_limits(oracle):
-    """A core longer than 8000 bases (or a template beyond 65000 columns) does not fail the batch."""
+@pytest.mark.gpu
+def test_align_pairs_long_queries_and_targets(capi, oracle):
+    """Beyond the int32 cells: a 9.5 kb core as the query (score > 16 bits of the packed word's half ->
+    chained rows), a 70 kb read as the target of a 1 kb anchor (tstart beyond 16 bits -> int64 cells),
+    both at once, and an N-rich pair; all equal the oracle."""
+    from nanorepeat_amd import synth
+    rng = np.random.default_rng(31)
+    core_t = synth.rand_seq(rng, 400) + "TATTG" * 1800 + synth.rand_seq(rng, 400)
+    core = synth.apply_errors(rng, core_t[300:-300], "ont_q20")
+    read70 = synth.rand_seq(rng, 70000)
+    anchor = synth.apply_errors(rng, read70[66000:67000], "ont")
+    long_q = synth.apply_errors(rng, read70[1000:21000], "hifi")            # 20 kb query, 70 kb target
+    seqs = [core_t, core, read70, anchor, long_q, ("ACGTN" * 800), ("ACGTN" * 900)]
+    pq, pt = [1, 3, 4, 5, 3], [0, 2, 2, 6, 0]
+    g = capi.align_pairs(seqs, pq, pt)
+    o = oracle.align_pairs(seqs, pq, pt)
+    for k in ("score", "tstart", "tend"):
+        assert np.array_equal(g[k], o[k]), (k, g[k], o[k])
+    assert g["score"][0] > 17000 and g["tstart"][1] > 65535 and g["score"][2] > 32767
+
+
+def test_round3_keeps_round2_size_for_cores_beyond_the_kernel_limits(oracle, monkeypatch):
+    """A core longer than the C ABI takes (or a template beyond its column limit) does not fail the batch."""
     import numpy as np
     from nanorepeat_amd import round3 as R3, synth
+    monkeypatch.setattr(R3, "MAX_CORE_LEN", 8000)
     rng = np.random.default_rng(8)
     rr = R3.RepeatRegion("chr1\t100\t160\tCAG")
     rr.left_anchor_seq, rr.right_anchor_seq = synth.rand_seq(rng, 200), synth.rand_seq(rng, 200)
