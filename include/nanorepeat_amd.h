@@ -34,7 +34,7 @@ extern "C" {
 #define NRA_OK            0
 #define NRA_E_ARG        -1   /* bad argument (null pointer, negative size, window too large ...) */
 #define NRA_E_DEVICE     -2   /* HIP runtime error / no device */
-#define NRA_E_RANGE      -3   /* a sequence exceeds what the int16/int32 score packing can hold */
+#define NRA_E_RANGE      -3   /* a sequence exceeds what the entry point holds (limits on each declaration) */
 #define NRA_E_NOMEM      -4
 
 /* per-read status (1D and 2D) */
@@ -133,8 +133,10 @@ void        nra_default_scoring(nra_scoring_t* sc);
  * Inputs: n_regions regions; n_reads oriented core sequences concatenated in `seqs`
  * with offsets seq_off[n_reads+1]; read_region[i] = region index of read i (NULL when
  * n_regions == 1); candidate window kmin[i]..kmax[i] inclusive (kmin > kmax = skipped).
- * A read holds at most 8000 bases (NRA_E_RANGE beyond; reads over 3072 bases are swept in
- * chained row blocks and need the junction decomposition: no NRA_F_BRUTE_FORCE / ALL_EXTENTS).
+ * A read holds at most 200 000 bases and a candidate template 4 000 000 columns (NRA_E_RANGE beyond).
+ * Reads of up to 3072 bases run two to a wave in packed int16 cells; longer ones (any round-2 size
+ * the reference's window rule covers, nanoRepeat_bam.py:463-472) run one to a wave as chained row
+ * blocks in int32 cells and need the junction decomposition: no NRA_F_BRUTE_FORCE / ALL_EXTENTS.
  *
  * Per-read outputs (all caller-allocated, n_reads entries):
  *   best_score  max AS over the read's candidates (0 when no record)
@@ -162,7 +164,8 @@ int nra_round3_1d(int device,
  *      estimate_two_repeats_from_paf :427-478 and the CIGAR window rescoring
  *      tk.target_region_alignment_stats_from_cigar tk.py:435-500 ----------------------
  *
- * Inputs: one joint region; n_reads full reads (either strand); a list of n_cells
+ * Inputs: one joint region; n_reads full reads (either strand, at most 200 000 bases; reads beyond
+ * 3072 bases are scored uncut, cell by cell, in chained row blocks); a list of n_cells
  * (read, k1, k2) grid cells, grouped by read (cell_read non-decreasing).
  * read_strand (n_reads, in/out, may be NULL): 0 = choose the strand with the higher DP
  * score against the read's first listed cell (ties -> '+'), +1 / -1 = forced; on return
@@ -190,8 +193,10 @@ int nra_joint_2d(int device,
  *
  * n_seqs sequences concatenated in `seqs` (offsets seq_off[n_seqs+1]); n_pairs pairs
  * (pair_query[i], pair_target[i]) of sequence indices.  A sequence used as a query holds at
- * most 8000 bases (above 3072: chained row blocks; nra_align_pairs_cigar: 3072), as a target
- * at most 65000.  Outputs per pair: score (AS; -1 when below
+ * most 200 000 bases (above 3072: chained row blocks), as a target at most 4 000 000 (a whole
+ * long read as the target of an anchor); pairs whose score or extents outgrow the int32 cells
+ * (score > 32000, target > 65000) run in int64 cells.  nra_align_pairs_cigar: query <= 3072,
+ * target <= 65000.  Outputs per pair: score (AS; -1 when below
  * min_dp_score), tstart, tend (target coordinates, 0-based half-open; oracle tie-breaks:
  * largest tstart, then smallest tend; -1 when no record). */
 int nra_align_pairs(int device,

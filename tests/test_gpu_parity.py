@@ -130,8 +130,9 @@ def test_1d_scoring_variants(capi, oracle):
 
 
 def test_1d_large_match_scores(capi, oracle):
-    """Scores that outgrow the 16-bit cell formats: the doubled (origin-bit) sweep hands over to the
-    brute-force kernel above match x length = 8000; beyond 24000 the call is refused."""
+    """Scores that outgrow the packed int16 sweeps (doubled scores: match x length > 8000) move to the
+    chained int32 sweeps; a scoring scheme the sweeps cannot hold (table bytes) falls back to the packed
+    brute-force kernel, which refuses scores beyond 24000."""
     d = synth.make_1d(6, "TATTG", (20, 60), "ont_q20", kwin=(10, 70), anchor=600, flank=500, seed=77)   # reads of 1.1-1.3 kb
     assert max(len(r) for r in d["reads"]) > 1000
     for over in (dict(match=7, mismatch=9, gap_open1=9, gap_ext1=4, gap_open2=40, gap_ext2=2),          # 7 x 1300 > 8000
@@ -145,13 +146,18 @@ def test_1d_large_match_scores(capi, oracle):
 def test_1d_errors(capi):
     L, R = "ACGT" * 20, "TTGCA" * 16
     with pytest.raises(capi.NraError) as e:
-        capi.round3_1d([(L, "CAG", R)], ["A" * 8001], [0], [1])
+        capi.round3_1d([(L, "CAG", R)], ["A" * 200001], [0], [1])       # NRA_MAX_QLEN
     assert e.value.code == -3
+    with pytest.raises(capi.NraError) as e:                              # long reads need the sweeps
+        capi.round3_1d([(L, "CAG", R)], ["A" * 8001], [0], [1], flags=capi.F_BRUTE_FORCE)
+    assert e.value.code == -3
+    out = capi.round3_1d([(L, "CAG", R)], ["A" * 8001], [0], [1])        # ... which take them
+    assert out["status"].tolist() == [2]
     with pytest.raises(capi.NraError) as e:
         capi.round3_1d([(L, "", R)], ["ACGT"], [0], [1])
     assert e.value.code == -1
     with pytest.raises(capi.NraError) as e:
-        capi.round3_1d([(L, "CAG", R)], ["ACGT"], [0], [30000])
+        capi.round3_1d([(L, "CAG", R)], ["ACGT"], [0], [3000000])        # NRA_MAX_TLEN_WIDE
     assert e.value.code == -3
     out = capi.round3_1d([(L, "CAG", R)], [], [], [])
     assert len(out["status"]) == 0
@@ -514,9 +520,6 @@ def test_1d_long_reads_over_one_register_block(capi, oracle):
         assert np.array_equal(g[k], o[k]), k
     assert (g["status"] == 0).all()
     with pytest.raises(capi.NraError) as e:
-        capi.round3_1d([(L, u, R)], ["A" * 8001], [0], [1])
-    assert e.value.code == -3
-    with pytest.raises(capi.NraError) as e:
         capi.round3_1d([(L, u, R)], reads[:1], kmin[:1], kmax[:1], flags=capi.F_BRUTE_FORCE)
     assert e.value.code == -3
 
@@ -605,8 +608,8 @@ def test_concurrent_calls_from_two_threads(capi, oracle):
                 for k in KEYS_2D:
                     assert np.array_equal(g2[k], want2d[k]), (which, rep, k)
                 with pytest.raises(capi.NraError) as e:          # the error text belongs to this thread's call
-                    capi.round3_1d(d["regions"], ["A" * (8001 + which)], [0], [1])
-                assert str(8001 + which) in str(e.value)
+                    capi.round3_1d(d["regions"], ["A" * (200001 + which)], [0], [1])
+                assert str(200001 + which) in str(e.value)
         except BaseException as exc:                              # noqa: BLE001 - reported in the main thread
             errors.append(exc)
 
@@ -655,5 +658,5 @@ def test_align_pairs_long_queries(capi, oracle):
     for k in ("score", "tstart", "tend"):
         assert np.array_equal(g[k], o[k]), (k, g[k], o[k])
     with pytest.raises(capi.NraError) as e:
-        capi.align_pairs([target, "A" * 8001], [1], [0])
+        capi.align_pairs([target, "A" * 200001], [1], [0])
     assert e.value.code == -3

@@ -135,7 +135,7 @@ def test_align_pairs_long_queries_and_targets(capi, oracle):
     o = oracle.align_pairs(seqs, pq, pt)
     for k in ("score", "tstart", "tend"):
         assert np.array_equal(g[k], o[k]), (k, g[k], o[k])
-    assert g["score"][0] > 17000 and g["tstart"][1] > 65535 and g["score"][2] > 32767
+    assert g["score"][0] > 16000 and g["tstart"][1] > 65535 and g["score"][2] > 32767
 
 
 def test_round3_keeps_round2_size_for_cores_beyond_the_kernel_limits(oracle, monkeypatch):
