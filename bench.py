@@ -321,12 +321,100 @@ def bench_1d(args):
         dist.destroy_process_group()
 
 
+def bench_joint(args):
+    """BASELINE config 3: the two grid rounds of the joint mode (nanoRepeat_joint.py:266-269) on 5000
+    HTT-like amplicon reads, through the product host path (joint.fine_tune_read_count) on a resident
+    GridSession.  One step = round 2 + round 3: per round the host builds the cell list from the previous
+    round's estimates, sets it on the resident reads, runs the kernels and fetches the per-read results."""
+    import copy
+    import numpy as np
+    from nanorepeat_amd import joint as J, synth
+    rank, local_rank, world, dist = init_dist(args)
+    if world != 1:
+        raise SystemExit("bench.py --config 3 is a one-GPU workload (5000 reads); see dist.joint_2d_sharded for N > 1")
+    n = args.reads if args.reads != 10000 else 5000
+    j = synth.config3(n)
+    init = J.Round1Estimation()
+    fq = {}
+    for i, s in enumerate(j["reads"]):
+        init.repeat1_count_range_dict[f"r{i}"] = tuple(int(x) for x in j["range1"][i])
+        init.repeat2_count_range_dict[f"r{i}"] = tuple(int(x) for x in j["range2"][i])
+        init.read_strand_dict[f"r{i}"] = int(j["strand"][i])        # round 1 knows the strand: no probe in the grid rounds
+        fq[f"r{i}"] = f"@r{i}\n{s}\n+\n{'!' * len(s)}\n"
+    left, u1, mid, u2, right = j["region"]
+    chrom = left + u1 * 19 + mid + u2 * 7 + right
+    a = J.Repeat.parse(f"chr4:{len(left)}:{len(left) + 57}:{u1}:200")
+    b = J.Repeat.parse(f"chr4:{len(left) + 57 + len(mid)}:{len(left) + 57 + len(mid) + 21}:{u2}:20")
+    a.max_size += 10; b.max_size += 10                               # nanoRepeat_joint.py:202-203
+    session = J.GridSession(J._joint_region(chrom, a, b), fq, device=local_rank)
+    last = {}
+
+    def step():
+        last["est"] = J.fine_tune_read_count(init, fq, chrom, copy.copy(a), copy.copy(b), device=local_rank, session=session)
+
+    dt = timed_steps(args, dist, step, on_warm=lambda: setattr(session, "rounds", []))
+    rounds = session.rounds
+    per_step = len(rounds) // max(args.steps, 1)
+    n_cells = sum(c for c, _ in rounds[:per_step])
+    # statistics: the batch accumulates event times over its runs; cells are per round
+    first, final = rounds[0][1], rounds[-1][1]
+    runs = final["n_runs"] - first["n_runs"] + 1
+    phase_ms = (final["sum_score_phase_ms"] - first["sum_score_phase_ms"] + first["score_phase_ms"]) / runs * per_step
+    total_ms = (final["sum_total_ms"] - first["sum_total_ms"] + first["total_ms"]) / runs * per_step
+    exe = sum(st["executed_cells"] for _, st in rounds[:per_step])
+    alg = sum(st["algorithmic_cells"] for _, st in rounds[:per_step])
+    est = last["est"]
+    k1 = np.array([est.repeat1_count_dict.get(f"r{i}", -1) for i in range(n)])
+    k2 = np.array([est.repeat2_count_dict.get(f"r{i}", -1) for i in range(n)])
+    achieved = exe * LANEOPS_PER_CELL / (phase_ms / 1e3) / 1e12
+    line = {
+        "metric": "read-alignments/sec (reads x candidate cells)",
+        "value": n_cells * args.steps / dt, "unit": "read-alignments/s",
+        "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "int32", "data": "synthetic",
+        "config": {"workload": f"config3: HTT-like joint CAG+CCG grid rounds 2+3, {n} amplicon reads (1.2 kb, either strand), "
+                               "round-1 ranges [k-20, k+5)", "reads": n, "alignments": n_cells,
+                   "cells_per_round": [c for c, _ in rounds[:per_step]],
+                   "timed_region": "reads resident in HBM; per round: host cell list -> nra_batch2d_set_cells -> kernels -> "
+                                   "on-device selection -> D2H of per-read results"},
+        "roofline": {"bound": "valu", "achieved": achieved, "peak": VALU_PEAK_TLANEOPS, "unit": "Tlane-op/s",
+                     "frac": achieved / VALU_PEAK_TLANEOPS, "traffic": None,
+                     "kernel": "k_joint_sweep<R,dir> (reverse, prefix and tail sweeps)",
+                     "kernel_ms_per_step": phase_ms, "device_ms_per_step": total_ms,
+                     "host_ms_per_step": dt / args.steps * 1e3 - total_ms,
+                     "executed_cells_per_step": exe, "executed_Tcell_per_s": exe / (phase_ms / 1e3) / 1e12,
+                     "laneops_per_cell": LANEOPS_PER_CELL,
+                     "note": "int32 cells = (score << 16 | window score): one cell per lane-op slot, priced like the 1D "
+                             "cell (10 lane-ops) against the same 78.6 T lane-op/s; launches are latency- rather than "
+                             "issue-bound at 5000 reads (DESIGN.md)",
+                     "algorithmic": {"cells_per_step": alg, "over_executed": alg / max(exe, 1)}},
+        "k1_within1": float(np.mean(np.abs(k1 - j["truth"][:, 0]) <= 1)),
+        "k2_within1": float(np.mean(np.abs(k2 - j["truth"][:, 1]) <= 1)),
+    }
+    if args.cpu_sample != 0:
+        from oracle import oracle as O
+        cores = host_cores()
+        m = cores if args.cpu_sample < 0 else min(args.cpu_sample, n)
+        cr, c1, c2 = [], [], []
+        for r in range(m):
+            for x in range(int(j["range1"][r][0]), int(j["range1"][r][1]), 7):
+                for y in range(int(j["range2"][r][0]), int(j["range2"][r][1]), 7):
+                    cr.append(r); c1.append(x); c2.append(y)
+        t0 = time.perf_counter()
+        O.joint_2d(j["region"], j["reads"][:m], cr, c1, c2, threads=cores)
+        dtc = time.perf_counter() - t0
+        line["cpu_baseline"] = {"value": len(cr) / dtc, "unit": "read-alignments/s", "cores": cores, "kind": "port",
+                                "sample": f"first {m} reads x their step-7 grid = {len(cr)} cells in {dtc:.1f} s; CPU "
+                                          "restatement (one optimal DP with window payload per cell), not minimap2"}
+    print(json.dumps(line), flush=True)
+    session.close()
+
+
 def main():
     args = parse()
     spawn_ranks_if_needed(args)
     if args.config == 3:
-        from tools import bench_joint
-        return bench_joint.run(args, sys.modules[__name__])
+        return bench_joint(args)
     bench_1d(args)
 
 

@@ -236,6 +236,18 @@ int  nra_batch2d_create(int device,
                         const int32_t* cell_k1, const int32_t* cell_k2,
                         const nra_scoring_t* sc, int32_t flags,
                         nra_batch_t** out);
+/* The joint mode scores the same reads in two grid rounds (nanoRepeat_joint.py:266-269): the reads can be
+ * packed and uploaded once (create_reads) and each round's cell list set on the resident batch
+ * (set_cells; may be called again after a run -- device buffers are reused).  nra_batch2d_create is the two
+ * calls in one. */
+int  nra_batch2d_create_reads(int device,
+                              const nra_joint_region_t* region,
+                              int32_t n_reads, const char* seqs, const int64_t* seq_off,
+                              const nra_scoring_t* sc, int32_t flags,
+                              nra_batch_t** out);
+int  nra_batch2d_set_cells(nra_batch_t* b, const int8_t* read_strand,
+                           int64_t n_cells, const int32_t* cell_read,
+                           const int32_t* cell_k1, const int32_t* cell_k2);
 int  nra_batch_run(nra_batch_t* b);      /* enqueue every kernel of the path; returns at once */
 int  nra_batch_sync(nra_batch_t* b);     /* wait for the batch stream */
 int  nra_batch_stats(nra_batch_t* b, nra_stats_t* st);   /* after sync */

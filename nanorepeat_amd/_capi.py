@@ -22,7 +22,7 @@ F_DPP_SWEEP = 16      # testing / comparison: k_sweep_pk16 instead of k_sweep_ri
 # every symbol include/nanorepeat_amd.h declares
 EXPORTS = ("nra_abi_version", "nra_version", "nra_last_error", "nra_device_count",
            "nra_default_scoring", "nra_round3_1d", "nra_joint_2d", "nra_align_pairs", "nra_align_pairs_cigar", "nra_batch1d_create",
-           "nra_batch2d_create", "nra_batch_run", "nra_batch_sync", "nra_batch_stats",
+           "nra_batch2d_create", "nra_batch2d_create_reads", "nra_batch2d_set_cells", "nra_batch_run", "nra_batch_sync", "nra_batch_stats",
            "nra_batch1d_fetch", "nra_batch2d_fetch", "nra_batch_destroy")
 
 
@@ -107,6 +107,11 @@ def load():
     lib.nra_batch2d_create.argtypes = [C.c_int, C.POINTER(JointRegion), C.c_int32, C.c_char_p, pi64,
                                        pi8, C.c_int64, pi32, pi32, pi32, C.POINTER(Scoring),
                                        C.c_int32, C.POINTER(vp)]
+    lib.nra_batch2d_create_reads.restype = C.c_int
+    lib.nra_batch2d_create_reads.argtypes = [C.c_int, C.POINTER(JointRegion), C.c_int32, C.c_char_p, pi64,
+                                             C.POINTER(Scoring), C.c_int32, C.POINTER(vp)]
+    lib.nra_batch2d_set_cells.restype = C.c_int
+    lib.nra_batch2d_set_cells.argtypes = [vp, pi8, C.c_int64, pi32, pi32, pi32]
     for f in (lib.nra_batch_run, lib.nra_batch_sync):
         f.restype = C.c_int
         f.argtypes = [vp]
@@ -367,6 +372,28 @@ class Batch:
                                       _ptr(k1, C.c_int32), _ptr(k2, C.c_int32), C.byref(sc), flags,
                                       C.byref(h)))
         return cls(h, 2, len(reads), len(cr))
+
+    @classmethod
+    def create_2d_reads(cls, region, reads, sc=None, flags=0, device=0):
+        """The reads of a joint run, packed and resident; give it a cell list with set_cells()."""
+        lib = load()
+        sc = sc or default_scoring()
+        seqs, off = pack_reads(reads)
+        jr, keep = _joint_region(region)
+        h = C.c_void_p()
+        _check(lib.nra_batch2d_create_reads(device, C.byref(jr), len(reads), seqs, _ptr(off, C.c_int64),
+                                            C.byref(sc), flags, C.byref(h)))
+        return cls(h, 2, len(reads), 0)
+
+    def set_cells(self, cell_read, cell_k1, cell_k2, read_strand=None):
+        """The (read, k1, k2) cells of the next run (grouped by read); the previous list is dropped."""
+        cr = np.ascontiguousarray(cell_read, np.int32)
+        k1 = np.ascontiguousarray(cell_k1, np.int32)
+        k2 = np.ascontiguousarray(cell_k2, np.int32)
+        st = None if read_strand is None else np.ascontiguousarray(read_strand, np.int8)
+        _check(load().nra_batch2d_set_cells(self._h, _ptr(st, C.c_int8), len(cr), _ptr(cr, C.c_int32),
+                                            _ptr(k1, C.c_int32), _ptr(k2, C.c_int32)))
+        self.n_cand = len(cr)
 
     def run(self):
         _check(load().nra_batch_run(self._h))

@@ -112,18 +112,18 @@ struct Arena {
     size_t next_chunk = 1 << 20;
     ~Arena() { for (Chunk& c : chunks) (void)hipFree(c.p); }
     void expect(size_t bytes) { next_chunk = std::max(next_chunk, bytes); }
+    void reset() { for (Chunk& c : chunks) c.used = 0; }        // keep the memory, hand it out again
     hipError_t alloc(size_t bytes, void** out)
     {
         bytes = (bytes + 255) & ~(size_t)255;
-        if (chunks.empty() || chunks.back().size - chunks.back().used < bytes) {
-            Chunk c{nullptr, std::max(bytes, next_chunk), 0};
-            hipError_t e = hipMalloc((void**)&c.p, c.size);
-            if (e != hipSuccess) return e;
-            chunks.push_back(c);
-        }
-        Chunk& c = chunks.back();
-        *out = c.p + c.used;
-        c.used += bytes;
+        for (Chunk& c : chunks)
+            if (c.size - c.used >= bytes) { *out = c.p + c.used; c.used += bytes; return hipSuccess; }
+        Chunk c{nullptr, std::max(bytes, next_chunk), 0};
+        hipError_t e = hipMalloc((void**)&c.p, c.size);
+        if (e != hipSuccess) return e;
+        c.used = bytes;
+        *out = c.p;
+        chunks.push_back(c);
         return hipSuccess;
     }
 };
@@ -301,6 +301,14 @@ int64_t sweep128_cells(int R, int ncols) { return (int64_t)64 * R * ((int64_t)nc
 
 struct nra_batch {
     Arena arena;               // declared first: released after every DevBuf below
+    Arena cell_arena;          // 2D: buffers that depend on the cell list; reset by nra_batch2d_set_cells
+    // 2D: what nra_batch2d_set_cells needs from the reads part
+    std::vector<NraDevRead> host_reads;
+    std::vector<uint8_t> chained_reads;
+    std::string jr_left, jr_unit1, jr_mid, jr_unit2, jr_right;
+    nra_scoring_t scoring{};
+    size_t n_q2bit_words = 0;
+    bool reads_have_n = false;
     int kind = 0;              // 1 = 1D, 2 = 2D
     int device = 0;
     int flags = 0;
@@ -359,6 +367,7 @@ struct nra_batch {
     std::vector<hipEvent_t> ev;    // [0]=run start, [1]=run end, then pairs per dominant launch
     int n_score_ev = 0, n_ext_ev = 0;
     bool ran = false, accounted = false;
+    bool have_cells = false;   // 2D: nra_batch2d_set_cells has run
     nra_stats_t stats{};
 
     ~nra_batch()
@@ -967,17 +976,16 @@ int nra_round3_1d(int device, const nra_region_t* regions, int32_t n_regions, in
 }
 
 // ---- 2D -----------------------------------------------------------------------------
-int nra_batch2d_create(int device, const nra_joint_region_t* reg, int32_t n_reads, const char* seqs,
-                       const int64_t* seq_off, const int8_t* read_strand, int64_t n_cells,
-                       const int32_t* cell_read, const int32_t* cell_k1, const int32_t* cell_k2,
-                       const nra_scoring_t* sc, int32_t flags, nra_batch_t** out)
+static int account_run(nra_batch* b);
+static int account_run_fwd(nra_batch* b) { return account_run(b); }
+
+int nra_batch2d_create_reads(int device, const nra_joint_region_t* reg, int32_t n_reads, const char* seqs,
+                             const int64_t* seq_off, const nra_scoring_t* sc, int32_t flags, nra_batch_t** out)
 {
     if (!out) return fail(NRA_E_ARG, "out is NULL");
     *out = nullptr;
-    if (!reg || n_reads < 0 || n_cells < 0) return fail(NRA_E_ARG, "bad region / counts");
+    if (!reg || n_reads < 0) return fail(NRA_E_ARG, "bad region / counts");
     if (n_reads > 0 && (!seqs || !seq_off)) return fail(NRA_E_ARG, "NULL input array");
-    if (n_cells > 0 && (!cell_read || !cell_k1 || !cell_k2)) return fail(NRA_E_ARG, "NULL cell array");
-    if (n_cells > 0x7ff00000ll) return fail(NRA_E_RANGE, "too many cells");
     if (!scoring_ok(sc)) return fail(NRA_E_ARG, "scoring parameters out of range");
     if (reg->left_len < 0 || reg->right_len < 0 || reg->mid_len < 0 || reg->unit1_len <= 0 ||
         reg->unit2_len <= 0 || !reg->unit1 || !reg->unit2)
@@ -986,18 +994,67 @@ int nra_batch2d_create(int device, const nra_joint_region_t* reg, int32_t n_read
     nra_batch* b = new nra_batch();
     std::unique_ptr<nra_batch> guard(b);
     ArenaScope arena_scope(&b->arena);
-    b->kind = 2; b->n_reads = n_reads; b->n_regions = 1; b->n_cands = n_cells;
+    b->kind = 2; b->n_reads = n_reads; b->n_regions = 1; b->n_cands = 0;
     int rc = common_init(b, device, sc, flags);
     if (rc) return rc;
+    b->scoring = *sc;
+    b->jr_left.assign(reg->left ? reg->left : "", (size_t)reg->left_len);
+    b->jr_unit1.assign(reg->unit1, (size_t)reg->unit1_len);
+    b->jr_mid.assign(reg->mid ? reg->mid : "", (size_t)reg->mid_len);
+    b->jr_unit2.assign(reg->unit2, (size_t)reg->unit2_len);
+    b->jr_right.assign(reg->right ? reg->right : "", (size_t)reg->right_len);
 
     PackedReads pr;
     rc = pack_reads(n_reads, seqs, seq_off, nullptr, 1, pr, NRA_MAX_QLEN);
     if (rc) return rc;
     // Reads longer than one register block (3072 bases), or whose scores do not fit the int32 cells of the
     // joint sweeps, are scored cell by cell in chained row blocks with int64 cells (rare: a long amplicon).
-    std::vector<uint8_t> chained((size_t)n_reads, 0);
+    b->chained_reads.assign((size_t)n_reads, 0);
     for (int32_t r = 0; r < n_reads; ++r)
-        chained[r] = pr.reads[r].qlen > NRA_MAX_QLEN_1BLOCK || max_score(sc, pr.reads[r].qlen) > kScoreCapPk16;
+        b->chained_reads[r] = pr.reads[r].qlen > NRA_MAX_QLEN_1BLOCK || max_score(sc, pr.reads[r].qlen) > kScoreCapPk16;
+    b->arena.expect(pr.q2bit.size() * 6 + (size_t)n_reads * 64 + (1u << 20));
+    HIP_TRY(b->q2bit.upload(pr.q2bit));
+    HIP_TRY(b->qnmask.upload(pr.nmask));
+    b->n_q2bit_words = pr.q2bit.size();
+    b->reads_have_n = pr.has_n;
+    b->host_reads = std::move(pr.reads);
+    rc = alloc_results(b, (size_t)n_reads, true);      // best_wscore, n_ties, sum_k, sum_k2, status, strand_out
+    if (rc) return rc;
+    for (int i = 0; i < 2; ++i) HIP_TRY(g_handles.event(b->device, true, &b->phase_ev[i]));
+    HIP_TRY(g_handles.event(b->device, false, &b->fork_ev));
+    HIP_TRY(g_handles.event(b->device, false, &b->fork2_ev));
+    *out = guard.release();
+    return NRA_OK;
+}
+
+// The cell list of one grid round.  May be called again on the same batch (the reads stay packed on the
+// device; the buffers of the previous list are handed out again).
+int nra_batch2d_set_cells(nra_batch_t* b, const int8_t* read_strand, int64_t n_cells, const int32_t* cell_read,
+                          const int32_t* cell_k1, const int32_t* cell_k2)
+{
+    if (!b || b->kind != 2) return fail(NRA_E_ARG, "not a 2D batch");
+    if (n_cells < 0) return fail(NRA_E_ARG, "bad cell count");
+    if (n_cells > 0 && (!cell_read || !cell_k1 || !cell_k2)) return fail(NRA_E_ARG, "NULL cell array");
+    if (n_cells > 0x7ff00000ll) return fail(NRA_E_RANGE, "too many cells");
+    HIP_TRY(hipSetDevice(b->device));
+    if (b->ran) HIP_TRY(hipStreamSynchronize(b->stream));      // the previous list's kernels own the buffers
+    {
+        int rc0 = account_run_fwd(b);
+        if (rc0) return rc0;
+    }
+    b->have_cells = false;
+    b->ran = false;
+    b->cell_arena.reset();
+    ArenaScope arena_scope(&b->cell_arena);
+    b->buckets.clear();
+    b->jgroups.clear();
+    b->n_cands = n_cells;
+    const int32_t n_reads = b->n_reads;
+    const int32_t flags = b->flags;
+    const nra_scoring_t* sc = &b->scoring;
+    (void)sc;
+    std::vector<NraDevRead> reads(b->host_reads);              // + the shadows of chained reads, below
+    int rc = NRA_OK;
 
     std::vector<uint32_t> first((size_t)n_reads, 0), cnt((size_t)n_reads, 0);
     int32_t k1max = 0, k2max = 0;
@@ -1010,31 +1067,34 @@ int nra_batch2d_create(int device, const nra_joint_region_t* reg, int32_t n_read
         k1max = std::max(k1max, cell_k1[c]);
         k2max = std::max(k2max, cell_k2[c]);
     }
-    const int64_t win = (int64_t)reg->unit1_len * k1max + reg->mid_len + (int64_t)reg->unit2_len * k2max + 20;
+    const int32_t left_len = (int32_t)b->jr_left.size(), unit1_len = (int32_t)b->jr_unit1.size(),
+                  mid_len = (int32_t)b->jr_mid.size(), unit2_len = (int32_t)b->jr_unit2.size(),
+                  right_len = (int32_t)b->jr_right.size();
+    const int64_t win = (int64_t)unit1_len * k1max + mid_len + (int64_t)unit2_len * k2max + 20;
     if (6 * win >= 32768) return fail(NRA_E_RANGE, "repeat window too long for the 16-bit window score");
-    const int64_t tlmax = (int64_t)reg->left_len + win - 20 + reg->right_len;
+    const int64_t tlmax = (int64_t)left_len + win - 20 + right_len;
     if (tlmax > NRA_MAX_TLEN) return fail(NRA_E_RANGE, "template too long");
 
     std::vector<uint8_t> pool;
-    bool has_n = pr.has_n;
+    bool has_n = b->reads_have_n;
     NraDevRegion d{};
-    d.p1_off = pool_append(pool, reg->left, reg->left_len, reg->unit1, reg->unit1_len, k1max, has_n);
-    d.p2_off = pool_append(pool, reg->mid, reg->mid_len, reg->unit2, reg->unit2_len, k2max, has_n);
-    d.p3_off = pool_append(pool, reg->right, reg->right_len, nullptr, 0, 0, has_n);
+    d.p1_off = pool_append(pool, b->jr_left.data(), left_len, b->jr_unit1.data(), unit1_len, k1max, has_n);
+    d.p2_off = pool_append(pool, b->jr_mid.data(), mid_len, b->jr_unit2.data(), unit2_len, k2max, has_n);
+    d.p3_off = pool_append(pool, b->jr_right.data(), right_len, nullptr, 0, 0, has_n);
     {
-        std::string rr(reg->right, reg->right + reg->right_len);
+        std::string rr(b->jr_right);
         std::reverse(rr.begin(), rr.end());
-        d.pr_off = pool_append(pool, rr.data(), reg->right_len, nullptr, 0, 0, has_n);
+        d.pr_off = pool_append(pool, rr.data(), right_len, nullptr, 0, 0, has_n);
     }
-    d.l1 = reg->left_len; d.m1 = reg->unit1_len; d.l2 = reg->mid_len; d.m2 = reg->unit2_len; d.l3 = reg->right_len;
+    d.l1 = left_len; d.m1 = unit1_len; d.l2 = mid_len; d.m2 = unit2_len; d.l3 = right_len;
     pool.push_back(0);
     b->has_n = has_n ? 1 : 0;
     std::vector<NraDevRegion> dregs(1, d);
 
     std::vector<std::vector<int32_t>> by_bucket((size_t)kNumR + 1);
     for (int32_t r = 0; r < n_reads; ++r) {
-        if (cnt[r] == 0 || pr.reads[r].qlen == 0) continue;
-        by_bucket[chained[r] ? kNumR : rows_for_qlen(pr.reads[r].qlen)].push_back(r);
+        if (cnt[r] == 0 || reads[r].qlen == 0) continue;
+        by_bucket[b->chained_reads[r] ? kNumR : rows_for_qlen(reads[r].qlen)].push_back(r);
     }
     const std::vector<int32_t> chain_reads = by_bucket[kNumR];
     by_bucket[kNumR].clear();
@@ -1047,7 +1107,7 @@ int nra_batch2d_create(int device, const nra_joint_region_t* reg, int32_t n_read
     std::vector<NraJointTask> jbwd, jpre, jtail;
     std::vector<int32_t> k1list;
     // junction decomposition needs a base left of the window and two bases of R
-    b->brute = (flags & NRA_F_BRUTE_FORCE) != 0 || reg->left_len < 1 || reg->right_len < 2;
+    b->brute = (flags & NRA_F_BRUTE_FORCE) != 0 || left_len < 1 || right_len < 2;
     // wave states of one group of reads (NRA_F_TEST_CHAIN: one read per group, to exercise the reuse)
     // The buckets run concurrently, each in its own part of the state buffer.
     size_t n_nonempty = 0;
@@ -1122,16 +1182,16 @@ int nra_batch2d_create(int device, const nra_joint_region_t* reg, int32_t n_read
                     bk.cells_pair += 2 * sweep_cells(bk.R, d.l1 + d.m1 * t.k1a + d.l2 + d.m2 * t.k2a + d.l3);
             } else {
                 // chained: the read and a reverse-complemented shadow of it against the same template
-                NraDevRead shadow = pr.reads[r];
+                NraDevRead shadow = reads[r];
                 shadow.rc = 1;
-                const int32_t sh = (int32_t)pr.reads.size();
-                pr.reads.push_back(shadow);
+                const int32_t sh = (int32_t)reads.size();
+                reads.push_back(shadow);
                 probe_tasks.push_back(NraTask{r, cell_k1[first[r]], cell_k2[first[r]], 2 * r});
                 probe_tasks.push_back(NraTask{sh, cell_k1[first[r]], cell_k2[first[r]], 2 * r + 1});
             }
             for (uint32_t c = first[r]; c < first[r] + cnt[r]; ++c) {
                 const int tl = d.l1 + d.m1 * cell_k1[c] + d.l2 + d.m2 * cell_k2[c] + d.l3;
-                alg_cells += (int64_t)pr.reads[r].qlen * tl;
+                alg_cells += (int64_t)reads[r].qlen * tl;
                 if (per_cell) {
                     queue_tasks.push_back(NraTask{r, cell_k1[c], cell_k2[c], (int32_t)c});
                     bk.cells_queue += sweep_cells(bk.R, tl);
@@ -1156,16 +1216,14 @@ int nra_batch2d_create(int device, const nra_joint_region_t* reg, int32_t n_read
     }
     const size_t nb = b->buckets.size();
 
-    // one chunk for everything but the wave states, which get their own
-    b->arena.expect(pr.q2bit.size() * 16 * 13 + (size_t)n_cells * 20 + pool.size() + (size_t)n_reads * 128 +
-                    (jbwd.size() + jpre.size() + jtail.size()) * sizeof(NraJointTask) + k1list.size() * 4 +
-                    queue_tasks.size() * sizeof(NraTask) + (4u << 20));
+    // one chunk for everything but the wave states, which get their own (all of it reused by the next cell list)
+    b->cell_arena.expect(b->n_q2bit_words * 16 * 13 + (size_t)n_cells * 20 + pool.size() + (size_t)n_reads * 128 +
+                         (jbwd.size() + jpre.size() + jtail.size()) * sizeof(NraJointTask) + k1list.size() * 4 +
+                         queue_tasks.size() * sizeof(NraTask) + (4u << 20));
     HIP_TRY(b->pool.upload(pool));
-    HIP_TRY(b->q2bit.upload(pr.q2bit));
-    HIP_TRY(b->qnmask.upload(pr.nmask));
     HIP_TRY(b->regions.upload(dregs));
-    HIP_TRY(b->reads.upload(pr.reads));
-    HIP_TRY(b->reads_init.upload(pr.reads));
+    HIP_TRY(b->reads.upload(reads));
+    HIP_TRY(b->reads_init.upload(reads));
     HIP_TRY(b->pair_tasks.upload(pair_tasks));
     HIP_TRY(b->queue_tasks.upload(queue_tasks));
     HIP_TRY(b->queue_count.upload(queue_count));
@@ -1182,7 +1240,7 @@ int nra_batch2d_create(int device, const nra_joint_region_t* reg, int32_t n_read
         HIP_TRY(b->jtail_tasks.upload(jtail));
         HIP_TRY(b->jk1list.upload(k1list));
         HIP_TRY(b->jstate.alloc((size_t)state_base));
-        HIP_TRY(b->jsnap.alloc(pr.q2bit.size() * 16 * 3));
+        HIP_TRY(b->jsnap.alloc(b->n_q2bit_words * 16 * 3));
         HIP_TRY(b->jread_a.alloc((size_t)n_reads));
     }
     HIP_TRY(b->probe_score.alloc(2 * (size_t)n_reads));
@@ -1192,31 +1250,48 @@ int nra_batch2d_create(int device, const nra_joint_region_t* reg, int32_t n_read
     }
     HIP_TRY(b->cell_first.upload(first));
     HIP_TRY(b->cell_cnt.upload(cnt));
+    b->have_strand_in = read_strand != nullptr;
     if (read_strand) {
         std::vector<int8_t> v(read_strand, read_strand + n_reads);
         HIP_TRY(b->strand_in.upload(v));
-        b->have_strand_in = true;
     }
     HIP_TRY(b->cand_score.alloc((size_t)n_cells));     // cell_score
     HIP_TRY(b->cand_tstart.alloc((size_t)n_cells));    // cell_wscore
-    rc = alloc_results(b, (size_t)n_reads, true);      // best_wscore, n_ties, sum_k, sum_k2, status, strand_out
-    if (rc) return rc;
-    rc = make_events(b, 2 + 6 * (int)nb + 4 * (int)b->jgroups.size() + 2);
-    if (rc) return rc;
-    // two streams per bucket: the buckets' chains overlap, and so do a bucket's reverse and prefix sweeps
-    b->bstreams.assign(2 * nb, nullptr); b->bdone.assign(3 * nb, nullptr);
-    for (size_t i = 0; i < 2 * nb; ++i) HIP_TRY(g_handles.stream(b->device, &b->bstreams[i]));
-    for (size_t i = 0; i < 3 * nb; ++i) HIP_TRY(g_handles.event(b->device, false, &b->bdone[i]));
-    HIP_TRY(g_handles.event(b->device, false, &b->fork_ev));
-    HIP_TRY(g_handles.event(b->device, false, &b->fork2_ev));
+    // events and streams: kept from one cell list to the next, more taken from the pool when needed
+    {
+        const size_t n_ev = 2 + 6 * nb + 4 * b->jgroups.size() + 2;
+        while (b->ev.size() < n_ev) { hipEvent_t e; HIP_TRY(g_handles.event(b->device, true, &e)); b->ev.push_back(e); }
+        // two streams per bucket: the buckets' chains overlap, and so do a bucket's reverse and prefix sweeps
+        while (b->bstreams.size() < 2 * nb) { hipStream_t q; HIP_TRY(g_handles.stream(b->device, &q)); b->bstreams.push_back(q); }
+        while (b->bdone.size() < 3 * nb) { hipEvent_t e; HIP_TRY(g_handles.event(b->device, false, &e)); b->bdone.push_back(e); }
+    }
 
     b->stats.n_alignments = n_cells;
     b->stats.algorithmic_cells = alg_cells;
     int64_t ex = 0;
     for (const Bucket& bk : b->buckets) ex += bk.cells_pair + bk.cells_queue + bk.cells_sweep;
     b->stats.executed_cells = ex;
-    b->stats.algorithmic_bytes = (int64_t)pr.q2bit.size() * 4 + (int64_t)pool.size() + n_cells * 8 + (int64_t)n_reads * 25;
-    *out = guard.release();
+    b->stats.algorithmic_bytes = (int64_t)b->n_q2bit_words * 4 + (int64_t)pool.size() + n_cells * 8 + (int64_t)n_reads * 25;
+    b->have_cells = true;
+    return NRA_OK;
+}
+
+
+int nra_batch2d_create(int device, const nra_joint_region_t* reg, int32_t n_reads, const char* seqs,
+                       const int64_t* seq_off, const int8_t* read_strand, int64_t n_cells,
+                       const int32_t* cell_read, const int32_t* cell_k1, const int32_t* cell_k2,
+                       const nra_scoring_t* sc, int32_t flags, nra_batch_t** out)
+{
+    if (!out) return fail(NRA_E_ARG, "out is NULL");
+    *out = nullptr;
+    if (n_cells < 0) return fail(NRA_E_ARG, "bad region / counts");
+    if (n_cells > 0 && (!cell_read || !cell_k1 || !cell_k2)) return fail(NRA_E_ARG, "NULL cell array");
+    nra_batch_t* b = nullptr;
+    int rc = nra_batch2d_create_reads(device, reg, n_reads, seqs, seq_off, sc, flags, &b);
+    if (rc) return rc;
+    rc = nra_batch2d_set_cells(b, read_strand, n_cells, cell_read, cell_k1, cell_k2);
+    if (rc) { nra_batch_destroy(b); return rc; }
+    *out = b;
     return NRA_OK;
 }
 
@@ -1636,6 +1711,7 @@ int nra_batch_run(nra_batch_t* b)
         int rc0 = account_run(b);
         if (rc0) return rc0;
     }
+    if (b->kind == 2 && !b->have_cells) return fail(NRA_E_ARG, "2D batch without a cell list: call nra_batch2d_set_cells");
     int rc = b->kind == 1 ? run_1d(b) : run_2d(b);
     if (!rc) { b->ran = true; b->accounted = false; }
     return rc;

@@ -6,60 +6,65 @@ The functions keep the reference's names, arguments and results; the aligner loo
 CIGAR walk of `estimate_two_repeats_from_paf` are replaced by ONE call through the C ABI
 (`nra_joint_2d`) per round: the (read, k1, k2) list goes in, per-read tie sums come back.
 """
+from dataclasses import dataclass, field
+
 import numpy as np
 
 from . import _capi
 
 
+@dataclass
 class Repeat:
-    """nanoRepeat_joint.py:42-69."""
+    """One of the two repeats of a joint run: the record nanoRepeat_joint.py:42-69 keeps (same field
+    names, so either object can be handed to the other code base)."""
+    repeat_id: str = ""
+    chrom: str = ""
+    start: int = -1
+    end: int = -1
+    repeat_unit: str = ""
+    repeat_unit_size: int = 0
+    min_size: int = 0
+    max_size: int = 1000
+    round1_min_size: int = 0
+    round1_max_size: int = 1000
 
-    def __init__(self):
-        self.repeat_id = ""
-        self.chrom = ""
-        self.start = -1
-        self.end = -1
-        self.repeat_unit = ""
-        self.repeat_unit_size = 0
-        self.min_size = 0
-        self.max_size = 1000
-        self.round1_min_size = 0
-        self.round1_max_size = 1000
+    SPEC = "chr:start:end:repeat_unit:max_size"
+
+    @classmethod
+    def parse(cls, spec):
+        """`--repeat1 chr4:3074876:3074933:CAG:200` -> Repeat."""
+        parts = spec.split(":")
+        if len(parts) != 5:
+            raise ValueError(f"--repeat1 and --repeat2 should be in this format: {cls.SPEC}")
+        chrom, start, end, unit, max_size = parts
+        return cls(repeat_id="-".join(parts[:4]), chrom=chrom, start=int(start), end=int(end), repeat_unit=unit,
+                   repeat_unit_size=len(unit), min_size=0, max_size=int(max_size))
 
     def init_from_string(self, string):
-        col_list = string.split(":")
-        if len(col_list) != 5:
-            raise ValueError("--repeat1 and --repeat2 should be in this format: "
-                             "chr:start:end:repeat_unit:max_size")
-        self.chrom, self.start, self.end, self.repeat_unit, self.max_size = col_list
-        self.start = int(self.start)
-        self.end = int(self.end)
-        self.repeat_unit_size = len(self.repeat_unit)
-        self.min_size = 0
-        self.max_size = int(self.max_size)
-        self.repeat_id = "-".join(col_list[0:4])
+        """The reference's spelling of parse(): fills this object in place and returns it."""
+        self.__dict__.update(Repeat.parse(string).__dict__)
         return self
 
 
+@dataclass
 class Round1Estimation:
-    """nanoRepeat_joint.py:71-84: per-read [min, max) ranges of both repeat counts."""
+    """What round 1 knows per read (nanoRepeat_joint.py:71-84): [min, max) ranges of both repeat counts,
+    where on the read the repeats lie, which reads to drop -- and, not in the reference, the strand, which
+    saves the grid rounds their strand probe."""
+    repeat1_count_range_dict: dict = field(default_factory=dict)
+    repeat2_count_range_dict: dict = field(default_factory=dict)
+    potential_repeat_region_dict: dict = field(default_factory=dict)
+    bad_reads_set: set = field(default_factory=set)
+    read_strand_dict: dict = field(default_factory=dict)      # +1 / -1
 
-    def __init__(self):
-        self.repeat1_count_range_dict = dict()
-        self.repeat2_count_range_dict = dict()
-        self.potential_repeat_region_dict = dict()
-        self.bad_reads_set = set()
-        self.read_strand_dict = dict()      # not in the reference: +1 / -1 from round 1, saves the strand probe
 
-
+@dataclass
 class RepeatSize:
-    """nanoRepeat_joint.py:86-91."""
-
-    def __init__(self):
-        self.repeat1_count_dict = dict()
-        self.repeat2_count_dict = dict()
-        self.step_size1 = 1
-        self.step_size2 = 1
+    """Per-read estimates of one grid round and the grid steps they were made with (nanoRepeat_joint.py:86-91)."""
+    repeat1_count_dict: dict = field(default_factory=dict)
+    repeat2_count_dict: dict = field(default_factory=dict)
+    step_size1: int = 1
+    step_size2: int = 1
 
 
 def choose_best_step_size(repeat, count_range_dict):
@@ -261,141 +266,199 @@ MAX_READ_2D = 3072          # rows one wave holds (NRA_MAX_QLEN_1BLOCK): the lim
                             # cell in chained row blocks, the full read like the reference (nanoRepeat_joint.py:332,408)
 
 
-def _grid_product(k1_values, k2_values):
-    """All (k1, k2) pairs, k1-major: the order the reference's nested loops list a read's cells in."""
-    return np.repeat(k1_values, len(k2_values)), np.tile(k2_values, len(k1_values))
+def _cells_of_ranges(grid1, lo1, hi1, grid2, lo2, hi2):
+    """Per read r the cells grid1[lo1[r]:hi1[r]] x grid2[lo2[r]:hi2[r]], k1-major -- the order the
+    reference's nested loops list a read's cells in -- for all reads at once: (cell_read, k1, k2)."""
+    n1 = np.maximum(hi1 - lo1, 0).astype(np.int64)
+    n2 = np.maximum(hi2 - lo2, 0).astype(np.int64)
+    cnt = n1 * n2
+    total = int(cnt.sum())
+    cell_read = np.repeat(np.arange(len(cnt), dtype=np.int32), cnt)
+    t = np.arange(total, dtype=np.int64) - np.repeat(np.cumsum(cnt) - cnt, cnt)
+    n2r = np.repeat(n2, cnt)
+    i1 = t // np.maximum(n2r, 1)
+    i2 = t - i1 * n2r
+    k1 = grid1[np.repeat(lo1, cnt) + i1] if total else np.zeros(0, np.int64)
+    k2 = grid2[np.repeat(lo2, cnt) + i2] if total else np.zeros(0, np.int64)
+    return cell_read, k1.astype(np.int32), k2.astype(np.int32)
 
 
-def _score_cells(region, readnames, fastq_dict, cells_by_read, device, scoring, scorer, strands, candidates=None):
-    """One C-ABI call for every (read, k1, k2) cell; returns (RepeatSize, raw outputs)."""
-    scorer = scorer or _capi.joint_2d
-    names = [n for n in readnames if n in cells_by_read and len(cells_by_read[n][0])]
-    reads = [_read_seq(fastq_dict[n]) for n in names]
-    # cells of a read: (k1 array, k2 array), k1-major like the reference's nested grid loops
-    per_read = [cells_by_read[n] for n in names]
-    counts = [len(c[0]) for c in per_read]
-    cell_read = np.repeat(np.arange(len(names), dtype=np.int32), counts)
-    k1 = np.concatenate([c[0] for c in per_read]).astype(np.int32) if names else np.zeros(0, np.int32)
-    k2 = np.concatenate([c[1] for c in per_read]).astype(np.int32) if names else np.zeros(0, np.int32)
+class GridSession:
+    """The reads of a joint run for the grid rounds: packed and uploaded once (`nra_batch2d_create_reads`),
+    scored against one cell list per round (`nra_batch2d_set_cells` + run).  With an injected `scorer`
+    (the tests' oracle twin of `_capi.joint_2d`) every round is a one-shot call instead."""
+
+    def __init__(self, region, fastq_dict, device=0, scoring=None, scorer=None):
+        self.region = region
+        self.names = list(fastq_dict)
+        self.index = {n: i for i, n in enumerate(self.names)}
+        self.reads = [_read_seq(fastq_dict[n]) for n in self.names]
+        self.device, self.scoring, self.scorer = device, scoring, scorer
+        self.batch = None
+        self.rounds = None          # set to a list to collect (n_cells, batch statistics) of every round
+        if scorer is None:
+            self.batch = _capi.Batch.create_2d_reads(region, self.reads, sc=scoring, device=device)
+
+    def score(self, cell_read, k1, k2, read_strand):
+        if self.scorer is not None:
+            return self.scorer(self.region, self.reads, cell_read, k1, k2, read_strand=read_strand, sc=self.scoring,
+                               device=self.device)
+        self.batch.set_cells(cell_read, k1, k2, read_strand)
+        self.batch.run()
+        self.batch.sync()
+        if self.rounds is not None:
+            self.rounds.append((len(cell_read), self.batch.stats()))
+        return self.batch.fetch(per_candidate=False)
+
+    def close(self):
+        if self.batch is not None:
+            self.batch.close()
+            self.batch = None
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+
+def _score_round(session, rows, grid1, lo1, hi1, grid2, lo2, hi2, strands):
+    """One grid round: `rows` = session read numbers with a cell range each.  Returns a RepeatSize."""
     est = RepeatSize()
-    if not names:
-        return est, None
+    if len(rows) == 0:
+        return est
+    n = len(session.names)
+    full = [np.zeros(n, np.int64) for _ in range(4)]                   # reads without cells: empty ranges
+    for dst, src in zip(full, (lo1, hi1, lo2, hi2)):
+        dst[rows] = src
+    cell_read, k1, k2 = _cells_of_ranges(grid1, full[0], full[1], grid2, full[2], full[3])
+    if len(cell_read) == 0:
+        return est
     st_in = None
     if strands is not None:
-        st_in = np.array([strands.get(n, 0) for n in names], np.int8)
-    out = scorer(region, reads, cell_read, k1, k2, read_strand=st_in, sc=scoring, device=device)
-    for i, n in enumerate(names):
-        if int(out["status"][i]) == _capi.READ_OK:        # nanoRepeat_joint.py:473-476
-            nt = np.float64(out["n_ties"][i])
-            est.repeat1_count_dict[n] = np.float64(out["sum_k1"][i]) / nt
-            est.repeat2_count_dict[n] = np.float64(out["sum_k2"][i]) / nt
-        if strands is not None:
-            strands[n] = int(out["read_strand"][i])
-    return est, out
+        st_in = np.fromiter((strands.get(name, 0) for name in session.names), np.int8, n)
+    out = session.score(cell_read, k1, k2, st_in)
+    has_cells = np.zeros(n, bool)
+    has_cells[cell_read] = True
+    ok = has_cells & (np.asarray(out["status"]) == _capi.READ_OK)      # nanoRepeat_joint.py:473-476
+    nt = np.asarray(out["n_ties"], np.float64)
+    for i in np.nonzero(ok)[0]:
+        name = session.names[i]
+        est.repeat1_count_dict[name] = np.float64(out["sum_k1"][i]) / nt[i]
+        est.repeat2_count_dict[name] = np.float64(out["sum_k2"][i]) / nt[i]
+    if strands is not None:
+        for i in np.nonzero(has_cells)[0]:
+            strands[session.names[i]] = int(out["read_strand"][i])
+    return est
+
+
+def _joint_region(repeat_chrom_seq, repeat1, repeat2, max_flanking_len=1000):
+    left, mid, right = extract_anchor_seq_for_two_repeats(repeat_chrom_seq, repeat1, repeat2, max_flanking_len)
+    return (left, repeat1.repeat_unit, mid, repeat2.repeat_unit, right)
+
+
+def _check_repeat_order(repeat1, repeat2):
+    if repeat1.chrom != repeat2.chrom or not repeat1.start < repeat2.start:
+        raise AssertionError("the two repeats must lie on one chromosome, repeat1 first")
 
 
 def round2_estimation_of_repeat_size(initial_estimation, fastq_dict, repeat_chrom_seq, repeat1,
                                      repeat2, data_type="ont", num_threads=1, out_dir=None,
-                                     device=0, scoring=None, scorer=None, strands=None):
-    """Coarse grid (nanoRepeat_joint.py:376-425).  `strands` (dict, optional) carries each
-    read's orientation between rounds so round 3 does not probe it again."""
-    assert repeat1.chrom == repeat2.chrom
-    assert repeat1.start < repeat2.start
-    max_flanking_len = 1000
+                                     device=0, scoring=None, scorer=None, strands=None, session=None):
+    """Coarse grid (nanoRepeat_joint.py:376-425).  `strands` (dict, optional) carries each read's
+    orientation between rounds so round 3 does not probe it again; `session` the resident reads."""
+    _check_repeat_order(repeat1, repeat2)
     step_size1 = choose_best_step_size(repeat1, initial_estimation.repeat1_count_range_dict)
     step_size2 = choose_best_step_size(repeat2, initial_estimation.repeat2_count_range_dict)
-    left, mid, right = extract_anchor_seq_for_two_repeats(repeat_chrom_seq, repeat1, repeat2, max_flanking_len)
-    # The reference loops grid cell by grid cell over all reads (:397-409); per read that is the
-    # product of the grid values inside its two round-1 ranges, k1-major.
-    grid1 = np.arange(repeat1.round1_min_size, repeat1.round1_max_size + 1, step_size1)
-    grid2 = np.arange(repeat2.round1_min_size, repeat2.round1_max_size + 1, step_size2)
-    cells = {}
-    for readname in fastq_dict:
-        if readname not in initial_estimation.repeat1_count_range_dict: continue
-        if readname not in initial_estimation.repeat2_count_range_dict: continue
-        min1, max1 = initial_estimation.repeat1_count_range_dict[readname]
-        min2, max2 = initial_estimation.repeat2_count_range_dict[readname]
-        cells[readname] = _grid_product(grid1[(grid1 >= min1) & (grid1 < max1)], grid2[(grid2 >= min2) & (grid2 < max2)])
-    region = (left, repeat1.repeat_unit, mid, repeat2.repeat_unit, right)
-    est, _ = _score_cells(region, list(fastq_dict), fastq_dict, cells, device, scoring, scorer, strands,
-                          getattr(initial_estimation, "potential_repeat_region_dict", None))
-    est.step_size1 = step_size1
-    est.step_size2 = step_size2
+    own = session is None
+    if own:
+        session = GridSession(_joint_region(repeat_chrom_seq, repeat1, repeat2), fastq_dict, device, scoring, scorer)
+    try:
+        # The reference visits grid cell by grid cell and, per cell, the reads whose round-1 ranges hold it
+        # (:397-409); per read that is the product of the grid values inside its two ranges.
+        grid1 = np.arange(repeat1.round1_min_size, repeat1.round1_max_size + 1, step_size1)
+        grid2 = np.arange(repeat2.round1_min_size, repeat2.round1_max_size + 1, step_size2)
+        r1, r2 = initial_estimation.repeat1_count_range_dict, initial_estimation.repeat2_count_range_dict
+        rows = np.array([i for i, name in enumerate(session.names) if name in r1 and name in r2], np.int64)
+        rng1 = np.array([r1[session.names[i]] for i in rows], np.int64).reshape(-1, 2)
+        rng2 = np.array([r2[session.names[i]] for i in rows], np.int64).reshape(-1, 2)
+        est = _score_round(session, rows,
+                           grid1, np.searchsorted(grid1, rng1[:, 0]), np.searchsorted(grid1, rng1[:, 1]),
+                           grid2, np.searchsorted(grid2, rng2[:, 0]), np.searchsorted(grid2, rng2[:, 1]), strands)
+    finally:
+        if own:
+            session.close()
+    est.step_size1, est.step_size2 = step_size1, step_size2
     return est
 
 
 def round3_estimation_of_repeat_size(initial_estimation, round2_estimation, fastq_dict,
                                      repeat_chrom_seq, repeat1, repeat2, data_type="ont",
                                      num_threads=1, out_dir=None, device=0, scoring=None,
-                                     scorer=None, strands=None):
+                                     scorer=None, strands=None, session=None):
     """Fine grid, step 1 (nanoRepeat_joint.py:275-349)."""
-    if len(round2_estimation.repeat1_count_dict) == 0 or len(round2_estimation.repeat2_count_dict) == 0:
+    done1, done2 = round2_estimation.repeat1_count_dict, round2_estimation.repeat2_count_dict
+    if len(done1) == 0 or len(done2) == 0:
         return RepeatSize()
-    assert repeat1.chrom == repeat2.chrom
-    assert repeat1.start < repeat2.start
-    max_flanking_len = 1000
-    buffer_size1 = round2_estimation.step_size1
-    buffer_size2 = round2_estimation.step_size2
-    size1_list, size2_list = [], []
-    for readname in round2_estimation.repeat1_count_dict:
-        if readname not in round2_estimation.repeat2_count_dict: continue
-        size1_list.append(round2_estimation.repeat1_count_dict[readname])
-        size2_list.append(round2_estimation.repeat2_count_dict[readname])
-    min_size1 = max(0, int(min(size1_list) - buffer_size1))               # :298-303
-    max_size1 = int(max(size1_list) + buffer_size1 + 2)
-    min_size2 = max(0, int(min(size2_list) - buffer_size2))
-    max_size2 = int(max(size2_list) + buffer_size2 + 2)
-    left, mid, right = extract_anchor_seq_for_two_repeats(repeat_chrom_seq, repeat1, repeat2, max_flanking_len)
-    grid1 = np.arange(min_size1, max_size1)
-    grid2 = np.arange(min_size2, max_size2)
-    cells = {}
-    for readname in fastq_dict:                                           # :320-330, per read
-        if readname not in round2_estimation.repeat1_count_dict: continue
-        if readname not in round2_estimation.repeat2_count_dict: continue
-        size1 = round2_estimation.repeat1_count_dict[readname]
-        size2 = round2_estimation.repeat2_count_dict[readname]
-        r1min1, r1max1 = initial_estimation.repeat1_count_range_dict[readname]
-        r1min2, r1max2 = initial_estimation.repeat2_count_range_dict[readname]
-        keep1 = (grid1 >= size1 - buffer_size1) & (grid1 < size1 + buffer_size1) & (grid1 >= r1min1) & (grid1 < r1max1)
-        keep2 = (grid2 >= size2 - buffer_size2) & (grid2 < size2 + buffer_size2) & (grid2 >= r1min2) & (grid2 < r1max2)
-        cells[readname] = _grid_product(grid1[keep1], grid2[keep2])
-    region = (left, repeat1.repeat_unit, mid, repeat2.repeat_unit, right)
-    est, _ = _score_cells(region, list(fastq_dict), fastq_dict, cells, device, scoring, scorer, strands,
-                          getattr(initial_estimation, "potential_repeat_region_dict", None))
-    est.step_size1 = 1
-    est.step_size2 = 1
+    _check_repeat_order(repeat1, repeat2)
+    buf1, buf2 = round2_estimation.step_size1, round2_estimation.step_size2
+    own = session is None
+    if own:
+        session = GridSession(_joint_region(repeat_chrom_seq, repeat1, repeat2), fastq_dict, device, scoring, scorer)
+    try:
+        rows = np.array([i for i, name in enumerate(session.names) if name in done1 and name in done2], np.int64)
+        size1 = np.array([done1[session.names[i]] for i in rows], np.float64)
+        size2 = np.array([done2[session.names[i]] for i in rows], np.float64)
+        # the global grid spans every read's round-2 size +- one coarse step (:298-303) ...
+        both = [name for name in done1 if name in done2]
+        all1 = np.array([done1[name] for name in both], np.float64)
+        all2 = np.array([done2[name] for name in both], np.float64)
+        grid1 = np.arange(max(0, int(all1.min() - buf1)), int(all1.max() + buf1 + 2))
+        grid2 = np.arange(max(0, int(all2.min() - buf2)), int(all2.max() + buf2 + 2))
+        # ... and a read takes the cells within one step of its own size that lie inside its round-1 range (:320-330)
+        r1 = np.array([initial_estimation.repeat1_count_range_dict[session.names[i]] for i in rows], np.float64).reshape(-1, 2)
+        r2 = np.array([initial_estimation.repeat2_count_range_dict[session.names[i]] for i in rows], np.float64).reshape(-1, 2)
+        est = _score_round(session, rows,
+                           grid1, np.searchsorted(grid1, np.maximum(size1 - buf1, r1[:, 0])),
+                           np.searchsorted(grid1, np.minimum(size1 + buf1, r1[:, 1])),
+                           grid2, np.searchsorted(grid2, np.maximum(size2 - buf2, r2[:, 0])),
+                           np.searchsorted(grid2, np.minimum(size2 + buf2, r2[:, 1])), strands)
+    finally:
+        if own:
+            session.close()
+    est.step_size1 = est.step_size2 = 1
     return est
 
 
 def fine_tune_read_count(initial_estimation, fastq_dict, repeat_chrom_seq, repeat1, repeat2,
                          data_type="ont", num_threads=1, out_dir=None, device=0, scoring=None,
-                         scorer=None):
+                         scorer=None, session=None):
     """nanoRepeat_joint.py:234-273.  Takes the FASTQ as the {readname: 4-line record} dict the
-    reference builds at :264 (file ingestion is outside the hot path)."""
-    assert repeat1.chrom == repeat2.chrom
-    assert repeat1.start < repeat2.start
-    repeat1.round1_max_size = 0
-    repeat2.round1_max_size = 0
-    repeat1.round1_min_size = repeat1.max_size
-    repeat2.round1_min_size = repeat2.max_size
-    for lo, hi in initial_estimation.repeat1_count_range_dict.values():
-        repeat1.round1_max_size = max(repeat1.round1_max_size, hi)
-        repeat1.round1_min_size = min(repeat1.round1_min_size, lo)
-    for lo, hi in initial_estimation.repeat2_count_range_dict.values():
-        repeat2.round1_max_size = max(repeat2.round1_max_size, hi)
-        repeat2.round1_min_size = min(repeat2.round1_min_size, lo)
-    repeat1.round1_max_size = min(repeat1.round1_max_size, repeat1.max_size)
-    repeat2.round1_max_size = min(repeat2.round1_max_size, repeat2.max_size)
+    reference builds at :264 (file ingestion is outside the hot path).  The reads are packed and
+    uploaded once for both grid rounds (`session`: a GridSession to reuse, e.g. a benchmark's)."""
+    _check_repeat_order(repeat1, repeat2)
+    for rep, ranges in ((repeat1, initial_estimation.repeat1_count_range_dict),
+                        (repeat2, initial_estimation.repeat2_count_range_dict)):
+        span = np.array(list(ranges.values()), np.int64).reshape(-1, 2)
+        lo = min(rep.max_size, int(span[:, 0].min())) if len(span) else rep.max_size
+        hi = max(0, int(span[:, 1].max())) if len(span) else 0
+        rep.round1_min_size, rep.round1_max_size = lo, min(hi, rep.max_size)            # :239-259
     # a read's strand is known from round 1 when that was run here (the left template is forward)
     strands = dict(getattr(initial_estimation, "read_strand_dict", {}))
-    round2_estimation = round2_estimation_of_repeat_size(
-        initial_estimation, fastq_dict, repeat_chrom_seq, repeat1, repeat2, data_type, num_threads,
-        out_dir, device, scoring, scorer, strands)
-    if round2_estimation.step_size1 > 1 and round2_estimation.step_size2 > 1:     # :268
-        return round3_estimation_of_repeat_size(
-            initial_estimation, round2_estimation, fastq_dict, repeat_chrom_seq, repeat1, repeat2,
-            data_type, num_threads, out_dir, device, scoring, scorer, strands)
-    return round2_estimation
+    own = session is None
+    if own:
+        session = GridSession(_joint_region(repeat_chrom_seq, repeat1, repeat2), fastq_dict, device, scoring, scorer)
+    try:
+        est = round2_estimation_of_repeat_size(initial_estimation, fastq_dict, repeat_chrom_seq, repeat1, repeat2,
+                                               data_type, num_threads, out_dir, device, scoring, scorer, strands, session)
+        if est.step_size1 > 1 and est.step_size2 > 1:                                    # :268
+            est = round3_estimation_of_repeat_size(initial_estimation, est, fastq_dict, repeat_chrom_seq, repeat1,
+                                                   repeat2, data_type, num_threads, out_dir, device, scoring, scorer,
+                                                   strands, session)
+    finally:
+        if own:
+            session.close()
+    return est
 
 
 def output_repeat_size_2d(in_fastq_file, repeat1_id, repeat2_id, out_prefix, repeat1_count_dict,
