@@ -394,7 +394,7 @@ def bench_joint(args):
     if args.cpu_sample != 0:
         from oracle import oracle as O
         cores = host_cores()
-        m = cores if args.cpu_sample < 0 else min(args.cpu_sample, n)
+        m = min(n, 64 * cores) if args.cpu_sample < 0 else min(args.cpu_sample, n)      # ~10 s of CPU work
         cr, c1, c2 = [], [], []
         for r in range(m):
             for x in range(int(j["range1"][r][0]), int(j["range1"][r][1]), 7):

@@ -4,32 +4,29 @@ exchanges integers, not text."""
 import re
 
 
+# the 12 mandatory PAF columns: (attribute, converter), in file order
+_COLUMNS = (("qname", str), ("qlen", int), ("qstart", int), ("qend", int), ("strand", str), ("tname", str),
+            ("tlen", int), ("tstart", int), ("tend", int), ("n_match", int), ("align_len", int), ("mapq", int))
+# optional tags the selectors read: tag prefix -> (attribute, converter)
+_TAGS = {"AS:i:": ("align_score", int), "cg:Z:": ("cigar", str), "tp:A:": ("is_primary", lambda v: v == "P")}
+
+
 class PAF:
-    """Parses the 12 fixed columns plus AS:i / cg:Z / tp:A, and flips qstart/qend to the read's own
-    strand on '-' records, exactly like the reference's class (paf.py:32-79)."""
+    """One PAF record with the attribute names the reference's selectors use (paf.py:32-79): the 12 fixed
+    columns, `align_score` (AS:i, default -1), `cigar` (cg:Z), `is_primary` (tp:A:P).  On '-' records
+    qstart/qend are turned onto the read's own strand (paf.py:70-74)."""
 
     def __init__(self, col_list):
-        if len(col_list) < 12:
+        if len(col_list) < len(_COLUMNS):
             raise ValueError("number of columns should be >= 12 in a PAF file: " + "\t".join(col_list))
-        self.qname, self.qlen, self.qstart, self.qend = col_list[0:4]
-        self.strand = col_list[4]
-        self.tname, self.tlen, self.tstart, self.tend = col_list[5:9]
-        self.n_match, self.align_len, self.mapq = col_list[9:12]
-        for f in ("qlen", "qstart", "qend", "tlen", "tstart", "tend", "n_match", "align_len", "mapq"):
-            setattr(self, f, int(getattr(self, f)))
-        self.is_primary = False
-        self.align_score = -1
-        self.cigar = ""
-        for col in col_list[12:]:
-            if col[0:5] == "AS:i:":
-                self.align_score = int(col[5:])
-            elif col[0:5] == "cg:Z:":
-                self.cigar = col[5:]
-            elif col == "tp:A:P":
-                self.is_primary = True
-            elif col == "tp:A:S":
-                self.is_primary = False
-        if self.strand not in "+-" or len(self.strand) != 1:
+        for (name, conv), text in zip(_COLUMNS, col_list):
+            setattr(self, name, conv(text))
+        self.align_score, self.cigar, self.is_primary, self.tscore = -1, "", False, 0
+        for tag in col_list[len(_COLUMNS):]:
+            known = _TAGS.get(tag[:5])
+            if known and (known[0] != "is_primary" or tag[5:] in ("P", "S")):
+                setattr(self, known[0], known[1](tag[5:]))
+        if self.strand not in ("+", "-"):
             raise ValueError(f"unknown strand: {self.strand}")
         if self.strand == "-":
             self.qstart, self.qend = self.qlen - self.qend, self.qlen - self.qstart

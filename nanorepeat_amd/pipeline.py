@@ -17,7 +17,29 @@ def quantify_regions(repeat_regions, reads_by_region, data_type="ont", fast_mode
     upstream.round1_and_round2_estimation_many(data_type, repeat_regions, num_cpu, device=device, scoring=scoring,
                                                aligner=aligner)
     round3.round3_estimation_regions(data_type, fast_mode, repeat_regions, num_cpu, device, scoring, scorer)
+    report_unscored_reads(repeat_regions)
     return [round3.output_repeat_size_1d(region) for region in repeat_regions]
+
+
+def report_unscored_reads(repeat_regions, stream=None):
+    """Reads that did not get a round-3 size of their own must not blend in silently: reads beyond the C
+    ABI's length limits (left out of steps 1-2, or kept at their round-2 size in step 3) are listed per
+    region on `region.skipped_reads` and counted on stderr.  Returns the number of such reads."""
+    import sys
+    stream = stream or sys.stderr
+    total = 0
+    for region in repeat_regions:
+        skipped = dict(getattr(region, "skipped_reads", None) or {})
+        for name, read in region.read_dict.items():
+            if getattr(read, "round3_status", None) == round3.READ_TOO_LONG:
+                skipped[name] = "core or template beyond the scorer's limits: kept at its round-2 size"
+        region.skipped_reads = skipped
+        if skipped:
+            total += len(skipped)
+            some = ", ".join(list(skipped)[:5]) + (" ..." if len(skipped) > 5 else "")
+            print(f"NOTICE: {region.to_unique_id()}: {len(skipped)} read(s) beyond the length limits were not "
+                  f"scored in full ({some})", file=stream)
+    return total
 
 
 def _fit_in_worker_processes(jobs, n_jobs):

@@ -31,53 +31,64 @@ class AnchorHit:
         self.align_score, self.align_len, self.mapq = align_score, align_len, mapq
 
 
-def check_anchor_mapping(one_read_anchor_paf_list):
-    """nanoRepeat_bam.py:165-179."""
-    if len(one_read_anchor_paf_list) == 0:
-        return False
-    if len(one_read_anchor_paf_list) == 1:
-        return True
-    if one_read_anchor_paf_list[0].align_len < 10:
-        return False
-    return (one_read_anchor_paf_list[0].align_score > 1.5 * one_read_anchor_paf_list[1].align_score
-            and one_read_anchor_paf_list[0].mapq > 30)
+def check_anchor_mapping(hits):
+    """Is the best hit of one anchor on one read unambiguous?  `hits` by decreasing score.  The rule of
+    nanoRepeat_bam.py:165-179 as one predicate: a lone hit is accepted; otherwise the best must span at
+    least 10 columns, beat the runner-up's score 1.5-fold and have mapq > 30."""
+    if len(hits) < 2:
+        return len(hits) == 1
+    best, second = hits[0], hits[1]
+    return best.align_len >= 10 and best.align_score > 1.5 * second.align_score and best.mapq > 30
+
+
+CORE_BUFFER = 100       # bases of flank kept on either side of the core (nanoRepeat_bam.py:221)
+MAX_READ_LEN = 4000000  # a read is the DP target of the anchors: NRA_MAX_TLEN_WIDE columns
+MAX_CORE_LEN = 200000   # a core is the DP query of the round-2 template: NRA_MAX_QLEN rows
+
+
+def _within_limit(repeat_region, sequences, limit, what):
+    """The entries of {name: sequence} the C ABI takes (length <= limit).  One over-long read must not
+    fail the call for every read of every region (the reference has no such limit): it is left out,
+    stays without an estimate, and is recorded on the region for the pipeline's report."""
+    keep = {}
+    for name, seq in sequences.items():
+        if len(seq.strip()) > limit:
+            skipped = getattr(repeat_region, "skipped_reads", None)
+            if skipped is None:
+                skipped = repeat_region.skipped_reads = {}
+            skipped[name] = f"{what} of {len(seq.strip())} bases (limit {limit})"
+        else:
+            keep[name] = seq
+    return keep
 
 
 def find_anchor_locations_for1read(read_paf_list, repeat_region):
-    """nanoRepeat_bam.py:181-236: accept a read when both anchors map uniquely, derive the core
-    (anchors' inner edges +- 100 bp) and middle coordinates, all on the read's own strand."""
-    if len(read_paf_list) == 0:
+    """Places one read (nanoRepeat_bam.py:181-236): both anchors must map unambiguously and in order
+    (gap > -10 when on one strand); then the read enters `repeat_region.read_dict` with its core
+    (anchors' inner edges +- 100 bases) and middle coordinates, all on the read's own strand."""
+    if not read_paf_list:
         return
-    left = sorted((p for p in read_paf_list if p.tname.startswith("left_anchor")),
-                  key=lambda p: p.align_score, reverse=True)
-    right = sorted((p for p in read_paf_list if p.tname.startswith("right_anchor")),
-                   key=lambda p: p.align_score, reverse=True)
+    ranked = {side: sorted((p for p in read_paf_list if p.tname.startswith(side + "_anchor")),
+                           key=lambda p: -p.align_score) for side in ("left", "right")}
+    if not (check_anchor_mapping(ranked["left"]) and check_anchor_mapping(ranked["right"])):
+        return
+    left, right = ranked["left"][0], ranked["right"][0]
+    # anchors on opposite strands keep a gap of 0 and pass, as upstream (:207-212)
+    gap = right.qstart - left.qend if left.strand == right.strand else 0
+    if gap <= -10:
+        return
     read = Read()
-    read.read_name = read_paf_list[0].qname
-    read.full_read_len = read_paf_list[0].qlen
-    read.both_anchors_are_good = False
-    read.left_anchor_is_good = check_anchor_mapping(left)
-    read.right_anchor_is_good = check_anchor_mapping(right)
-    if not read.left_anchor_is_good or not read.right_anchor_is_good:
-        return
-    repeat_region_length = 0
-    read.left_anchor_paf, read.right_anchor_paf = left[0], right[0]
-    if left[0].strand == right[0].strand:
-        repeat_region_length = right[0].qstart - left[0].qend
-    if repeat_region_length > -10:                       # :210 (also true when the strands differ, as upstream)
-        read.both_anchors_are_good = True
-        read.dist_between_anchors = repeat_region_length
-    if not read.both_anchors_are_good:
-        return
+    read.read_name, read.full_read_len = read_paf_list[0].qname, read_paf_list[0].qlen
+    read.left_anchor_is_good = read.right_anchor_is_good = read.both_anchors_are_good = True
+    read.left_anchor_paf, read.right_anchor_paf, read.dist_between_anchors = left, right, gap
+    read.strand = "+" if left.strand == "+" else "-"
+    read.mid_seq_start_pos, read.mid_seq_end_pos = left.qend, right.qstart
+    read.core_seq_start_pos = max(0, left.qend - CORE_BUFFER)
+    read.core_seq_end_pos = min(read.full_read_len, right.qstart + CORE_BUFFER)
+    read.left_buffer_len = left.qend - read.core_seq_start_pos
+    read.right_buffer_len = read.core_seq_end_pos - right.qstart
+    repeat_region.buffer_len = CORE_BUFFER
     repeat_region.read_dict[read.read_name] = read
-    repeat_region.buffer_len = 100
-    read.core_seq_start_pos = max(0, left[0].qend - repeat_region.buffer_len)
-    read.core_seq_end_pos = min(read.full_read_len, right[0].qstart + repeat_region.buffer_len)
-    read.mid_seq_start_pos = left[0].qend
-    read.mid_seq_end_pos = right[0].qstart
-    read.left_buffer_len = left[0].qend - read.core_seq_start_pos
-    read.right_buffer_len = read.core_seq_end_pos - right[0].qstart
-    read.strand = "+" if left[0].strand == "+" else "-"
 
 
 def find_anchor_locations_in_reads(data_type, repeat_region, num_cpu=1, region_reads=None, device=0,
@@ -86,6 +97,7 @@ def find_anchor_locations_in_reads(data_type, repeat_region, num_cpu=1, region_r
     reference reads them from region_fq_file)."""
     aligner = aligner or _capi.align_pairs
     region_reads = region_reads if region_reads is not None else repeat_region.region_reads
+    region_reads = _within_limit(repeat_region, region_reads, MAX_READ_LEN, "read")
     names = list(region_reads)
     if not names:
         return
@@ -142,7 +154,8 @@ def round1_and_round2_estimation(data_type, repeat_region, num_cpu=1, device=0, 
     if template_repeat_size < max(round1) + 10:
         template_repeat_size = int(max(round1) + 10)
     left = repeat_region.left_anchor_seq
-    names = [n for n in repeat_region.read_dict if n in repeat_region.read_core_seq_dict]
+    cores = _within_limit(repeat_region, repeat_region.read_core_seq_dict, MAX_CORE_LEN, "core")
+    names = [n for n in repeat_region.read_dict if n in cores]
     seqs = [left + unit * template_repeat_size] + [repeat_region.read_core_seq_dict[n] for n in names]
     out = aligner(seqs, np.arange(1, len(seqs), dtype=np.int32), np.zeros(len(names), np.int32),
                   sc=scoring, device=device)
@@ -177,6 +190,8 @@ def find_anchor_locations_in_reads_many(data_type, repeat_regions, reads_by_regi
     """find_anchor_locations_in_reads for many regions with ONE aligner call per ~256 M bases:
     same pairs, same per-read rule, one set of device buffers instead of one per region."""
     aligner = aligner or _capi.align_pairs
+    reads_by_region = [_within_limit(region, reads, MAX_READ_LEN, "read")
+                       for region, reads in zip(repeat_regions, reads_by_region)]
     sizes = [2 * sum(len(s) for s in reads.values()) for reads in reads_by_region]
     for lo, hi in _chunks_by_bases(sizes, max_bases):
         seqs, pq, pt, where = [], [], [], []
@@ -226,7 +241,8 @@ def round1_and_round2_estimation_many(data_type, repeat_regions, num_cpu=1, devi
         template_repeat_size = int(max(round1) * 1.5) + 1
         if template_repeat_size < max(round1) + 10:
             template_repeat_size = int(max(round1) + 10)
-        names = [n for n in region.read_dict if n in region.read_core_seq_dict]
+        cores = _within_limit(region, region.read_core_seq_dict, MAX_CORE_LEN, "core")
+        names = [n for n in region.read_dict if n in cores]
         plans.append((region.left_anchor_seq + unit * template_repeat_size, names))
     sizes = [0 if p is None else len(p[0]) + sum(len(repeat_regions[g].read_core_seq_dict[n]) for n in p[1])
              for g, p in enumerate(plans)]

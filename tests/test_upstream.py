@@ -192,3 +192,36 @@ def test_many_region_calls_equal_per_region_calls(oracle):
                 ra, rb = a.read_dict[n], b.read_dict[n]
                 assert ((ra.round1_repeat_size, ra.round2_repeat_size, ra.strand, ra.core_seq_start_pos, ra.core_seq_end_pos) ==
                         (rb.round1_repeat_size, rb.round2_repeat_size, rb.strand, rb.core_seq_start_pos, rb.core_seq_end_pos))
+
+
+def test_over_long_reads_and_cores_are_left_out_not_fatal(oracle, monkeypatch, capsys):
+    """one read beyond the aligner's target limit, or one core beyond its query limit, must not
+    abort every region: it is skipped, recorded on its region and reported; the other reads are unaffected."""
+    import copy
+    from nanorepeat_amd import pipeline, round3 as R3, synth
+    rng = np.random.default_rng(23)
+    regions, reads_by_region = [], []
+    for g, unit in enumerate(("CAG", "TATTG")):
+        left, right = synth.rand_seq(rng, 300), synth.rand_seq(rng, 300)
+        rr = R3.RepeatRegion(f"chr3\t{500 * g}\t{500 * g + 30}\t{unit}")
+        rr.left_anchor_seq, rr.right_anchor_seq, rr.left_anchor_len, rr.right_anchor_len = left, right, 300, 300
+        reads = {f"g{g}r{i}": synth.apply_errors(rng, left[-200:] + unit * (8 + 5 * (i % 2)) + right[:200], "ont_q20")
+                 for i in range(5)}
+        regions.append(rr); reads_by_region.append(reads)
+    base = copy.deepcopy(regions)
+    pipeline.quantify_regions(base, reads_by_region, aligner=oracle.align_pairs, scorer=oracle.round3_1d)
+    # the same with a huge read in region 0 and a read with a huge core in region 1
+    monkeypatch.setattr(U, "MAX_READ_LEN", 5000)
+    monkeypatch.setattr(U, "MAX_CORE_LEN", 1500)
+    reads_by_region[0]["giant"] = synth.rand_seq(rng, 6000)
+    l1, r1 = regions[1].left_anchor_seq, regions[1].right_anchor_seq
+    reads_by_region[1]["expanded"] = l1[-200:] + "TATTG" * 400 + r1[:200]                 # core of 2200 bases
+    test = copy.deepcopy(regions)
+    pipeline.quantify_regions(test, reads_by_region, aligner=oracle.align_pairs, scorer=oracle.round3_1d)
+    assert "giant" in test[0].skipped_reads and "expanded" in test[1].skipped_reads
+    assert "giant" not in test[0].read_dict and test[1].read_dict["expanded"].round3_repeat_size is None
+    for a, b in zip(base, test):
+        for n, ra in a.read_dict.items():
+            assert b.read_dict[n].round3_repeat_size == ra.round3_repeat_size
+    err = capsys.readouterr().err
+    assert err.count("NOTICE") == 2 and "giant" in err and "expanded" in err
