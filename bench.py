@@ -171,7 +171,10 @@ def roofline(st0, st1, n_steps, brute, kernel_name):
                             "over_executed": st1["algorithmic_cells"] / max(st1["executed_cells"], 1)},
             "hbm": {"algorithmic_bytes_per_step": st1["algorithmic_bytes"], "achieved_GBps": hbm_gbps,
                     "peak_GBps": HBM_PEAK_GBPS, "frac": hbm_gbps / HBM_PEAK_GBPS,
-                    "note": "compute-bound by design: ~5 B per read-alignment"},
+                    "junction_snapshot_bytes_per_step": st1["intermediate_bytes"],
+                    "note": "compute-bound by design: ~5 B per read-alignment of inputs and results; 'traffic' (PMC) "
+                            "also holds the decomposition's own hand-off between the reverse and the forward sweep "
+                            "(the R side of the junction, 12 B per row pair, written once and read once)"},
             "extent_kernel_ms_per_step": ext_ms, "device_ms_per_step": total_ms}
 
 

@@ -115,6 +115,8 @@ typedef struct nra_stats {
                                  buckets overlap on their own streams */
     /* the four timings above belong to the LAST run; these are summed over all n_runs runs */
     double  sum_score_kernel_ms, sum_extent_kernel_ms, sum_total_ms, sum_score_phase_ms;
+    int64_t intermediate_bytes; /* HBM bytes the decomposition itself moves per run between its kernels: the R side
+                                   of the junction (1D) / the wave states and the R side (2D), written once, read once */
 } nra_stats_t;
 
 typedef struct nra_batch nra_batch_t;   /* device-resident inputs + outputs of one call */

@@ -58,7 +58,8 @@ class Stats(C.Structure):
                 ("n_score_launches", C.c_int32), ("n_runs", C.c_int32),
                 ("score_phase_ms", C.c_double),
                 ("sum_score_kernel_ms", C.c_double), ("sum_extent_kernel_ms", C.c_double),
-                ("sum_total_ms", C.c_double), ("sum_score_phase_ms", C.c_double)]
+                ("sum_total_ms", C.c_double), ("sum_score_phase_ms", C.c_double),
+                ("intermediate_bytes", C.c_int64)]
 
     def as_dict(self):
         return {n: getattr(self, n) for n, _ in self._fields_}

@@ -825,6 +825,7 @@ int nra_batch1d_create(int device, const nra_region_t* regions, int32_t n_region
     for (const Bucket& bk : b->buckets) ex += bk.cells_pair + bk.cells_queue + bk.cells_sweep;
     b->stats.executed_cells = ex;
     b->stats.algorithmic_bytes = (int64_t)pr.q2bit.size() * 4 + (int64_t)pool.size() + total * 4 + (int64_t)n_reads * 17;
+    b->stats.intermediate_bytes = brute ? 0 : 2 * (int64_t)snap_total * 4;      // the junction snapshot: written, then read
     *out = guard.release();
     return NRA_OK;
 }
@@ -1272,6 +1273,7 @@ int nra_batch2d_set_cells(nra_batch_t* b, const int8_t* read_strand, int64_t n_c
     for (const Bucket& bk : b->buckets) ex += bk.cells_pair + bk.cells_queue + bk.cells_sweep;
     b->stats.executed_cells = ex;
     b->stats.algorithmic_bytes = (int64_t)b->n_q2bit_words * 4 + (int64_t)pool.size() + n_cells * 8 + (int64_t)n_reads * 25;
+    b->stats.intermediate_bytes = b->brute ? 0 : 2 * ((int64_t)state_base * 4 + (int64_t)b->n_q2bit_words * 16 * 3 * 4);
     b->have_cells = true;
     return NRA_OK;
 }

@@ -35,7 +35,7 @@ def test_structs_match_header_layout(capi):
     assert ctypes.sizeof(capi.Scoring) == 32
     assert ctypes.sizeof(capi.Region) == 3 * ctypes.sizeof(ctypes.c_void_p) + 12 + 4   # padded to 8
     assert ctypes.sizeof(capi.JointRegion) == 5 * ctypes.sizeof(ctypes.c_void_p) + 20 + 4
-    assert ctypes.sizeof(capi.Stats) == 5 * 8 + 3 * 8 + 8 + 8 + 4 * 8
+    assert ctypes.sizeof(capi.Stats) == 5 * 8 + 3 * 8 + 8 + 8 + 4 * 8 + 8
 
 
 def test_no_cpu_fallback_in_product(capi):
