@@ -190,7 +190,9 @@ def init_dist(args):
         local_rank = 0
     torch.cuda.set_device(local_rank)
     dist = None
-    if world > 1:
+    # NRA_BENCH_FORCE_DIST: rehearse the process-group path (RCCL init, all_reduce, all_gather, barrier) with
+    # the one rank a one-GPU box allows; needs the launcher's MASTER_ADDR / MASTER_PORT / RANK / WORLD_SIZE
+    if world > 1 or os.environ.get("NRA_BENCH_FORCE_DIST"):
         import torch.distributed as dist
         if args.backend == "nccl":
             dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))

@@ -480,10 +480,18 @@ __global__ __launch_bounds__(WAVE) void k_sweep_pk16(int n_tasks, const NraSweep
 // S and B travel through a second, one-slot LDS array on those steps only.  Price: the pipeline is 64*m
 // columns deep instead of 128.  No DPP moves, one cell per lane: ~12 instead of ~35 instructions of
 // per-step overhead.  (m <= SWEEP_RING_D; other regions and chained reads use k_sweep_pk16.)
+//
+// Measured and not kept (round 2, config 2 at 6.2 ms per step): persistent waves taking tasks from a global
+// counter (1-6 waves per SIMD: 6.3-6.6 ms; the task loop keeps ~35 more registers live); issuing the
+// hand-off's LDS read one step ahead (6.5 ms); a two- or three-column skew in the reverse sweep (6.6-6.7 ms);
+// two or four waves (= tasks) per workgroup (6.1-6.3 ms, SWEEP_RING_WPB below).
 #define SWEEP_RING_D NRA_SWEEP_RING_MAX_M
 
+#ifndef SWEEP_RING_WPB
+#define SWEEP_RING_WPB 1
+#endif
 template <int R, bool HAS_N, int DIR>
-__global__ __launch_bounds__(WAVE) void k_sweep_ring(int n_tasks, const NraSweepTask* __restrict__ tasks,
+__global__ __launch_bounds__(WAVE * SWEEP_RING_WPB) void k_sweep_ring(int n_tasks, const NraSweepTask* __restrict__ tasks,
                                                      const NraDevRead* __restrict__ reads,
                                                      const NraDevRegion* __restrict__ regions,
                                                      const uint8_t* __restrict__ pool,
@@ -499,11 +507,14 @@ __global__ __launch_bounds__(WAVE) void k_sweep_ring(int n_tasks, const NraSweep
                                                      uint8_t* __restrict__ cand_flag)
 {
     constexpr int SC = 2;                 // origin-bit scheme: doubled scores
-    __shared__ int4 ring[SWEEP_RING_D * 64];
-    __shared__ int2 racc[64];
-    const int task = blockIdx.x;
+    __shared__ int4 ring_all[SWEEP_RING_WPB * SWEEP_RING_D * 64];
+    __shared__ int2 racc_all[SWEEP_RING_WPB * 64];
+    const int wave_in_block = threadIdx.x >> 6;
+    int4* ring = ring_all + wave_in_block * SWEEP_RING_D * 64;
+    int2* racc = racc_all + wave_in_block * 64;
+    const int task = blockIdx.x * SWEEP_RING_WPB + wave_in_block;
     if (task >= n_tasks) return;
-    const int lane = threadIdx.x;
+    const int lane = threadIdx.x & 63;
     const NraSweepTask tk = tasks[task];
     const bool has_b = tk.read_b >= 0;
     const int ra = tk.read_a, rb = has_b ? tk.read_b : tk.read_a;
@@ -605,6 +616,8 @@ __global__ __launch_bounds__(WAVE) void k_sweep_ring(int n_tasks, const NraSweep
     const int nsteps = ncols + 63 * skew;                   // lane 63 finishes the last column at step ncols - 1 + 63*skew
     const int wr = (lane + 1) & 63;
     int slot = 0;                                           // step mod skew
+    // A (best alignment inside R, doubled) of the two reads: written by the reverse sweep, constant here
+    const int a_of_a = DIR ? read_a[ra] : 0, a_of_b = DIR ? read_a[rb] : 0;
     int phase = jfirst % m;                                 // boundary steps: step mod m == phase, step >= jfirst
     int pcnt = 0;                                           // step mod m
     int bidx = 0;                                           // boundary steps so far
@@ -640,7 +653,7 @@ __global__ __launch_bounds__(WAVE) void k_sweep_ring(int n_tasks, const NraSweep
                             const int S = (s2 ? half_hi(accS) : half_lo(accS)) - 2 * BIAS;
                             const int lo = sp.min_score > 1 ? sp.min_score : 1;
                             // packed 2*score + origin bit; an alignment inside R starts at a column >= |L|
-                            const int V = imax(imax(S, B), read_a[s2 ? rb : ra] + 1);
+                            const int V = imax(imax(S, B), (s2 ? a_of_b : a_of_a) + 1);
                             const int best = V >> 1;
                             int flag = 1;
                             if (V & 1) flag = 0;                                  // an optimal alignment starts at >= |L|
@@ -722,8 +735,8 @@ static int launch_sweep_ring(int R, int has_n, hipStream_t st, int n_tasks, cons
 #define ARGS n_tasks, tasks, reads, regions, pool, q2bit, qnmask, sp, kmin, kmax, coff, snap, read_a, cand_score, cand_flag
 #define CASE(r)                                                                          \
     case r:                                                                              \
-        if (has_n) k_sweep_ring<r, true, DIR><<<n_tasks, WAVE, 0, st>>>(ARGS);           \
-        else k_sweep_ring<r, false, DIR><<<n_tasks, WAVE, 0, st>>>(ARGS);                \
+        if (has_n) k_sweep_ring<r, true, DIR><<<(n_tasks + SWEEP_RING_WPB - 1) / SWEEP_RING_WPB, WAVE * SWEEP_RING_WPB, 0, st>>>(ARGS); \
+        else k_sweep_ring<r, false, DIR><<<(n_tasks + SWEEP_RING_WPB - 1) / SWEEP_RING_WPB, WAVE * SWEEP_RING_WPB, 0, st>>>(ARGS);      \
         break;
     switch (R) {
         NRA_R_LIST(CASE)

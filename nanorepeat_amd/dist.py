@@ -137,8 +137,9 @@ class ShardedBatch1D:
         import torch
         import torch.distributed as dist
         self.group = group
-        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
-        self.rank = dist.get_rank(group) if dist.is_initialized() else 0
+        self.collective = dist.is_initialized()          # a one-rank group still goes through the backend
+        self.world = dist.get_world_size(group) if self.collective else 1
+        self.rank = dist.get_rank(group) if self.collective else 0
         self.index = np.asarray(index, np.int64)
         self.n_total = int(n_total)
         self.error = None
@@ -156,7 +157,7 @@ class ShardedBatch1D:
             self.error = e
         self._dev = torch.device("cpu")
         self.cap = len(self.index)
-        if self.world > 1:
+        if self.collective:
             if dist.get_backend(group) == "nccl":
                 self._dev = torch.device("cuda", torch.cuda.current_device())
             sizes = torch.tensor([len(self.index)], dtype=torch.int64, device=self._dev)
@@ -189,7 +190,7 @@ class ShardedBatch1D:
             rows[1:n_local + 1, 1] = local["best_score"]
             rows[1:n_local + 1, 2] = local["sum_k"]
             rows[1:n_local + 1, 3] = (local["n_ties"].astype(np.int64) << 8) | local["status"].astype(np.int64)
-        if self.world == 1:
+        if not self.collective:
             parts = [rows]
         else:
             buf = torch.from_numpy(rows).to(self._dev)
