@@ -9,6 +9,8 @@ Metric (BASELINE.json): read-alignments/sec = (reads x candidate-k) scored per s
 --config 4 (BASELINE.json configs[3]): 1000 regions x 1000 reads, mixed 3-6 bp motifs, reference
     window rule; the regions are dealt to the ranks by executed DP cells (strong scaling).
 --config 3 (BASELINE.json configs[2]): joint CAG+CCG grid rounds 2+3 on 5000 amplicon reads, N = 1.
+--config 5 (BASELINE.json configs[4]): HiFi error model, k in [5,500] wide sweep (496 candidates), cores of
+    0.5 / 2.3 kb; like config 2 one region of --reads reads per rank.
 
 A "step" is one pass of the whole hot path over the rank's shard, whose inputs are already
 resident in HBM (nanorepeat_amd.dist.ShardedBatch1D = nra_batch1d_create has run): every scoring
@@ -52,7 +54,7 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--config", type=int, default=2, choices=(2, 3, 4))
+    ap.add_argument("--config", type=int, default=2, choices=(2, 3, 4, 5))
     ap.add_argument("--reads", type=int, default=10000, help="config 2: reads per GPU (10000); config 3: reads (5000)")
     ap.add_argument("--regions", type=int, default=1000, help="config 4: regions in the whole job")
     ap.add_argument("--reads-per-region", type=int, default=1000, help="config 4")
@@ -233,13 +235,17 @@ def bench_1d(args):
     from nanorepeat_amd import _capi as A, dist as D, synth
     rank, local_rank, world, dist = init_dist(args)
 
-    if args.config == 2:
-        # every rank owns one region of `reads` reads (weak scaling); rank 0's is BASELINE config 2 exactly
-        data = synth.config2(n_reads=args.reads, seed=synth.SEED + rank)
+    if args.config in (2, 5):
+        # every rank owns one region of `reads` reads (weak scaling); rank 0's is the BASELINE config exactly
+        make = synth.config2 if args.config == 2 else synth.config5
+        data = make(n_reads=args.reads, seed=synth.SEED + rank)
         index = rank * args.reads + np.arange(args.reads, dtype=np.int64)
         n_total = world * args.reads
         workload = ("config2: 10k synthetic ONT-error core reads (q~400/950), motif TATTG, k in [5,200] "
-                    "(196 candidates/read), 1000 bp flanks" + ("" if world == 1 else f"; one such region per GPU x {world}"))
+                    "(196 candidates/read), 1000 bp flanks" if args.config == 2 else
+                    f"config5: {args.reads} synthetic HiFi-error core reads (q~500/2300), motif TATTG, k in [5,500] "
+                    "(496 candidates/read, wide sweep), 1000 bp flanks")
+        workload += "" if world == 1 else f"; one such region per GPU x {world}"
         scaling = "weak"
     else:
         # the whole job is fixed; regions go to ranks by the cells the kernels will execute for them,

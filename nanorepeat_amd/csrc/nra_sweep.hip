@@ -80,6 +80,13 @@ __device__ __forceinline__ int pmax3(int a, int b, int c)
     return __builtin_bit_cast(int, __builtin_elementwise_maximum(__builtin_elementwise_maximum(x, y), z));
 }
 
+// A value parked in an accumulation register (AGPR).  A wave addresses 256 arch VGPRs; a forward sweep with
+// R rows per lane wants 8R + ~35, so from R = 28 on something has to live in the 256 AGPRs.  The compiler's
+// own choice costs a v_accvgpr move at every use of whatever it picked; the R side of the junction is read
+// on every m-th step only, so it is parked there by hand.
+__device__ __forceinline__ int agpr_put(int v) { int a; asm volatile("v_accvgpr_write_b32 %0, %1" : "=a"(a) : "v"(v)); return a; }
+__device__ __forceinline__ int agpr_get(int a) { int v; asm volatile("v_accvgpr_read_b32 %0, %1" : "=v"(v) : "a"(a)); return v; }
+
 // cell arithmetic of the sweeps: packed int16 pairs (two reads per wave, biased), or -- WIDE, the chained
 // sweeps of reads longer than one register block -- plain int32 (one read per wave, no bias, no range limit)
 template <bool W> __device__ __forceinline__ int mx2(int a, int b) { return W ? imax(a, b) : pmaxi(a, b); }
@@ -138,7 +145,7 @@ __device__ __forceinline__ void sweep_cell(int (&Hq)[R], int (&Hq2)[R], int (&E)
 // junction combine of one cell's rows at a boundary column (values biased twice).  The forward H is
 // taken as it is, not as max(H, 0): a term with H < 0 is below Hb alone, an alignment inside R, and
 // that is in the final maximum anyway (A, or A_k for chained reads).
-template <int OFF, int N, int R, bool W = false>
+template <int OFF, int N, int R, bool W = false, bool PARK = false>
 __device__ __forceinline__ int sweep_combine(const int (&Hq)[R], const int (&E)[R], const int (&E2)[R],
                                              const int (&Hbo)[R], const int (&Ebo)[R],
                                              const int (&E2bo)[R], int tS)
@@ -147,9 +154,9 @@ __device__ __forceinline__ int sweep_combine(const int (&Hq)[R], const int (&E)[
 #pragma unroll
     for (int n = 0; n < N; ++n) {
         const int i = OFF + n;
-        const int t1 = Hq[i] + Hbo[i];
-        const int t2 = E[i] + Ebo[i];
-        const int t3 = E2[i] + E2bo[i];
+        const int t1 = Hq[i] + (PARK ? agpr_get(Hbo[i]) : Hbo[i]);
+        const int t2 = E[i] + (PARK ? agpr_get(Ebo[i]) : Ebo[i]);
+        const int t3 = E2[i] + (PARK ? agpr_get(E2bo[i]) : E2bo[i]);
         tS = mx3<W>(tS, t1, t2);
         if (n & 1) tS = mx3<W>(tS, t3_prev, t3);
         else if (n == N - 1) tS = mx2<W>(tS, t3);
@@ -577,6 +584,7 @@ __global__ __launch_bounds__(WAVE * SWEEP_RING_WPB) void k_sweep_ring(int n_task
         const int cb = sweep_query_sel<HAS_N>(rdb, q2bit, qnmask, gi, DIR == 0);
         qc[i] = ca | (0x0c << 8) | (cb << 16) | (0x0c << 24);
     }
+    constexpr bool PARK = R >= 28;        // the R side of the junction in AGPRs
     int Hbo[DIR ? R : 1], Ebo[DIR ? R : 1], E2bo[DIR ? R : 1];
     if (DIR) {
         const int q1 = SC * (sp.open1 - sp.ext1), q2 = SC * (sp.open2 - sp.ext2);
@@ -596,9 +604,9 @@ __global__ __launch_bounds__(WAVE * SWEEP_RING_WPB) void k_sweep_ring(int n_task
                     e2[s] = (s ? half_hi(ve2) : half_lo(ve2)) + q2;
                 } else { h[s] = BIAS + o1 - SC; e[s] = BIAS - SC; e2[s] = BIAS - SC; }
             }
-            Hbo[i] = pack2(h[0], h[1]);
-            Ebo[i] = pack2(e[0], e[1]);
-            E2bo[i] = pack2(e2[0], e2[1]);
+            Hbo[i] = PARK ? agpr_put(pack2(h[0], h[1])) : pack2(h[0], h[1]);
+            Ebo[i] = PARK ? agpr_put(pack2(e[0], e[1])) : pack2(e[0], e[1]);
+            E2bo[i] = PARK ? agpr_put(pack2(e2[0], e2[1])) : pack2(e2[0], e2[1]);
         }
     }
     int Hq[R], Hq2[R], E[R], E2[R];
@@ -639,7 +647,7 @@ __global__ __launch_bounds__(WAVE * SWEEP_RING_WPB) void k_sweep_ring(int n_task
             if (tt & FLAG_SNAPSHOT) sweep_snapshot<0, R, R>(Hq, E, E2, snap_task, lane);
         } else {
             if (pcnt == phase && step >= jfirst) {          // every lane is on a unit boundary: wave-uniform
-                const int tS = sweep_combine<0, R, R>(Hq, E, E2, Hbo, Ebo, E2bo, NEG2);
+                const int tS = sweep_combine<0, R, R, false, PARK>(Hq, E, E2, Hbo, Ebo, E2bo, NEG2);
                 const int2 acc = racc[lane];
                 const int accS = pmaxi(acc.x, tS), accB = pmaxi(acc.y, M);
                 racc[wr] = make_int2(accS, accB);

@@ -310,6 +310,25 @@ def test_long_cores_chained_int32_sweeps_equal_oracle(capi, oracle):
     assert (g["status"] == 0).all() and g["best_score"][2] > 32767
 
 
+def test_large_row_counts_park_the_junction_in_agprs(capi, oracle):
+    """Reads of 1.7-3.0 kb take 28-48 rows per lane in the packed sweeps: the forward sweep then keeps the R
+    side of the junction in accumulation registers.  Two reads per bucket (pairs) plus a single, N bases."""
+    rng = np.random.default_rng(91)
+    L, R = synth.rand_seq(rng, 400), synth.rand_seq(rng, 400)
+    reads, kmin, kmax = [], [], []
+    for k_true in (300, 310, 350, 360, 440, 450, 520, 530, 560):          # cores of 1.7 ... 3.0 kb
+        s = synth.apply_errors(rng, L[-100:] + "TATTG" * k_true + R[:100], "hifi")
+        if k_true == 440:
+            s = s[:700] + "NN" + s[702:]
+        reads.append(s[:3072]); kmin.append(k_true - 6); kmax.append(k_true + 6)
+    assert max(len(r) for r in reads) > 2900
+    o = oracle.round3_1d([(L, "TATTG", R)], reads, kmin, kmax)
+    for flags in (0, capi.F_TIE_EXTENTS, capi.F_DPP_SWEEP):
+        g = capi.round3_1d([(L, "TATTG", R)], reads, kmin, kmax, flags=flags)
+        for k in ("best_score", "sum_k", "n_ties", "status", "cand_score"):
+            assert np.array_equal(g[k], o[k]), (flags, k, g[k][:8], o[k][:8])
+
+
 def test_long_joint_reads_uncut_equal_oracle(capi, oracle):
     """Joint reads of 5 kb (beyond one register block) are scored uncut, cell by cell in chained row
     blocks with int64 cells; strands probed (0) or given; short reads of the same batch take the sweeps."""
