@@ -13,6 +13,8 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <condition_variable>
+#include <functional>
 #include <memory>
 #include <mutex>
 #include <string>
@@ -106,11 +108,16 @@ inline uint8_t encode_base(char c)
 // Device memory of one call or batch: hipMalloc costs ~0.3 ms per call, a batch has ~25 buffers, so
 // they are carved out of a few large chunks.  While an Arena is "current" on this thread, DevBuf
 // allocations come from it (and are released with it); otherwise a DevBuf owns its allocation.
+// chunks come from / go back to a small per-device cache (HandlePool below)
+hipError_t device_chunk_get(int device, size_t bytes, char** out, size_t* got);
+void device_chunk_put(int device, char* p, size_t bytes);
+
 struct Arena {
     struct Chunk { char* p; size_t size, used; };
     std::vector<Chunk> chunks;
     size_t next_chunk = 1 << 20;
-    ~Arena() { for (Chunk& c : chunks) (void)hipFree(c.p); }
+    int device = 0;            // set before the first allocation; the work using the chunks is over when it dies
+    ~Arena() { for (Chunk& c : chunks) device_chunk_put(device, c.p, c.size); }
     void expect(size_t bytes) { next_chunk = std::max(next_chunk, bytes); }
     void reset() { for (Chunk& c : chunks) c.used = 0; }        // keep the memory, hand it out again
     hipError_t alloc(size_t bytes, void** out)
@@ -119,7 +126,7 @@ struct Arena {
         for (Chunk& c : chunks)
             if (c.size - c.used >= bytes) { *out = c.p + c.used; c.used += bytes; return hipSuccess; }
         Chunk c{nullptr, std::max(bytes, next_chunk), 0};
-        hipError_t e = hipMalloc((void**)&c.p, c.size);
+        hipError_t e = device_chunk_get(device, c.size, &c.p, &c.size);
         if (e != hipSuccess) return e;
         c.used = bytes;
         *out = c.p;
@@ -185,6 +192,39 @@ struct HandlePool {
         }
         return timing ? hipEventCreate(out) : hipEventCreateWithFlags(out, hipEventDisableTiming);
     }
+    // device chunks of destroyed arenas (hipMalloc + hipFree cost ~0.5 ms per one-shot call): a few are kept
+    std::vector<std::vector<std::pair<char*, size_t>>> chunks;      // [device]
+    size_t cached_bytes = 0;
+    static constexpr size_t kMaxCachedBytes = (size_t)2 << 30;
+    hipError_t chunk_get(int device, size_t bytes, char** out, size_t* got)
+    {
+        {
+            std::lock_guard<std::mutex> lk(mu);
+            auto& v = at(chunks, device);
+            for (size_t i = 0; i < v.size(); ++i)
+                if (v[i].second >= bytes && v[i].second <= 2 * bytes + ((size_t)16 << 20)) {
+                    *out = v[i].first; *got = v[i].second;
+                    cached_bytes -= v[i].second;
+                    v.erase(v.begin() + (long)i);
+                    return hipSuccess;
+                }
+        }
+        *got = bytes;
+        return hipMalloc((void**)out, bytes);
+    }
+    void chunk_put(int device, char* p, size_t bytes)
+    {
+        {
+            std::lock_guard<std::mutex> lk(mu);
+            auto& v = at(chunks, device);
+            if (v.size() < 6 && cached_bytes + bytes <= kMaxCachedBytes) {
+                v.push_back({p, bytes});
+                cached_bytes += bytes;
+                return;
+            }
+        }
+        (void)hipFree(p);
+    }
     // pinned staging buffers (hipHostMalloc costs ~0.2 ms): reused like the streams
     std::vector<std::pair<void*, size_t>> pinned;
     hipError_t pinned_get(size_t bytes, void** out, size_t* got)
@@ -219,6 +259,8 @@ struct HandlePool {
     }
 };
 HandlePool g_handles;
+hipError_t device_chunk_get(int device, size_t bytes, char** out, size_t* got) { return g_handles.chunk_get(device, bytes, out, got); }
+void device_chunk_put(int device, char* p, size_t bytes) { g_handles.chunk_put(device, p, bytes); }
 
 // 2D decomposition: reads of one bucket whose wave states fit the state buffer together; the
 // prefix sweeps of a group run, then its tail sweeps, then the next group reuses the buffer.
@@ -388,6 +430,60 @@ struct nra_batch {
 
 namespace {
 
+// ---- host worker threads --------------------------------------------------------------
+// Starting a thread costs ~50 us and a one-shot call has ~1 ms of packing to spread: the workers are
+// started once and woken per job.  run(n, fn) runs fn(0..n-1) on the caller and n-1 workers and returns
+// when all are done.  One job at a time (callers from several threads take turns).
+class HostWorkers {
+    std::mutex job_mu, mu;
+    std::condition_variable wake, done;
+    std::vector<std::thread> threads;
+    const std::function<void(int)>* fn = nullptr;
+    int n_jobs = 0, next = 0, pending = 0;
+    uint64_t generation = 0;
+
+    void loop()
+    {
+        uint64_t seen = 0;
+        std::unique_lock<std::mutex> lk(mu);
+        for (;;) {
+            wake.wait(lk, [&] { return generation != seen; });
+            seen = generation;
+            while (next < n_jobs) {
+                const int i = next++;
+                lk.unlock();
+                (*fn)(i);
+                lk.lock();
+                if (--pending == 0) done.notify_all();
+            }
+        }
+    }
+
+public:
+    void run(int n, const std::function<void(int)>& f)
+    {
+        if (n <= 1) { if (n == 1) f(0); return; }
+        std::lock_guard<std::mutex> one_job(job_mu);
+        std::unique_lock<std::mutex> lk(mu);
+        while ((int)threads.size() < n - 1) { threads.emplace_back([this] { loop(); }); threads.back().detach(); }
+        fn = &f; n_jobs = n; next = 0; pending = n;
+        ++generation;
+        wake.notify_all();
+        while (next < n_jobs) {            // the caller works too
+            const int i = next++;
+            lk.unlock();
+            f(i);
+            lk.lock();
+            --pending;
+        }
+        done.wait(lk, [&] { return pending == 0; });
+        fn = nullptr;
+    }
+};
+// never destroyed: the workers wait on its condition variable for the life of the process, and destroying
+// a condition variable that has waiters blocks (glibc) -- at exit that is a hang
+HostWorkers& g_workers = *new HostWorkers;
+
 // ---- sequence packing ---------------------------------------------------------------
 struct PackedReads {
     std::vector<uint32_t> q2bit, nmask;
@@ -418,40 +514,36 @@ int pack_reads(int32_t n_reads, const char* seqs, const int64_t* seq_off, const 
     out.q2bit.assign((size_t)(base / 16) + 1, 0);
     out.nmask.assign((size_t)(base / 32) + 1, 0);
     // every read starts on a 32-base boundary, so reads write disjoint words: encode in parallel
+    // one worker per ~256 k bases, each a contiguous run of reads
     const unsigned hw = std::max(1u, std::thread::hardware_concurrency());
-    const int nthreads = base < (1u << 20) ? 1 : (int)std::min<unsigned>(hw, 16);
+    const int nthreads = (int)std::max<uint64_t>(1, std::min<uint64_t>(std::min<unsigned>(hw, 16), base >> 18));
     std::vector<uint8_t> saw_n((size_t)nthreads, 0);
     auto work = [&](int t) {
-        bool has_n = false;
-        for (int32_t r = t; r < n_reads; r += nthreads) {
+        uint32_t any_n = 0;
+        const int32_t r0 = (int32_t)((int64_t)n_reads * t / nthreads), r1 = (int32_t)((int64_t)n_reads * (t + 1) / nthreads);
+        for (int32_t r = r0; r < r1; ++r) {
             const uint8_t* s = reinterpret_cast<const uint8_t*>(seqs + seq_off[r]);
             const int32_t len = out.reads[r].qlen;
             uint32_t* q2 = out.q2bit.data() + (out.reads[r].qoff >> 4);
             uint32_t* nm = out.nmask.data() + (out.reads[r].qoff >> 5);
             for (int32_t i = 0; i < len; i += 32) {
                 const int32_t n = std::min(32, len - i);
-                uint32_t w0 = 0, w1 = 0, mask = 0;
-                for (int32_t j = 0; j < n; ++j) {
+                uint64_t w = 0;                    // 32 bases x 2 bits; an N keeps code 0 and sets its mask bit
+                uint32_t mask = 0;
+                for (int32_t j = 0; j < n; ++j) {  // branch-free: code 4 (N) = 0b100 -> bits 0..1 = 0, bit 2 = the mask
                     const uint32_t c = kBaseCode[s[i + j]];
-                    if (c >= 4) mask |= 1u << j;
-                    else if (j < 16) w0 |= c << (2 * j);
-                    else w1 |= c << (2 * (j - 16));
+                    w |= (uint64_t)(c & 3u) << (2 * j);
+                    mask |= (c >> 2) << j;
                 }
-                q2[(i >> 4)] = w0;
-                if (n > 16) q2[(i >> 4) + 1] = w1;
+                q2[(i >> 4)] = (uint32_t)w;
+                if (n > 16) q2[(i >> 4) + 1] = (uint32_t)(w >> 32);
                 nm[i >> 5] = mask;
-                has_n |= mask != 0;
+                any_n |= mask;
             }
         }
-        saw_n[(size_t)t] = has_n ? 1 : 0;
+        saw_n[(size_t)t] = any_n ? 1 : 0;
     };
-    if (nthreads == 1) {
-        work(0);
-    } else {
-        std::vector<std::thread> pool;
-        for (int t = 0; t < nthreads; ++t) pool.emplace_back(work, t);
-        for (std::thread& th : pool) th.join();
-    }
+    g_workers.run(nthreads, work);
     for (uint8_t v : saw_n) out.has_n |= v != 0;
     return NRA_OK;
 }
@@ -474,6 +566,8 @@ int common_init(nra_batch* b, int device, const nra_scoring_t* sc, int flags)
     if (device < 0 || device >= ndev) return fail(NRA_E_ARG, "device index out of range");
     HIP_TRY(hipSetDevice(device));
     b->device = device;
+    b->arena.device = device;
+    b->cell_arena.device = device;
     b->flags = flags;
     b->sp = to_params(*sc);
     HIP_TRY(g_handles.stream(device, &b->stream));
@@ -1572,6 +1666,7 @@ int nra_align_pairs(int device, int32_t n_seqs, const char* seqs, const int64_t*
         any_chain |= g.chain;
     }
     Arena arena;                       // before the buffers: released after them
+    arena.device = device;
     ArenaScope arena_scope(&arena);
     arena.expect(ps.pool.size() + ps.q2bit.size() * 6 + (size_t)n_pairs * 32 + (2u << 20));
     DevBuf<uint8_t> d_pool; DevBuf<uint32_t> d_q2, d_nm; DevBuf<NraDevRegion> d_regs; DevBuf<NraDevRead> d_reads;
@@ -1645,6 +1740,7 @@ int nra_align_pairs_cigar(int device, int32_t n_seqs, const char* seqs, const in
     if (trace_bytes > (8ull << 30)) return fail(NRA_E_RANGE, "trace needs more than 8 GiB: split the call");
     const size_t nt = tasks.size();
     Arena arena;                       // before the buffers: released after them
+    arena.device = device;
     ArenaScope arena_scope(&arena);
     arena.expect(ps.pool.size() + ps.q2bit.size() * 6 + nt * 128 + (size_t)ops_bytes + (2u << 20));
     DevBuf<uint8_t> d_pool, d_trace, d_ops; DevBuf<uint32_t> d_q2, d_nm; DevBuf<NraDevRegion> d_regs;
