@@ -351,6 +351,10 @@ struct nra_batch {
     nra_scoring_t scoring{};
     size_t n_q2bit_words = 0;
     bool reads_have_n = false;
+    // 2D: the reverse sweep of a read (the R side of the junction, A) depends on the read, R and the strand
+    // only: a later cell list of the same batch reuses it (rev_strand: strand it was made for, 0 = not made)
+    std::vector<int8_t> rev_strand;
+    std::vector<std::pair<int32_t, int8_t>> rev_pending;    // made by the next run
     int kind = 0;              // 1 = 1D, 2 = 2D
     int device = 0;
     int flags = 0;
@@ -1113,6 +1117,9 @@ int nra_batch2d_create_reads(int device, const nra_joint_region_t* reg, int32_t 
     b->n_q2bit_words = pr.q2bit.size();
     b->reads_have_n = pr.has_n;
     b->host_reads = std::move(pr.reads);
+    b->rev_strand.assign((size_t)n_reads, 0);
+    HIP_TRY(b->jsnap.alloc(b->n_q2bit_words * 16 * 3));    // R side of the junction per read base: kept across cell lists
+    HIP_TRY(b->jread_a.alloc((size_t)n_reads));
     rc = alloc_results(b, (size_t)n_reads, true);      // best_wscore, n_ties, sum_k, sum_k2, status, strand_out
     if (rc) return rc;
     for (int i = 0; i < 2; ++i) HIP_TRY(g_handles.event(b->device, true, &b->phase_ev[i]));
@@ -1139,6 +1146,7 @@ int nra_batch2d_set_cells(nra_batch_t* b, const int8_t* read_strand, int64_t n_c
     }
     b->have_cells = false;
     b->ran = false;
+    b->rev_pending.clear();
     b->cell_arena.reset();
     ArenaScope arena_scope(&b->cell_arena);
     b->buckets.clear();
@@ -1232,9 +1240,14 @@ int nra_batch2d_set_cells(nra_batch_t* b, const int8_t* read_strand, int64_t n_c
                 // one reverse sweep over R per read; one prefix sweep over L + u1^k1max per read that
                 // leaves the wave state at each of the read's k1 values; one tail sweep per run of cells
                 // with the same k1 and k2 in arithmetic progression (how the grid rounds list them)
-                NraJointTask tb{}; tb.read = r; tb.k2step = 1; tb.n2 = 1;
-                jbwd.push_back(tb);
-                bk.cells_sweep += sweep_cells(bk.R, d.l3);
+                const int8_t given = read_strand ? read_strand[r] : 0;
+                if (given == 0 || b->rev_strand[r] != given) {      // not made yet (or for the other strand)
+                    NraJointTask tb{}; tb.read = r; tb.k2step = 1; tb.n2 = 1;
+                    jbwd.push_back(tb);
+                    bk.cells_sweep += sweep_cells(bk.R, d.l3);
+                    b->rev_strand[r] = 0;
+                    b->rev_pending.push_back({r, given});
+                }
                 std::vector<int32_t> ks(cell_k1 + first[r], cell_k1 + first[r] + cnt[r]);
                 std::sort(ks.begin(), ks.end());
                 ks.erase(std::unique(ks.begin(), ks.end()), ks.end());
@@ -1335,8 +1348,6 @@ int nra_batch2d_set_cells(nra_batch_t* b, const int8_t* read_strand, int64_t n_c
         HIP_TRY(b->jtail_tasks.upload(jtail));
         HIP_TRY(b->jk1list.upload(k1list));
         HIP_TRY(b->jstate.alloc((size_t)state_base));
-        HIP_TRY(b->jsnap.alloc(b->n_q2bit_words * 16 * 3));
-        HIP_TRY(b->jread_a.alloc((size_t)n_reads));
     }
     HIP_TRY(b->probe_score.alloc(2 * (size_t)n_reads));
     {
@@ -1488,6 +1499,10 @@ static int run_2d(nra_batch* b)
             HIP_TRY(hipStreamWaitEvent(st, b->bdone[3 * i + 1], 0));
         }
     }
+    // the reverse sweeps enqueued above stay valid for later cell lists of this batch (given strands only:
+    // a probed strand is not known on the host)
+    for (const auto& pr2 : b->rev_pending) b->rev_strand[(size_t)pr2.first] = pr2.second;
+    b->rev_pending.clear();
     HIP_TRY(hipEventRecord(b->phase_ev[1], st));
     LAUNCH_TRY(nra_launch_select_2d(st, b->n_reads, b->cell_first.p, b->cell_cnt.p, b->cell_k1.p, b->cell_k2.p,
                                     b->cand_score.p, b->cand_tstart.p, b->best_score.p, b->sum_k.p,

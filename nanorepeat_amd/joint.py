@@ -268,19 +268,25 @@ MAX_READ_2D = 3072          # rows one wave holds (NRA_MAX_QLEN_1BLOCK): the lim
 
 def _cells_of_ranges(grid1, lo1, hi1, grid2, lo2, hi2):
     """Per read r the cells grid1[lo1[r]:hi1[r]] x grid2[lo2[r]:hi2[r]], k1-major -- the order the
-    reference's nested loops list a read's cells in -- for all reads at once: (cell_read, k1, k2)."""
+    reference's nested loops list a read's cells in -- for all reads at once: (cell_read, k1, k2).
+    Built row by row ((read, k1) pairs first, then each row's k2 run): no per-cell division."""
     n1 = np.maximum(hi1 - lo1, 0).astype(np.int64)
     n2 = np.maximum(hi2 - lo2, 0).astype(np.int64)
-    cnt = n1 * n2
-    total = int(cnt.sum())
-    cell_read = np.repeat(np.arange(len(cnt), dtype=np.int32), cnt)
-    t = np.arange(total, dtype=np.int64) - np.repeat(np.cumsum(cnt) - cnt, cnt)
-    n2r = np.repeat(n2, cnt)
-    i1 = t // np.maximum(n2r, 1)
-    i2 = t - i1 * n2r
-    k1 = grid1[np.repeat(lo1, cnt) + i1] if total else np.zeros(0, np.int64)
-    k2 = grid2[np.repeat(lo2, cnt) + i2] if total else np.zeros(0, np.int64)
-    return cell_read, k1.astype(np.int32), k2.astype(np.int32)
+    n1 = np.where(n2 > 0, n1, 0)
+    n_rows = int(n1.sum())
+    if n_rows == 0:
+        z = np.zeros(0, np.int32)
+        return z, z, z
+    row_read = np.repeat(np.arange(len(n1), dtype=np.int32), n1)
+    i1 = np.arange(n_rows, dtype=np.int64) - np.repeat(np.cumsum(n1) - n1, n1)
+    row_k1 = grid1[lo1[row_read] + i1].astype(np.int32)
+    row_n2 = n2[row_read]
+    total = int(row_n2.sum())
+    cell_read = np.repeat(row_read, row_n2)
+    k1 = np.repeat(row_k1, row_n2)
+    i2 = np.arange(total, dtype=np.int64) - np.repeat(np.cumsum(row_n2) - row_n2, row_n2)
+    k2 = grid2[np.repeat(lo2[row_read], row_n2) + i2].astype(np.int32)
+    return cell_read, k1, k2
 
 
 class GridSession:
@@ -340,15 +346,14 @@ def _score_round(session, rows, grid1, lo1, hi1, grid2, lo2, hi2, strands):
     out = session.score(cell_read, k1, k2, st_in)
     has_cells = np.zeros(n, bool)
     has_cells[cell_read] = True
-    ok = has_cells & (np.asarray(out["status"]) == _capi.READ_OK)      # nanoRepeat_joint.py:473-476
-    nt = np.asarray(out["n_ties"], np.float64)
-    for i in np.nonzero(ok)[0]:
-        name = session.names[i]
-        est.repeat1_count_dict[name] = np.float64(out["sum_k1"][i]) / nt[i]
-        est.repeat2_count_dict[name] = np.float64(out["sum_k2"][i]) / nt[i]
+    ok = np.nonzero(has_cells & (np.asarray(out["status"]) == _capi.READ_OK))[0]     # nanoRepeat_joint.py:473-476
+    nt = np.asarray(out["n_ties"], np.float64)[ok]
+    names = [session.names[i] for i in ok]
+    est.repeat1_count_dict = dict(zip(names, np.asarray(out["sum_k1"], np.float64)[ok] / nt))   # np.float64 values,
+    est.repeat2_count_dict = dict(zip(names, np.asarray(out["sum_k2"], np.float64)[ok] / nt))   # like np.mean's
     if strands is not None:
-        for i in np.nonzero(has_cells)[0]:
-            strands[session.names[i]] = int(out["read_strand"][i])
+        idx = np.nonzero(has_cells)[0]
+        strands.update(zip((session.names[i] for i in idx), np.asarray(out["read_strand"])[idx].tolist()))
     return est
 
 

@@ -329,6 +329,42 @@ def test_large_row_counts_park_the_junction_in_agprs(capi, oracle):
             assert np.array_equal(g[k], o[k]), (flags, k, g[k][:8], o[k][:8])
 
 
+def test_joint_resident_reads_across_cell_lists(capi, oracle):
+    """nra_batch2d_create_reads + set_cells: several cell lists on one resident batch (the two grid rounds).
+    The reverse sweeps of a read are made once per strand and reused by later lists; every list's results
+    equal the one-shot call's and the oracle's, also after a strand changes or is left to the probe."""
+    j = synth.make_joint(10, alleles=((9, 5), (14, 3)), read_len=520, read_sd=30, anchor=300, seed=73)
+    n = len(j["reads"])
+
+    def cells(step, shift):
+        cr, k1, k2 = [], [], []
+        for r in range(n):
+            if (r + shift) % 4 == 3:
+                continue                                   # some reads sit a list out
+            for a in range(max(0, int(j["truth"][r][0]) - 4 + shift), int(j["truth"][r][0]) + 5, step):
+                for b in range(max(0, int(j["truth"][r][1]) - 2), int(j["truth"][r][1]) + 3, step):
+                    cr.append(r); k1.append(a); k2.append(b)
+        return cr, k1, k2
+
+    true_strand = j["strand"].astype(np.int8)
+    flipped = true_strand.copy(); flipped[[1, 4]] *= -1
+    with capi.Batch.create_2d_reads(j["region"], j["reads"]) as b:
+        for step, shift, strands in ((2, 0, true_strand), (1, 1, true_strand), (1, 0, flipped), (1, 2, None),
+                                     (2, 1, true_strand)):
+            cr, k1, k2 = cells(step, shift)
+            b.set_cells(cr, k1, k2, strands)
+            b.run(); b.sync()
+            g = b.fetch()
+            o = oracle.joint_2d(j["region"], j["reads"], cr, k1, k2, read_strand=strands)
+            one = capi.joint_2d(j["region"], j["reads"], cr, k1, k2, read_strand=strands)
+            has = np.zeros(n, bool); has[cr] = True
+            for key in o:
+                per_read = len(o[key]) == n
+                sel = has if per_read else slice(None)
+                assert np.array_equal(np.asarray(g[key])[sel], np.asarray(o[key])[sel]), (step, shift, key)
+                assert np.array_equal(np.asarray(one[key])[sel], np.asarray(o[key])[sel]), (step, shift, key)
+
+
 def test_long_joint_reads_uncut_equal_oracle(capi, oracle):
     """Joint reads of 5 kb (beyond one register block) are scored uncut, cell by cell in chained row
     blocks with int64 cells; strands probed (0) or given; short reads of the same batch take the sweeps."""
