@@ -361,6 +361,7 @@ def bench_joint(args):
     last = {}
 
     def step():
+        session.new_run()       # every step is a whole run: round 2 makes the reverse sweeps, round 3 reuses them
         last["est"] = J.fine_tune_read_count(init, fq, chrom, copy.copy(a), copy.copy(b), device=local_rank, session=session)
 
     dt = timed_steps(args, dist, step, on_warm=lambda: setattr(session, "rounds", []))

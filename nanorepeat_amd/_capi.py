@@ -22,7 +22,7 @@ F_DPP_SWEEP = 16      # testing / comparison: k_sweep_pk16 instead of k_sweep_ri
 # every symbol include/nanorepeat_amd.h declares
 EXPORTS = ("nra_abi_version", "nra_version", "nra_last_error", "nra_device_count",
            "nra_default_scoring", "nra_round3_1d", "nra_joint_2d", "nra_align_pairs", "nra_align_pairs_cigar", "nra_batch1d_create",
-           "nra_batch2d_create", "nra_batch2d_create_reads", "nra_batch2d_set_cells", "nra_batch_run", "nra_batch_sync", "nra_batch_stats",
+           "nra_batch2d_create", "nra_batch2d_create_reads", "nra_batch2d_set_cells", "nra_batch2d_invalidate", "nra_batch_run", "nra_batch_sync", "nra_batch_stats",
            "nra_batch1d_fetch", "nra_batch2d_fetch", "nra_batch_destroy")
 
 
@@ -113,7 +113,7 @@ def load():
                                              C.POINTER(Scoring), C.c_int32, C.POINTER(vp)]
     lib.nra_batch2d_set_cells.restype = C.c_int
     lib.nra_batch2d_set_cells.argtypes = [vp, pi8, C.c_int64, pi32, pi32, pi32]
-    for f in (lib.nra_batch_run, lib.nra_batch_sync):
+    for f in (lib.nra_batch_run, lib.nra_batch_sync, lib.nra_batch2d_invalidate):
         f.restype = C.c_int
         f.argtypes = [vp]
     lib.nra_batch_stats.restype = C.c_int
@@ -395,6 +395,10 @@ class Batch:
         _check(load().nra_batch2d_set_cells(self._h, _ptr(st, C.c_int8), len(cr), _ptr(cr, C.c_int32),
                                             _ptr(k1, C.c_int32), _ptr(k2, C.c_int32)))
         self.n_cand = len(cr)
+
+    def invalidate(self):
+        """Drop what earlier cell lists left for later ones (reverse sweeps): the next list starts like the first."""
+        _check(load().nra_batch2d_invalidate(self._h))
 
     def run(self):
         _check(load().nra_batch_run(self._h))

@@ -1384,6 +1384,14 @@ int nra_batch2d_set_cells(nra_batch_t* b, const int8_t* read_strand, int64_t n_c
 }
 
 
+// Forget what earlier cell lists left for later ones (the reverse sweeps): the next list starts like the first.
+int nra_batch2d_invalidate(nra_batch_t* b)
+{
+    if (!b || b->kind != 2) return fail(NRA_E_ARG, "not a 2D batch");
+    std::fill(b->rev_strand.begin(), b->rev_strand.end(), (int8_t)0);
+    return NRA_OK;
+}
+
 int nra_batch2d_create(int device, const nra_joint_region_t* reg, int32_t n_reads, const char* seqs,
                        const int64_t* seq_off, const int8_t* read_strand, int64_t n_cells,
                        const int32_t* cell_read, const int32_t* cell_k1, const int32_t* cell_k2,

@@ -316,6 +316,11 @@ class GridSession:
             self.rounds.append((len(cell_read), self.batch.stats()))
         return self.batch.fetch(per_candidate=False)
 
+    def new_run(self):
+        """The grid rounds are about to start over on these reads: nothing of an earlier run is reused."""
+        if self.batch is not None:
+            self.batch.invalidate()
+
     def close(self):
         if self.batch is not None:
             self.batch.close()
