@@ -203,8 +203,8 @@ def init_dist(args):
     return rank, local_rank, world, dist
 
 
-def timed_steps(args, dist, step, on_warm=None):
-    """W warm-up steps, then exactly K steps between barrier + synchronize; max over ranks."""
+def timed_steps(args, dist, step, on_warm=None, on_done=None):
+    """W warm-up steps, then exactly K steps (+ on_done, still inside) between barrier + synchronize; max over ranks."""
     import torch
 
     def barrier():
@@ -220,6 +220,8 @@ def timed_steps(args, dist, step, on_warm=None):
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
+    if on_done is not None:
+        on_done()
     barrier()
     dt = time.perf_counter() - t0
     if dist is not None:
@@ -265,12 +267,21 @@ def bench_1d(args):
                           index, n_total, flags=A.F_BRUTE_FORCE if args.brute else 0, device=local_rank)
     last = {}
 
+    # One step = one pass over the rank's shard: kernels -> on-device selection -> D2H of the per-read results
+    # -> (N > 1) the all_gather.  The exchange of pass i runs on the host / RCCL while the kernels of pass
+    # i + 1 execute; the last one is exposed before the closing barrier.  N = 1: nothing to overlap.
     def step():
         sb.run()
-        last["out"] = sb.gather()       # device selection -> D2H of the per-read results -> all_gather (N > 1)
+        if "pending" in last:
+            last["out"] = sb.exchange(last.pop("pending"))
+        last["pending"] = sb.fetch_local()
+
+    def drain():
+        if "pending" in last:
+            last["out"] = sb.exchange(last.pop("pending"))
 
     warm = {}
-    dt = timed_steps(args, dist, step, on_warm=lambda: warm.update(sb.stats()))
+    dt = timed_steps(args, dist, step, on_warm=lambda: (drain(), warm.update(sb.stats())), on_done=drain)
     st = sb.stats()
     out = last["out"]
     n_align = n_align_local
@@ -297,7 +308,8 @@ def bench_1d(args):
                        "mode": "brute force (K independent alignments)" if args.brute else
                                "junction decomposition (exact; shares L+unit^k and R across k)",
                        "timed_region": "inputs resident in HBM; kernels + on-device selection + D2H of per-read "
-                                       "results" + (" + all_gather" if world > 1 else ""),
+                                       "results" + (" + all_gather (pass i's exchange overlaps pass i+1's kernels; the last "
+                                                    "one is exposed)" if world > 1 else ""),
                        "parallelism": f"region blocks sharded over {world} GPU(s), no data-path collective, one all_gather of 32 B/read"},
             "roofline": roofline(warm, st, args.steps, args.brute, kern),
             "extent_tasks_per_step": st["n_extent_tasks"],

@@ -1158,6 +1158,7 @@ int nra_batch2d_set_cells(nra_batch_t* b, const int8_t* read_strand, int64_t n_c
     (void)sc;
     std::vector<NraDevRead> reads(b->host_reads);              // + the shadows of chained reads, below
     int rc = NRA_OK;
+    PhaseClock clk;
 
     std::vector<uint32_t> first((size_t)n_reads, 0), cnt((size_t)n_reads, 0);
     int32_t k1max = 0, k2max = 0;
@@ -1178,6 +1179,7 @@ int nra_batch2d_set_cells(nra_batch_t* b, const int8_t* read_strand, int64_t n_c
     const int64_t tlmax = (int64_t)left_len + win - 20 + right_len;
     if (tlmax > NRA_MAX_TLEN) return fail(NRA_E_RANGE, "template too long");
 
+    clk.mark("2D cells: first/count");
     std::vector<uint8_t> pool;
     bool has_n = b->reads_have_n;
     NraDevRegion d{};
@@ -1324,6 +1326,7 @@ int nra_batch2d_set_cells(nra_batch_t* b, const int8_t* read_strand, int64_t n_c
     }
     const size_t nb = b->buckets.size();
 
+    clk.mark("2D cells: buckets, tasks");
     // one chunk for everything but the wave states, which get their own (all of it reused by the next cell list)
     b->cell_arena.expect(b->n_q2bit_words * 16 * 13 + (size_t)n_cells * 20 + pool.size() + (size_t)n_reads * 128 +
                          (jbwd.size() + jpre.size() + jtail.size()) * sizeof(NraJointTask) + k1list.size() * 4 +
@@ -1363,6 +1366,7 @@ int nra_batch2d_set_cells(nra_batch_t* b, const int8_t* read_strand, int64_t n_c
     }
     HIP_TRY(b->cand_score.alloc((size_t)n_cells));     // cell_score
     HIP_TRY(b->cand_tstart.alloc((size_t)n_cells));    // cell_wscore
+    clk.mark("2D cells: device buffers, H2D");
     // events and streams: kept from one cell list to the next, more taken from the pool when needed
     {
         const size_t n_ev = 2 + 6 * nb + 4 * b->jgroups.size() + 2;

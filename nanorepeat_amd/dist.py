@@ -171,20 +171,25 @@ class ShardedBatch1D:
             except Exception as e:
                 self.error = e
 
-    def gather(self):
-        """-> dict(best_score, sum_k, n_ties, status) for all n_total reads, on every rank."""
+    def fetch_local(self):
+        """Wait for this rank's kernels and fetch its per-read results (host arrays; None after an error)."""
+        if self.error is None:
+            try:
+                self.batch.sync()
+                return self.batch.fetch(per_candidate=False)
+            except Exception as e:
+                self.error = e
+        return None
+
+    def exchange(self, local):
+        """The one exchange step: `local` (fetch_local's result) of every rank -> dict(best_score, sum_k,
+        n_ties, status) for all n_total reads, on every rank.  Independent of the batch's streams, so a
+        caller may run it while the next pass's kernels execute."""
         import torch
         import torch.distributed as dist
         n_local = len(self.index)
         rows = np.full((self.cap + 1, 4), -1, np.int64)
-        local = None
-        if self.error is None:
-            try:
-                self.batch.sync()
-                local = self.batch.fetch(per_candidate=False)
-            except Exception as e:
-                self.error = e
-        rows[0] = (n_local, 0 if self.error is None else 1, 0, 0)
+        rows[0] = (n_local, 0 if self.error is None and (local is not None or n_local == 0) else 1, 0, 0)
         if local is not None and n_local:
             rows[1:n_local + 1, 0] = self.index
             rows[1:n_local + 1, 1] = local["best_score"]
@@ -195,7 +200,7 @@ class ShardedBatch1D:
         else:
             buf = torch.from_numpy(rows).to(self._dev)
             gathered = [torch.empty_like(buf) for _ in range(self.world)]
-            dist.all_gather(gathered, buf, group=self.group)      # the one exchange step, un-chunked
+            dist.all_gather(gathered, buf, group=self.group)      # un-chunked: 32 B per read
             parts = [g.cpu().numpy() for g in gathered]
         failed = [r for r, p in enumerate(parts) if p[0, 1] != 0]
         if failed:
@@ -211,6 +216,10 @@ class ShardedBatch1D:
             out["n_ties"][idx] = p[1:k + 1, 3] >> 8
             out["status"][idx] = p[1:k + 1, 3] & 0xff
         return out
+
+    def gather(self):
+        """fetch_local + exchange: per-read results of ALL ranks on every rank."""
+        return self.exchange(self.fetch_local())
 
     def stats(self):
         return self.batch.stats()
