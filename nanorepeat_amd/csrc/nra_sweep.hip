@@ -516,12 +516,13 @@ __global__ __launch_bounds__(WAVE * SWEEP_RING_WPB) void k_sweep_ring(int n_task
     constexpr int SC = 2;                 // origin-bit scheme: doubled scores
     __shared__ int4 ring_all[SWEEP_RING_WPB * SWEEP_RING_D * 64];
     __shared__ int2 racc_all[SWEEP_RING_WPB * 64];
-    const int wave_in_block = threadIdx.x >> 6;
+    // (with one wave per block everything below is a constant: LDS addresses stay immediates)
+    const int wave_in_block = SWEEP_RING_WPB > 1 ? (int)(threadIdx.x >> 6) : 0;
     int4* ring = ring_all + wave_in_block * SWEEP_RING_D * 64;
     int2* racc = racc_all + wave_in_block * 64;
     const int task = blockIdx.x * SWEEP_RING_WPB + wave_in_block;
     if (task >= n_tasks) return;
-    const int lane = threadIdx.x & 63;
+    const int lane = SWEEP_RING_WPB > 1 ? (int)(threadIdx.x & 63) : (int)threadIdx.x;
     const NraSweepTask tk = tasks[task];
     const bool has_b = tk.read_b >= 0;
     const int ra = tk.read_a, rb = has_b ? tk.read_b : tk.read_a;
