@@ -169,3 +169,38 @@ def test_pipeline_with_a_long_expansion_gpu_equals_oracle(capi, oracle):
     assert out["gpu"] == out["cpu"]
     sizes = [out["gpu"][f"x{i}"][1] for i in range(4)]
     assert abs(sizes[0] - 30) <= 1 and abs(sizes[1] - 1150) <= 12 and abs(sizes[3] - 1148) <= 12, sizes   # ~1 % indel noise
+
+
+@pytest.mark.gpu
+def test_pipeline_70kb_read_and_9kb_core_in_a_multi_region_batch(capi, oracle):
+    """whole-genome ONT reads over 65 kb and cores over 8 kb are routine and must not abort a
+    batch.  Region 0 holds a 70 kb read (the anchors' DP target: int64 extents), region 1 a read whose
+    core is 9.2 kb (round 2: chained pair alignment; round 3: chained int32 sweeps with the reference's
+    window for r2 = 1800, K = 181); both regions also hold ordinary reads.  GPU == oracle, nothing skipped."""
+    rng = np.random.default_rng(131)
+    regions, reads_by_region = [], []
+    for g, unit in enumerate(("CAG", "TATTG")):
+        left, right = synth.rand_seq(rng, 600), synth.rand_seq(rng, 600)
+        rr = R3.RepeatRegion(f"chrW\t{3000 * g + 600}\t{3000 * g + 660}\t{unit}")
+        rr.left_anchor_seq, rr.right_anchor_seq, rr.left_anchor_len, rr.right_anchor_len = left, right, 600, 600
+        reads = {f"g{g}r{i}": synth.apply_errors(rng, left[-400:] + unit * (11 + 7 * (i % 2)) + right[:400], "ont_q20")
+                 for i in range(4)}
+        if g == 0:
+            body = left + unit * 25 + right
+            reads["long70k"] = synth.rand_seq(rng, 41000) + synth.apply_errors(rng, body, "ont_q20") + synth.rand_seq(rng, 28000)
+        else:
+            reads["core9k"] = synth.apply_errors(rng, left[-500:] + unit * 1800 + right[:500], "hifi")
+        regions.append(rr); reads_by_region.append(reads)
+    assert len(reads_by_region[0]["long70k"]) > 70000
+    import copy
+    out = {}
+    for name, kw in (("gpu", {}), ("cpu", dict(aligner=oracle.align_pairs, scorer=oracle.round3_1d))):
+        test = copy.deepcopy(regions)
+        pipeline.quantify_regions(test, reads_by_region, "ont_q20", **kw)
+        out[name] = [{n: (r.strand, r.core_seq_start_pos, r.core_seq_end_pos, r.round2_repeat_size, r.round3_repeat_size,
+                          r.round3_status) for n, r in rr.read_dict.items()} for rr in test]
+        assert not any(getattr(rr, "skipped_reads", None) for rr in test)
+    assert out["gpu"] == out["cpu"]
+    long_read, core = out["gpu"][0]["long70k"], out["gpu"][1]["core9k"]
+    assert long_read[1] > 40000 and abs(long_read[4] - 25) <= 1                # placed beyond 16-bit extents, sized
+    assert core[2] - core[1] > 9000 and abs(core[4] - 1800) <= 20
