@@ -254,7 +254,7 @@ def bench_1d(args):
         # computed from the region descriptors alone, and every rank materialises only its own reads
         cost = np.array([synth.config4_region_cost(synth.config4_region(g), args.reads_per_region)
                          for g in range(args.regions)], np.int64)
-        owner = D._lpt(cost, world)
+        owner = D.lpt_assign(cost, world)
         data = synth.config4(args.regions, args.reads_per_region, only=np.nonzero(owner == rank)[0])
         index = data["read_id"]
         n_total = args.regions * args.reads_per_region

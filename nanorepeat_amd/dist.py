@@ -56,7 +56,7 @@ def estimate_cells(regions, reads, kmin, kmax, read_region=None):
     return q * sum_t
 
 
-def _lpt(cost, world):
+def lpt_assign(cost, world):
     """Longest-processing-time assignment of a few thousand items at most (heap)."""
     owner = np.zeros(len(cost), np.int32)
     heap = [(0, r) for r in range(world)]
@@ -87,7 +87,7 @@ def shard_region_blocks(cost, read_region, world, blocks_per_rank=8):
     blk_in_region = (cs - region_start) // target
     new_blk = first | np.r_[False, blk_in_region[1:] != blk_in_region[:-1]]
     blk = np.cumsum(new_blk) - 1
-    blk_owner = _lpt(np.bincount(blk, weights=c).astype(np.int64), world)
+    blk_owner = lpt_assign(np.bincount(blk, weights=c).astype(np.int64), world)
     owner = np.empty(n, np.int32)
     owner[order] = blk_owner[blk]
     return owner

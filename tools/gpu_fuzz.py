@@ -113,6 +113,31 @@ def fuzz_1d_multi(rng):
     return None
 
 
+def fuzz_pairs(rng):
+    """nra_align_pairs across its launch groups: short and chained queries, int32 and int64 cells (a target
+    beyond 65000 columns), N bases, empty sequences."""
+    seqs, pq, pt = [], [], []
+    n = int(rng.integers(1, 6))
+    for i in range(n):
+        tl = int(rng.choice([0, 30, 400, 3000, 9000] + ([66000] if rng.random() < 0.15 else [])))
+        t = synth.rand_seq(rng, tl)
+        a = int(rng.integers(0, max(1, tl - 20)))
+        ql = int(rng.choice([0, 25, 300, 1200] + ([3300] if rng.random() < 0.2 else [])))
+        q = synth.apply_errors(rng, t[a:a + ql] if tl else synth.rand_seq(rng, ql), ["hifi", "ont"][int(rng.integers(0, 2))])
+        if rng.random() < 0.3: q = synth.revcomp(q)
+        seqs += [mangle(rng, t) if tl < 5000 else t, mangle(rng, q)]
+        pq.append(2 * i + 1); pt.append(2 * i)
+        if i and rng.random() < 0.5:
+            pq.append(2 * i + 1); pt.append(2 * int(rng.integers(0, i)))
+    sc = rand_scoring(rng)
+    o = O.align_pairs(seqs, pq, pt, sc=O.default_scoring(**sc))
+    g = A.align_pairs(seqs, pq, pt, sc=A.default_scoring(**sc))
+    for k in ("score", "tstart", "tend"):
+        if not np.array_equal(g[k], o[k]):
+            return dict(kind="pairs", key=k, lens=[len(x) for x in seqs], pq=pq, pt=pt, sc=sc, got=g[k].tolist(), want=o[k].tolist())
+    return None
+
+
 def fuzz_2d(rng):
     u1 = synth.rand_unit(rng, int(rng.integers(1, 6))); u2 = synth.rand_unit(rng, int(rng.integers(1, 6)))
     L = synth.rand_seq(rng, int(rng.choice([1, 3, 9, 10, 11, 60, 300]))); R = synth.rand_seq(rng, int(rng.choice([1, 2, 3, 9, 10, 11, 60, 300])))
@@ -122,6 +147,8 @@ def fuzz_2d(rng):
         a, b = int(rng.integers(0, 25)), int(rng.integers(0, 15))
         fl, fr = int(rng.integers(0, len(L) + 1)), int(rng.integers(0, len(R) + 1))
         s = synth.apply_errors(rng, L[len(L) - fl:] + u1 * a + mid + u2 * b + R[:fr], ["hifi", "ont"][int(rng.integers(0, 2))])
+        if rng.random() < 0.04:      # a read beyond one register block: scored cell by cell in chained int64 blocks
+            s = synth.rand_seq(rng, int(rng.integers(1500, 2200))) + s + synth.rand_seq(rng, int(rng.integers(1500, 2200)))
         if rng.random() < 0.4: s = synth.revcomp(s)
         reads.append(mangle(rng, s))
         s1, s2 = int(rng.integers(1, 4)), int(rng.integers(1, 4))
@@ -148,7 +175,7 @@ if __name__ == "__main__":
     rng = np.random.default_rng(seed)
     t0 = time.time(); bad = 0
     for i in range(rounds):
-        for f in (fuzz_1d, fuzz_1d_multi, fuzz_2d):
+        for f in (fuzz_1d, fuzz_1d_multi, fuzz_2d, fuzz_pairs):
             r = f(rng)
             if r is not None:
                 bad += 1
