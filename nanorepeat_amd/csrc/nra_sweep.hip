@@ -12,37 +12,32 @@
 // node column; a gap spanning the junction is handled per gap piece by refunding one open).
 // Both sweeps are ONE alignment-sized DP per read instead of K:
 //
-//   reverse sweep (DIR 0): reversed read vs  rev(R) + rev(unit)^kmax.  At the last column
-//     of rev(R) every lane stores H, E_in, E2_in of its rows (the "R side" of the junction:
-//     best paths starting at node (i, R[0]) -- closed, or inside a piece-1 / piece-2 gap).
-//     At every unit boundary lenR + m*k - 1 the running maximum over all cells so far is A_k.
+//   reverse sweep (DIR 0): reversed read vs rev(R).  At its last column every lane stores H, E_in,
+//     E2_in of its rows (the "R side" of the junction: best paths starting at node (i, R[0]) --
+//     closed, or inside a piece-1 / piece-2 gap); the maximum over all its cells is A = the best
+//     score entirely inside R.
 //   forward sweep (DIR 1): read vs L + unit^kmax.  At every unit boundary L + m*k - 1 each
 //     row combines its three states with the stored R side:
-//        max(H,0) + Hb,   E_in + Eb_in + q,   E2_in + E2b_in + q2        -> S_k
+//        H + Hb,   E_in + Eb_in + q,   E2_in + E2b_in + q2        -> S_k
 //     and the running maximum gives B_k.
 //
-// Per-column results travel with the column through the lanes (DPP wave_shr:1, like the
-// DP hand-off), so lane 63 holds the wave-wide value of a boundary column when it finishes
-// it and writes Score(k) and the flank-test verdict:
-//   left  flank (tstart < |L|)      passes  iff A_k < Score   (oracle: largest tstart wins)
-//   right flank (tend > |L|+m*k)    passes  if  B_k < Score;  fails if B_k == Score > S_k;
-//                                   B_k == S_k == Score is ambiguous -> explicit extents DP.
-//
-// Reads that fit one register block (<= 3072 bases, CHAIN = false) do not sweep rev(unit)^kmax at
-// all.  A_k is only needed to know whether an optimal alignment STARTS at a column >= |L|, and
-// that is one bit of payload: all scores are doubled and the low bit of a state says "the best
+// The origin bit.  A_k is only needed to know whether an optimal alignment STARTS at a column >= |L|,
+// and that is one bit of payload: all scores are doubled and the low bit of a state says "the best
 // path into this state (largest bit among co-optimal ones) starts at column >= |L|".  An
 // alignment starting at column j enters through max(H(i-1,j-1), 0): the 0 becomes 0|1 for
 // j >= |L| (a flag travelling with the template column), every other operation adds even
 // numbers, and max() on 2*score+bit is the lexicographic max.  So the forward sweep alone
-// yields (Score, bit) of S_k and B_k, the reverse sweep shrinks to rev(R) -- it leaves the R
-// side of the junction and A = best score entirely inside R (bit 1) -- and
-//   left flank passes  iff  bit of max(S_k, B_k, 2A+1) is 0.
-// 4q+1 must fit the int16 half: chained reads (up to 8000 bases) keep the A_k sweep.
+// yields (Score, bit) of S_k and B_k, the reverse sweep never needs rev(unit)^kmax, and
+//   left  flank (tstart < |L|)    passes  iff  the bit of V = max(S_k, B_k, 2A+1) is 0
+//                                              (oracle: the largest tstart among co-optimal paths wins)
+//   right flank (tend > |L|+m*k)  passes  if  B_k < Score;  fails if B_k == Score > S_k;
+//                                 B_k == S_k == Score is ambiguous -> explicit extents DP.
 //
-// The two int16 halves of every VGPR hold two READS of the same region (paired by length
-// on the host); the template base is shared.  Inner loop = k_score_pk16's, with E updated
-// lazily (E_in of the current column stays in the register, which the combine needs).
+// Two kernels run these sweeps: k_sweep_ring (reads <= 3072 bases, unit <= 8 bases: two reads per wave
+// in the int16 halves of every VGPR, lane-to-lane hand-off through an LDS ring, the combine on every
+// m-th step) and k_sweep_pk16 (DPP hand-off: longer units; and -- CHAIN -- reads of any length as
+// chained row blocks in int32 cells, one read per wave).  E is updated lazily in both (E_in of the
+// current column stays in the register, which the combine needs).
 #include "nra_device.h"
 
 #ifndef NRA_PART
