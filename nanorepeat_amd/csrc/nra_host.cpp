@@ -274,6 +274,10 @@ struct JointGroup {
 struct Bucket {
     int R = 0;
     bool chain = false;        // reads longer than one register block: chained row blocks
+    bool wide = false;         // chained: int32 cells, one read per wave (else packed int16, two reads per wave)
+    int payload_R = 0;         // chained: row block of the extents kernel (NRA_CHAIN_R / NRA_CHAIN_R_TEST)
+    size_t strip_off = 0;      // chained: this bucket's scratch strips in chain_sweep (int32 index)
+    int n_strips = 0;
     int n_pair = 0;            // pk16 tasks (1D score / 2D strand probe)
     size_t pair_off = 0;       // offset into pair_tasks
     int n_queue = 0;           // payload tasks prebuilt on the host (ALL_EXTENTS / 2D cells)
@@ -758,34 +762,57 @@ int nra_batch1d_create(int device, const nra_region_t* regions, int32_t n_region
     b->brute = brute;
     std::vector<NraSweepTask> sweep_tasks;
     uint64_t snap_total = 0;
-    // bucket kNumR = the chained reads (every read with NRA_F_TEST_CHAIN)
-    std::vector<std::vector<int32_t>> by_bucket((size_t)kNumR + 1);
+    // the chained reads (every read with NRA_F_TEST_CHAIN): bucket kNumR = int32 cells, one read per wave;
+    // bucket kNumR + 1 = packed int16, two reads per wave -- doubled scores up to 16000 (reads of up to 4000
+    // bases with the default scoring) in the LDS-ring kernels, which hold units of up to NRA_SWEEP_RING_MAX_M
+    std::vector<std::vector<int32_t>> by_bucket((size_t)kNumR + 2);
     int chain_cols = 0;
     for (int32_t r = 0; r < n_reads; ++r) {
         if (kmin[r] > kmax[r] || pr.reads[r].qlen == 0) continue;
-        int bi = chained[r] ? kNumR : rows_for_qlen(pr.reads[r].qlen);
-        read_bucket[r] = bi;
-        by_bucket[bi].push_back(r);
-        if (bi == kNumR) {
+        int bi = rows_for_qlen(pr.reads[r].qlen);
+        if (chained[r]) {
             const nra_region_t& rg = regions[pr.reads[r].region];
+            const bool packed = max_score(sc, pr.reads[r].qlen) <= kScoreCapBit && rg.unit_len <= NRA_SWEEP_RING_MAX_M &&
+                                (flags & NRA_F_DPP_SWEEP) == 0;
+            bi = packed ? kNumR + 1 : kNumR;
             chain_cols = std::max(chain_cols, rg.left_len + rg.unit_len * kmax[r] + rg.right_len);
         }
+        read_bucket[r] = bi;
+        by_bucket[bi].push_back(r);
     }
-    if (!by_bucket[kNumR].empty() && brute)
+    if ((!by_bucket[kNumR].empty() || !by_bucket[kNumR + 1].empty()) && brute)
         return fail(NRA_E_RANGE, "NRA_F_TEST_CHAIN needs the junction decomposition (no brute force / ALL_EXTENTS, flanks >= 1)");
     b->chain_cap = (chain_cols + 127) / 64 * 64 + 64;
-    fold_small_buckets(by_bucket, 1024, 2);    // wider folding (up to 16384 reads / 4 rows) changes nothing in 1D
+    {
+        std::vector<int32_t> cw(std::move(by_bucket[kNumR])), cp(std::move(by_bucket[kNumR + 1]));
+        by_bucket[kNumR].clear(); by_bucket[kNumR + 1].clear();
+        fold_small_buckets(by_bucket, 1024, 2);    // wider folding (up to 16384 reads / 4 rows) changes nothing in 1D
+        by_bucket[kNumR] = std::move(cw); by_bucket[kNumR + 1] = std::move(cp);
+    }
+    size_t strip_total = 0;
     std::vector<NraPairTask> pair_tasks;
     std::vector<NraTask> queue_tasks;       // ALL_EXTENTS only; otherwise just capacity
     std::vector<int32_t> queue_count;
     std::vector<uint32_t> task_base;
     size_t queue_total = 0;
     int64_t alg_cells = 0;
-    for (int bi = kNumR; bi >= 0; --bi) {           // longest reads first
+    const int bucket_order_first = kNumR + 1;
+    for (int bi0 = bucket_order_first; bi0 >= 0; --bi0) {           // longest reads first: int32 chain, packed chain, R = 48 ...
+        const int bi = bi0 == kNumR + 1 ? kNumR : (bi0 == kNumR ? kNumR + 1 : bi0);
         if (by_bucket[bi].empty()) continue;
         Bucket bk;
-        bk.chain = bi == kNumR;
-        bk.R = bk.chain ? (test_chain ? NRA_CHAIN_R_TEST : NRA_CHAIN_R) : kRList[bi];
+        bk.chain = bi >= kNumR;
+        bk.wide = bi == kNumR;
+        if (bk.chain) {
+            // LDS-ring chain unless a unit is too long for the ring (then the DPP chain, int32 only)
+            bk.ring = (flags & NRA_F_DPP_SWEEP) == 0;
+            for (int32_t r : by_bucket[bi])
+                if (regions[pr.reads[r].region].unit_len > NRA_SWEEP_RING_MAX_M) bk.ring = false;
+            bk.payload_R = test_chain ? NRA_CHAIN_R_TEST : NRA_CHAIN_R;
+            bk.R = test_chain ? NRA_CHAIN_R_TEST : (bk.ring ? NRA_RING_CHAIN_R : NRA_CHAIN_R);
+        } else {
+            bk.R = kRList[bi];
+        }
         bk.pair_off = pair_tasks.size();
         bk.queue_off = queue_total;
         for (int32_t r : by_bucket[bi]) {
@@ -825,16 +852,18 @@ int nra_batch1d_create(int device, const nra_region_t* regions, int32_t n_region
             });
             bk.sweep_off = sweep_tasks.size();
             // the LDS-ring sweeps hold unit lengths up to NRA_SWEEP_RING_MAX_M; a bucket with a longer unit
-            // (and chained reads) keeps the DPP sweeps
-            bk.ring = !bk.chain && (flags & NRA_F_DPP_SWEEP) == 0;
-            for (int32_t r : order)
-                if (dregs[pr.reads[r].region].m1 > NRA_SWEEP_RING_MAX_M) bk.ring = false;
+            // keeps the DPP sweeps
+            if (!bk.chain) {
+                bk.ring = (flags & NRA_F_DPP_SWEEP) == 0;
+                for (int32_t r : order)
+                    if (dregs[pr.reads[r].region].m1 > NRA_SWEEP_RING_MAX_M) bk.ring = false;
+            }
             for (size_t i = 0; i < order.size();) {
                 NraSweepTask t{};
                 t.read_a = order[i]; t.read_b = -1;
                 t.kmin = kmin[t.read_a]; t.kmax = kmax[t.read_a];
-                // (the chained sweeps take one read per wave)
-                if (!bk.chain && i + 1 < order.size() && pr.reads[order[i + 1]].region == pr.reads[order[i]].region) {
+                // (the int32 chained sweeps take one read per wave)
+                if (!bk.wide && i + 1 < order.size() && pr.reads[order[i + 1]].region == pr.reads[order[i]].region) {
                     t.read_b = order[i + 1];
                     t.kmin = std::min(t.kmin, kmin[t.read_b]);
                     t.kmax = std::max(t.kmax, kmax[t.read_b]);
@@ -846,17 +875,22 @@ int nra_batch1d_create(int device, const nra_region_t* regions, int32_t n_region
                 int qmax = pr.reads[t.read_a].qlen;
                 if (t.read_b >= 0) qmax = std::max(qmax, pr.reads[t.read_b].qlen);
                 const int nblk = bk.chain ? (qmax + 64 * bk.R - 1) / (64 * bk.R) : 1;
-                // chained reads sweep rev(unit)^kmax for A_k; the others stop at the end of rev(R)
-                if (bk.ring)    // pipelines 64*m (forward) and 64 (reverse) columns deep
-                    bk.cells_sweep += 2 * (int64_t)64 * bk.R * ((d.l1 + d.m1 * t.kmax + 63 * d.m1) + (d.l3 + 63));
+                if (bk.ring)    // pipelines 64*m (forward) and 64 (reverse) columns deep, per row block
+                    bk.cells_sweep += (int64_t)nblk * (bk.wide ? 1 : 2) * 64 * bk.R *
+                                      ((d.l1 + d.m1 * t.kmax + 63 * d.m1) + (d.l3 + 63));
                 else
-                    bk.cells_sweep += (int64_t)nblk * (bk.chain ? 1 : 2) * (sweep128_cells(bk.R, d.l1 + d.m1 * t.kmax) +
-                                                                            sweep128_cells(bk.R, d.l3));
+                    bk.cells_sweep += (int64_t)nblk * (bk.wide ? 1 : 2) * (sweep128_cells(bk.R, d.l1 + d.m1 * t.kmax) +
+                                                                           sweep128_cells(bk.R, d.l3));
                 t.snap_off = snap_total;
                 snap_total += (uint64_t)nblk * 3 * bk.R * 64;
                 sweep_tasks.push_back(t);
             }
             bk.n_sweep = (int)(sweep_tasks.size() - bk.sweep_off);
+            if (bk.chain) {
+                bk.n_strips = std::min(bk.n_sweep, bk.ring ? NRA_RING_CHAIN_STRIPS : NRA_CHAIN_STRIPS);
+                bk.strip_off = strip_total;
+                strip_total += (size_t)bk.n_strips * 10 * (size_t)b->chain_cap;
+            }
         }
         bk.n_pair = (int)(pair_tasks.size() - bk.pair_off);
         bk.n_queue = all_ext ? (int)bk.queue_cap : 0;
@@ -883,10 +917,9 @@ int nra_batch1d_create(int device, const nra_region_t* regions, int32_t n_region
         HIP_TRY(b->read_a1d.alloc((size_t)n_reads));
     }
     HIP_TRY(b->cand_flag.alloc((size_t)total));
-    for (const Bucket& bk : b->buckets) {
-        if (!bk.chain) continue;
-        HIP_TRY(b->chain_sweep.alloc((size_t)std::min(bk.n_sweep, NRA_CHAIN_STRIPS) * 10 * (size_t)b->chain_cap));
-        HIP_TRY(b->chain_payload.alloc(std::min<size_t>(bk.queue_cap, NRA_CHAIN_STRIPS) * 6 * (size_t)b->chain_cap));
+    if (strip_total) {
+        HIP_TRY(b->chain_sweep.alloc(strip_total));
+        HIP_TRY(b->chain_payload.alloc((size_t)NRA_CHAIN_STRIPS * 6 * (size_t)b->chain_cap));   // the buckets' extents launches run in turn
     }
     if (all_ext) HIP_TRY(b->queue_tasks.upload(queue_tasks));
     else HIP_TRY(b->queue_tasks.alloc(queue_total));
@@ -954,7 +987,13 @@ static int run_1d(nra_batch* b)
             hipStream_t q = b->bstreams[i];
             HIP_TRY(hipStreamWaitEvent(q, b->fork_ev, 0));
             HIP_TRY(hipEventRecord(b->ev[ev++], q));
-            if (bk.ring)
+            int32_t* strips = bk.chain ? b->chain_sweep.p + bk.strip_off : nullptr;
+            if (bk.ring && bk.chain)
+                LAUNCH_TRY(nra_launch_sweep_ringchain_bwd(bk.R, b->has_n, bk.wide ? 1 : 0, q, bk.n_sweep,
+                                                          b->sweep_tasks.p + bk.sweep_off, b->reads.p, b->regions.p, b->pool.p,
+                                                          b->q2bit.p, b->qnmask.p, b->sp, b->kmin.p, b->kmax.p, b->coff.p,
+                                                          b->snap.p, b->read_a1d.p, strips, b->chain_cap, bk.n_strips));
+            else if (bk.ring)
                 LAUNCH_TRY(nra_launch_sweep_ring_bwd(bk.R, b->has_n, q, bk.n_sweep, b->sweep_tasks.p + bk.sweep_off,
                                                      b->reads.p, b->regions.p, b->pool.p, b->q2bit.p, b->qnmask.p, b->sp,
                                                      b->kmin.p, b->kmax.p, b->coff.p, b->snap.p, b->read_a1d.p));
@@ -962,10 +1001,16 @@ static int run_1d(nra_batch* b)
                 LAUNCH_TRY(nra_launch_sweep_bwd(bk.R, b->has_n, bk.chain ? 1 : 0, q, bk.n_sweep, b->sweep_tasks.p + bk.sweep_off,
                                                 b->reads.p, b->regions.p, b->pool.p, b->q2bit.p, b->qnmask.p, b->sp,
                                                 b->kmin.p, b->kmax.p, b->coff.p, b->snap.p,
-                                                b->read_a1d.p, b->chain_sweep.p, b->chain_cap));
+                                                b->read_a1d.p, strips, b->chain_cap));
             HIP_TRY(hipEventRecord(b->ev[ev++], q));
             HIP_TRY(hipEventRecord(b->ev[ev++], q));
-            if (bk.ring)
+            if (bk.ring && bk.chain)
+                LAUNCH_TRY(nra_launch_sweep_ringchain_fwd(bk.R, b->has_n, bk.wide ? 1 : 0, q, bk.n_sweep,
+                                                          b->sweep_tasks.p + bk.sweep_off, b->reads.p, b->regions.p, b->pool.p,
+                                                          b->q2bit.p, b->qnmask.p, b->sp, b->kmin.p, b->kmax.p, b->coff.p,
+                                                          b->snap.p, b->read_a1d.p, b->cand_score.p, b->cand_flag.p,
+                                                          strips, b->chain_cap, bk.n_strips));
+            else if (bk.ring)
                 LAUNCH_TRY(nra_launch_sweep_ring_fwd(bk.R, b->has_n, q, bk.n_sweep, b->sweep_tasks.p + bk.sweep_off,
                                                      b->reads.p, b->regions.p, b->pool.p, b->q2bit.p, b->qnmask.p, b->sp,
                                                      b->kmin.p, b->kmax.p, b->coff.p, b->snap.p, b->read_a1d.p,
@@ -975,7 +1020,7 @@ static int run_1d(nra_batch* b)
                                                 b->reads.p, b->regions.p, b->pool.p, b->q2bit.p, b->qnmask.p, b->sp,
                                                 b->kmin.p, b->kmax.p, b->coff.p, b->snap.p,
                                                 b->read_a1d.p, b->cand_score.p, b->cand_flag.p,
-                                                b->chain_sweep.p, b->chain_cap));
+                                                strips, b->chain_cap));
             HIP_TRY(hipEventRecord(b->ev[ev++], q));
             b->n_score_ev += 2;
             HIP_TRY(hipEventRecord(b->bdone[i], q));
@@ -1012,7 +1057,7 @@ static int run_1d(nra_batch* b)
             const Bucket& bk = b->buckets[i];
             HIP_TRY(hipEventRecord(b->ev[ev++], st));
             // chained reads: int64 cells (scores and extents of any size)
-            LAUNCH_TRY(nra_launch_payload_origin(bk.R, b->has_n, st,
+            LAUNCH_TRY(nra_launch_payload_origin(bk.chain ? bk.payload_R : bk.R, b->has_n, st,
                                               (int)std::min<size_t>(bk.queue_cap, bk.chain ? NRA_CHAIN_STRIPS : max_waves),
                                               b->queue_tasks.p + bk.queue_off, b->tie_count.p + i,
                                               b->reads.p, b->regions.p, b->pool.p,

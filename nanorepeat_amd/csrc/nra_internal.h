@@ -175,6 +175,26 @@ int nra_launch_sweep_ring_fwd(int R, int has_n, hipStream_t st, int n_tasks, con
                               const int32_t* kmin, const int32_t* kmax, const uint32_t* coff,
                               int32_t* snap, int32_t* read_a, int32_t* cand_score, uint8_t* cand_flag);
 
+// chained LDS-ring sweeps (k_sweep_ringchain): reads of more than NRA_RING_CHAIN_MIN_ROWS rows as row blocks of
+// 64 * NRA_RING_CHAIN_R; wide = 0: two reads per wave in packed int16, 1: one read per wave in int32 cells.
+// chain_buf: n_strips strips of 10 * chain_cap int32; the launch has min(n_tasks, n_strips) waves
+#define NRA_RING_CHAIN_R 20
+#define NRA_RING_CHAIN_MIN_ROWS NRA_MAX_QLEN_1BLOCK   // shorter reads stay unchained: a block costs a pipeline fill and half a block of padding
+#define NRA_RING_CHAIN_STRIPS 4096
+int nra_launch_sweep_ringchain_bwd(int R, int has_n, int wide, hipStream_t st, int n_tasks,
+                                   const NraSweepTask* tasks, const NraDevRead* reads,
+                                   const NraDevRegion* regions, const uint8_t* pool,
+                                   const uint32_t* q2bit, const uint32_t* qnmask, NraScoreParams sp,
+                                   const int32_t* kmin, const int32_t* kmax, const uint32_t* coff,
+                                   int32_t* snap, int32_t* read_a, int32_t* chain_buf, int chain_cap, int n_strips);
+int nra_launch_sweep_ringchain_fwd(int R, int has_n, int wide, hipStream_t st, int n_tasks,
+                                   const NraSweepTask* tasks, const NraDevRead* reads,
+                                   const NraDevRegion* regions, const uint8_t* pool,
+                                   const uint32_t* q2bit, const uint32_t* qnmask, NraScoreParams sp,
+                                   const int32_t* kmin, const int32_t* kmax, const uint32_t* coff,
+                                   int32_t* snap, int32_t* read_a, int32_t* cand_score, uint8_t* cand_flag,
+                                   int32_t* chain_buf, int chain_cap, int n_strips);
+
 // 2D junction decomposition (nra_joint.hip)
 int nra_launch_joint_bwd(int R, int has_n, hipStream_t st, int n_tasks, const NraJointTask* tasks,
                          const NraDevRead* reads, const NraDevRegion* regions, const uint8_t* pool,

@@ -691,6 +691,240 @@ __global__ __launch_bounds__(WAVE * SWEEP_RING_WPB) void k_sweep_ring(int n_task
 }
 
 // ------------------------------------------------------------------------------------
+// k_sweep_ringchain: the LDS-ring sweep for reads of more than NRA_RING_CHAIN_MIN_ROWS rows.
+//
+// k_sweep_ring keeps all rows of a read pair in the registers of one wave: from 28 rows per lane on that is one
+// wave per SIMD.  Here the rows are swept as consecutive blocks of 64*R rows (R = NRA_RING_CHAIN_R) by the same
+// wave, which then fits three to a SIMD: what lane 63 leaves per column -- H of the block's last row, the two
+// vertical-gap states and, on boundary columns, the S and B accumulators -- goes to a scratch strip that the
+// next block's lane 0 picks up (lane 63 feeds lane 0's ring slot anyway: it hands out the strip's values
+// together with the template column).  W = false: two reads per wave in packed int16 (doubled scores up to
+// 16000); W = true: one read per wave in int32 cells, any length.  A launch has one wave per strip and walks its
+// tasks with a wave-uniform grid stride.
+template <int R, bool HAS_N, int DIR, bool W>
+__global__ __launch_bounds__(WAVE) void k_sweep_ringchain(int n_tasks, const NraSweepTask* __restrict__ tasks,
+                                                          const NraDevRead* __restrict__ reads,
+                                                          const NraDevRegion* __restrict__ regions,
+                                                          const uint8_t* __restrict__ pool,
+                                                          const uint32_t* __restrict__ q2bit,
+                                                          const uint32_t* __restrict__ qnmask,
+                                                          NraScoreParams sp,
+                                                          const int32_t* __restrict__ kmin_arr,
+                                                          const int32_t* __restrict__ kmax_arr,
+                                                          const uint32_t* __restrict__ coff,
+                                                          int32_t* __restrict__ snap,
+                                                          int32_t* __restrict__ read_a,
+                                                          int32_t* __restrict__ cand_score,
+                                                          uint8_t* __restrict__ cand_flag,
+                                                          int32_t* chain_buf, int chain_cap)
+{
+    constexpr int SC = 2;
+    constexpr int BIASW = W ? 0 : BIAS;
+    __shared__ int4 ring[SWEEP_RING_D * 64];
+    __shared__ int2 racc[64];
+    const int lane = threadIdx.x;
+    const int wr = (lane + 1) & 63;
+    volatile int32_t* strip = chain_buf + (size_t)blockIdx.x * 10 * chain_cap;
+  for (int task = blockIdx.x; task < n_tasks; task += gridDim.x) {
+    const NraSweepTask tk = tasks[task];
+    const bool has_b = !W && tk.read_b >= 0;
+    const int ra = tk.read_a, rb = has_b ? tk.read_b : tk.read_a;
+    const NraDevRead rda = reads[ra], rdb = reads[rb];
+    const NraDevRegion rg = regions[rda.region];
+    const int m = rg.m1;
+    const int flank = DIR ? rg.l1 : rg.l3;
+    const uint8_t* __restrict__ piece = pool + (DIR ? rg.p1_off : rg.pr_off);
+    const int ncols = DIR ? flank + m * tk.kmax : flank;
+    const int jfirst = DIR ? flank + m * tk.kmin - 1 : flank - 1;
+    const int skew = DIR ? m : 1;
+    const int kmin_a = kmin_arr[ra], kmax_a = kmax_arr[ra];
+    const int kmin_b = kmin_arr[rb], kmax_b = kmax_arr[rb];
+    const uint32_t coff_a = coff[ra], coff_b = coff[rb];
+    int32_t* __restrict__ snap_task = snap + tk.snap_off;
+
+    const int o1 = SC * sp.open1, o2 = SC * sp.open2;
+    const int P1 = W ? 1 : 0x00010001;
+    const int v_floor = (BIASW - o1) * P1;
+    const int v_o1 = o1 * P1, v_e1 = SC * sp.ext1 * P1, v_o2 = o2 * P1, v_e2 = SC * sp.ext2 * P1;
+    const int NEG1 = W ? -(1 << 28) : NEGB * P1;
+    const int NEG2 = W ? -(1 << 28) : 2 * NEGB * P1;
+    const int s_match = SC * sp.match + o1, s_mis = o1 - SC * sp.mismatch, s_ambi = o1 - SC * sp.ambi;
+    const int tbl_hi = s_mis | (s_ambi << 8);
+    const int tbl_mis4 = s_mis * 0x01010101, tbl_ambi4 = s_ambi * 0x01010101;
+
+    auto column_table = [&](int col) {
+        int t = tbl_mis4;
+        if (col >= 0 && col < ncols) {
+            const int code = piece[col];
+            t = code < 4 ? tbl_mis4 + ((s_match - s_mis) << (8 * code)) : tbl_ambi4;
+            if (DIR == 0 && col == flank - 1) t |= FLAG_SNAPSHOT;
+            if (DIR == 1 && col >= flank) t |= FLAG_INREP;
+        }
+        return t;
+    };
+
+    int out_a = 0, out_b = 0;
+    int n_out = 0, kcur = tk.kmin;                          // wave-uniform
+    auto flush = [&](int n_valid) {
+        const int k = kcur - 64 + lane;
+        if (lane < 64 - n_valid) return;
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2) {
+            if (s2 == 1 && !has_b) break;
+            const int lo_k = s2 ? kmin_b : kmin_a, hi_k = s2 ? kmax_b : kmax_a;
+            if (k < lo_k || k > hi_k) continue;
+            const uint32_t idx = (s2 ? coff_b : coff_a) + (uint32_t)(k - lo_k);
+            const int v = s2 ? out_b : out_a;
+            cand_score[idx] = v >> 2;
+            cand_flag[idx] = (uint8_t)(v & 3);
+        }
+    };
+    const int a_of_a = DIR ? read_a[ra] : 0, a_of_b = DIR ? read_a[rb] : 0;
+    int a_all = BIASW * P1;                                  // reverse sweep: maximum over the cells of every block
+
+    const int n_blk = (imax(rda.qlen, rdb.qlen) + 64 * R - 1) / (64 * R);
+    const int nsteps = ncols + 63 * skew;
+  for (int blk = 0; blk < n_blk; ++blk) {
+    const int row_base = blk * 64 * R;
+    const bool first_blk = blk == 0, last_blk = blk == n_blk - 1;
+    volatile int32_t* cin = strip + ((blk + 1) & 1) * 5 * chain_cap;
+    volatile int32_t* cout = strip + (blk & 1) * 5 * chain_cap;
+    // what enters row 0 of this block at template column `col`: constants for the first block, else the strip
+    auto strip_in = [&](int col, int which, int dflt) {
+        return (!first_blk && col >= 0 && col < ncols) ? (int)cin[which * chain_cap + col] : dflt;
+    };
+
+    int qc[R];
+#pragma unroll
+    for (int i = 0; i < R; ++i) {
+        const int gi = row_base + lane * R + i;
+        const int ca = sweep_query_sel<HAS_N>(rda, q2bit, qnmask, gi, DIR == 0);
+        const int cb = W ? 0x0c : sweep_query_sel<HAS_N>(rdb, q2bit, qnmask, gi, DIR == 0);
+        qc[i] = ca | (0x0c << 8) | (cb << 16) | (0x0c << 24);
+    }
+    int Hbo[DIR ? R : 1], Ebo[DIR ? R : 1], E2bo[DIR ? R : 1];
+    if (DIR) {
+        const int q1 = SC * (sp.open1 - sp.ext1), q2 = SC * (sp.open2 - sp.ext2);
+#pragma unroll
+        for (int i = 0; i < R; ++i) {
+            const int r = row_base + lane * R + i;
+            int h[2], e[2], e2[2];
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+                const int a = (s ? rdb.qlen : rda.qlen) - 2 - r;
+                if (a >= 0) {
+                    const int ablk = a / (64 * R);
+                    const int w = a - ablk * 64 * R;
+                    const int al = w / R, ai = w - al * R;
+                    const int32_t* __restrict__ p = snap_task + ((size_t)ablk * 3 * R + ai) * 64 + al;
+                    const int vh = p[0], ve = p[R * 64], ve2 = p[2 * R * 64];
+                    h[s] = (W ? vh : (s ? half_hi(vh) : half_lo(vh))) + 2 * o1;
+                    e[s] = (W ? ve : (s ? half_hi(ve) : half_lo(ve))) + q1;
+                    e2[s] = (W ? ve2 : (s ? half_hi(ve2) : half_lo(ve2))) + q2;
+                } else { h[s] = BIASW + o1 - SC; e[s] = BIASW - SC; e2[s] = BIASW - SC; }
+            }
+            Hbo[i] = W ? h[0] : pack2(h[0], h[1]);
+            Ebo[i] = W ? e[0] : pack2(e[0], e[1]);
+            E2bo[i] = W ? e2[0] : pack2(e2[0], e2[1]);
+        }
+    }
+    int Hq[R], Hq2[R], E[R], E2[R];
+#pragma unroll
+    for (int i = 0; i < R; ++i) { Hq[i] = v_floor; Hq2[i] = NEG1; E[i] = NEG1; E2[i] = NEG1; }
+
+    // ring: padding columns everywhere, then lane 0's first `skew` columns and first boundary
+#pragma unroll
+    for (int s = 0; s < SWEEP_RING_D; ++s) ring[s * 64 + lane] = make_int4(v_floor, NEG1, NEG1, tbl_mis4);
+    racc[lane] = make_int2(NEG2, NEG1);
+    if (lane < skew)
+        ring[lane * 64] = make_int4(strip_in(lane, 0, v_floor), strip_in(lane, 1, NEG1), strip_in(lane, 2, NEG1), column_table(lane));
+    if (DIR == 1 && lane == 0) racc[0] = make_int2(strip_in(jfirst, 3, NEG2), strip_in(jfirst, 4, NEG1));
+
+    int Hup_prev = v_floor, M = BIASW * P1;
+    int feed = tbl_mis4, sH = v_floor, sF = NEG1, sF2 = NEG1, sS = NEG2, sB = NEG1;   // what lane 63 hands to lane 0
+    int slot = 0;
+    int phase = jfirst % m, pcnt = 0, bidx = 0;
+    n_out = 0; kcur = tk.kmin;
+#pragma unroll 1
+    for (int step = 0; step < nsteps; ++step) {
+        if ((step & 63) == 0) {                                            // columns step + skew + (0..63)
+            const int col = step + skew + wr;
+            feed = column_table(col);
+            sH = strip_in(col, 0, v_floor); sF = strip_in(col, 1, NEG1); sF2 = strip_in(col, 2, NEG1);
+            if (DIR == 1) { sS = strip_in(col, 3, NEG2); sB = strip_in(col, 4, NEG1); }
+        }
+        const int4 in = ring[slot * 64 + lane];
+        int F = in.y, F2 = in.z;
+        const int tt = in.w;
+        const int floor_c = DIR == 1 ? (int)((((unsigned)tt >> 15) & (unsigned)P1) | (unsigned)v_floor) : v_floor;
+        sweep_cell<0, R, R, W>(Hq, Hq2, E, E2, qc, Hup_prev, F, F2, M, tt & 0x7f7f7f7f, tbl_hi, floor_c, v_e1, v_e2, v_o1, v_o2);
+        Hup_prev = in.x;
+        ring[slot * 64 + wr] = make_int4(Hq[R - 1], F, F2, tt);
+        if (lane == 63) ring[slot * 64] = make_int4(sH, sF, sF2, feed);
+        const int c63 = step - 63 * skew;                                  // the column lane 63 has just finished
+        if (lane == 63 && !last_blk && c63 >= 0) {
+            cout[c63] = Hq[R - 1]; cout[chain_cap + c63] = F; cout[2 * chain_cap + c63] = F2;
+        }
+        feed = dpp_rol1(feed); sH = dpp_rol1(sH); sF = dpp_rol1(sF); sF2 = dpp_rol1(sF2);
+        if (++slot == skew) slot = 0;
+
+        if constexpr (DIR == 0) {
+            if (tt & FLAG_SNAPSHOT) sweep_snapshot<0, R, R>(Hq, E, E2, snap_task + (size_t)blk * 3 * R * 64, lane);
+        } else {
+            const bool boundary = pcnt == phase && step >= jfirst;         // wave-uniform: every lane on a unit boundary
+            if (boundary) {
+                const int tS = sweep_combine<0, R, R, W>(Hq, E, E2, Hbo, Ebo, E2bo, NEG2);
+                const int2 acc = racc[lane];
+                const int accS = mx2<W>(acc.x, tS), accB = mx2<W>(acc.y, M);
+                racc[wr] = make_int2(accS, accB);
+                if (lane == 63) {
+                    racc[0] = make_int2(sS, sB);                           // of column step + skew: lane 0's next boundary
+                    if (!last_blk && c63 >= 0) { cout[3 * chain_cap + c63] = accS; cout[4 * chain_cap + c63] = accB; }
+                }
+                if (last_blk && bidx >= 63 && kcur <= tk.kmax) {           // lane 63 is on the boundary of k = kcur
+                    int va = 0, vb = 0;
+                    if (lane == 63) {
+#pragma unroll
+                        for (int s2 = 0; s2 < (W ? 1 : 2); ++s2) {
+                            const int B = (W ? accB : (s2 ? half_hi(accB) : half_lo(accB))) - BIASW;
+                            const int S = (W ? accS : (s2 ? half_hi(accS) : half_lo(accS))) - 2 * BIASW;
+                            const int lo = sp.min_score > 1 ? sp.min_score : 1;
+                            const int V = imax(imax(S, B), (s2 ? a_of_b : a_of_a) + 1);
+                            const int best = V >> 1;
+                            int flag = 1;
+                            if (V & 1) flag = 0;
+                            else if ((B >> 1) >= best) flag = ((S >> 1) >= best) ? 2 : 0;
+                            const int v = ((best >= lo ? best : -1) << 2) | flag;
+                            if (s2) vb = v; else va = v;
+                        }
+                    }
+                    out_a = dpp_rol1(out_a); out_b = dpp_rol1(out_b);
+                    if (lane == 63) { out_a = va; out_b = vb; }
+                    ++kcur; ++n_out;
+                    if (n_out == 64) { flush(64); n_out = 0; }
+                }
+                ++bidx;
+            }
+            sS = dpp_rol1(sS); sB = dpp_rol1(sB);
+            if (++pcnt == m) pcnt = 0;
+        }
+    }
+    if (DIR == 0) a_all = mx2<W>(a_all, M);
+    else if (last_blk && n_out > 0) flush(n_out);
+  }   // row blocks
+    if (DIR == 0) {
+        // A = best alignment inside R (doubled) = the maximum over every cell of the sweep
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) a_all = mx2<W>(a_all, __shfl_xor(a_all, off, 64));
+        if (lane == 0) {
+            read_a[ra] = (W ? a_all : half_lo(a_all)) - BIASW;
+            if (has_b) read_a[rb] = half_hi(a_all) - BIASW;
+        }
+    }
+  }   // tasks
+}
+
+// ------------------------------------------------------------------------------------
 // launchers
 // ------------------------------------------------------------------------------------
 template <int DIR>
@@ -771,6 +1005,59 @@ extern "C" int nra_launch_sweep_ring_fwd(int R, int has_n, hipStream_t st, int n
 {
     return launch_sweep_ring<1>(R, has_n, st, n_tasks, tasks, reads, regions, pool, q2bit, qnmask, sp, kmin, kmax,
                                 coff, snap, read_a, cand_score, cand_flag);
+}
+#endif
+
+template <int DIR>
+static int launch_sweep_ringchain(int R, int has_n, int wide, hipStream_t st, int n_tasks, const NraSweepTask* tasks,
+                                  const NraDevRead* reads, const NraDevRegion* regions, const uint8_t* pool,
+                                  const uint32_t* q2bit, const uint32_t* qnmask, NraScoreParams sp,
+                                  const int32_t* kmin, const int32_t* kmax, const uint32_t* coff,
+                                  int32_t* snap, int32_t* read_a, int32_t* cand_score, uint8_t* cand_flag,
+                                  int32_t* chain_buf, int chain_cap, int n_strips)
+{
+    if (n_tasks <= 0) return 0;
+    const int grid = n_tasks < n_strips ? n_tasks : n_strips;
+#define ARGS n_tasks, tasks, reads, regions, pool, q2bit, qnmask, sp, kmin, kmax, coff, snap, read_a, cand_score, cand_flag, chain_buf, chain_cap
+#define LAUNCH(r)                                                                                        \
+    do {                                                                                                 \
+        if (wide) { if (has_n) k_sweep_ringchain<r, true, DIR, true><<<grid, WAVE, 0, st>>>(ARGS);      \
+                    else k_sweep_ringchain<r, false, DIR, true><<<grid, WAVE, 0, st>>>(ARGS); }         \
+        else { if (has_n) k_sweep_ringchain<r, true, DIR, false><<<grid, WAVE, 0, st>>>(ARGS);          \
+               else k_sweep_ringchain<r, false, DIR, false><<<grid, WAVE, 0, st>>>(ARGS); }             \
+    } while (0)
+    if (R == NRA_RING_CHAIN_R) LAUNCH(NRA_RING_CHAIN_R);
+    else if (R == NRA_CHAIN_R_TEST) LAUNCH(NRA_CHAIN_R_TEST);
+    else return (int)hipErrorInvalidValue;
+#undef LAUNCH
+#undef ARGS
+    return (int)hipGetLastError();
+}
+
+#if NRA_HAS_PART(13)
+extern "C" int nra_launch_sweep_ringchain_bwd(int R, int has_n, int wide, hipStream_t st, int n_tasks,
+                                              const NraSweepTask* tasks, const NraDevRead* reads,
+                                              const NraDevRegion* regions, const uint8_t* pool,
+                                              const uint32_t* q2bit, const uint32_t* qnmask, NraScoreParams sp,
+                                              const int32_t* kmin, const int32_t* kmax, const uint32_t* coff,
+                                              int32_t* snap, int32_t* read_a, int32_t* chain_buf, int chain_cap,
+                                              int n_strips)
+{
+    return launch_sweep_ringchain<0>(R, has_n, wide, st, n_tasks, tasks, reads, regions, pool, q2bit, qnmask, sp, kmin,
+                                     kmax, coff, snap, read_a, nullptr, nullptr, chain_buf, chain_cap, n_strips);
+}
+#endif
+#if NRA_HAS_PART(14)
+extern "C" int nra_launch_sweep_ringchain_fwd(int R, int has_n, int wide, hipStream_t st, int n_tasks,
+                                              const NraSweepTask* tasks, const NraDevRead* reads,
+                                              const NraDevRegion* regions, const uint8_t* pool,
+                                              const uint32_t* q2bit, const uint32_t* qnmask, NraScoreParams sp,
+                                              const int32_t* kmin, const int32_t* kmax, const uint32_t* coff,
+                                              int32_t* snap, int32_t* read_a, int32_t* cand_score,
+                                              uint8_t* cand_flag, int32_t* chain_buf, int chain_cap, int n_strips)
+{
+    return launch_sweep_ringchain<1>(R, has_n, wide, st, n_tasks, tasks, reads, regions, pool, q2bit, qnmask, sp, kmin,
+                                     kmax, coff, snap, read_a, cand_score, cand_flag, chain_buf, chain_cap, n_strips);
 }
 #endif
 

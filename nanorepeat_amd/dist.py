@@ -15,9 +15,9 @@ import numpy as np
 from . import _capi
 
 # rows-per-lane instantiations of the sweep kernels (csrc/nra_internal.h NRA_R_LIST); longer reads
-# run as chained blocks of 64 * 24 rows
+# run as chained blocks of 64 * 20 rows
 _R_LIST = np.array([1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16, 18, 20, 22, 24, 28, 32, 40, 48], np.int64)
-_CHAIN_ROWS = 64 * 24
+_CHAIN_ROWS = 64 * 20      # NRA_RING_CHAIN_R
 
 
 def padded_rows(qlen):

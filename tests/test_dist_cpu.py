@@ -179,7 +179,7 @@ def test_region_block_sharder_properties():
     assert np.bincount(owner, minlength=8).min() >= 100
     # executed-cell cost: padded rows x executed columns
     cells = D.executed_cells([("A" * 10, "CAG", "T" * 7)], [5, 65, 3073], [4, 4, 4])
-    assert cells.tolist() == [64 * (17 + 12 + 254), 128 * (17 + 12 + 254), 3 * 1536 * (17 + 12 + 254)]
+    assert cells.tolist() == [64 * (17 + 12 + 254), 128 * (17 + 12 + 254), 3 * 1280 * (17 + 12 + 254)]
 
 
 def test_shard_reads_is_a_balanced_partition():
