@@ -319,7 +319,7 @@ bool scoring_ok(const nra_scoring_t* sc)
 // int32 cells keep the score in their upper 16 bits; the packed int16 kernels keep value + 8192
 // (brute force), two biased values added (chained sweep: 2 x 8192 + score), or the same with
 // doubled scores (origin-bit sweep).
-const int64_t kScoreCapI32 = 32000, kScoreCapPk16 = 24000, kScoreCapBit = 8000;
+const int64_t kScoreCapI32 = 32000, kScoreCapPk16 = 24000, kScoreCapBit = 13500;
 inline int64_t max_score(const nra_scoring_t* sc, int64_t qlen) { return (int64_t)sc->match * qlen; }
 
 // A rows-per-lane bucket with few reads would run as its own under-filled launches: fold it into the
@@ -734,9 +734,9 @@ int nra_batch1d_create(int device, const nra_region_t* regions, int32_t n_region
         // (doubled: the low bit of every state is the origin bit)
         const int o1 = sc->gap_open1 + sc->gap_ext1;
         if (o1 < sc->mismatch || o1 < sc->sc_ambi || 2 * (sc->match + o1) > 127) brute = true;
-        // and every state in [0x0400, 0x7bff] (nra_sweep.hip: bias 4096, "minus infinity" 1280)
+        // and every state in [0x0400, 0x7bff] (nra_sweep.hip: bias 2048, "minus infinity" 1280)
         const int o2 = sc->gap_open2 + sc->gap_ext2;
-        if (2 * sc->gap_ext1 > 256 || 2 * sc->gap_ext2 > 256 || 2 * o2 > 2048) brute = true;
+        if (2 * sc->gap_ext1 > 256 || 2 * sc->gap_ext2 > 256 || 2 * (o2 + sc->mismatch + sc->sc_ambi) > 700) brute = true;
     }
     // Which reads leave the packed int16 sweeps for the chained int32 ones (one read per wave, any length):
     // more rows than one register block, scores beyond the doubled int16 range, or a template whose
@@ -763,7 +763,7 @@ int nra_batch1d_create(int device, const nra_region_t* regions, int32_t n_region
     std::vector<NraSweepTask> sweep_tasks;
     uint64_t snap_total = 0;
     // the chained reads (every read with NRA_F_TEST_CHAIN): bucket kNumR = int32 cells, one read per wave;
-    // bucket kNumR + 1 = packed int16, two reads per wave -- doubled scores up to 16000 (reads of up to 4000
+    // bucket kNumR + 1 = packed int16, two reads per wave -- doubled scores up to 27000 (reads of up to 6750
     // bases with the default scoring) in the LDS-ring kernels, which hold units of up to NRA_SWEEP_RING_MAX_M
     std::vector<std::vector<int32_t>> by_bucket((size_t)kNumR + 2);
     int chain_cols = 0;

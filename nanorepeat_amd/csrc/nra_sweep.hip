@@ -53,11 +53,12 @@
 // other, so adding or subtracting a small constant or another biased value is a plain 32-bit
 // v_add/v_sub_u32.  The substitution score is one v_perm_b32 through a 4-entry byte table that travels
 // with the template base.
-//   range: one bias 4096 + doubled score <= 16000 -> 20096; the junction combine adds two biased
-//   values -> <= 24192 < 0x7bff; the smallest real state is 4096 - (gap open 2 + a mismatch) ~ 4000,
-//   "minus infinity" is NEGB and survives one subtraction of a gap extension (host: nra_host.cpp
-//   sends scoring schemes that do not fit these bounds to the brute-force kernel).
-#define BIAS 4096
+//   range: one bias 2048 + doubled score <= 27000 -> 29048; the junction combine adds two biased
+//   values, 4096 + the doubled score of ONE alignment -> <= 31096 < 0x7bff; the smallest real state is
+//   2048 - 2 * (gap open 2 + a mismatch) ~ 1990, "minus infinity" is NEGB and survives one subtraction of a
+//   gap extension (host: nra_host.cpp keeps doubled scores <= 27000 in these cells and sends scoring
+//   schemes that do not fit the bounds to the brute-force kernel).
+#define BIAS 2048
 #define NEGB 1280                     // biased "minus infinity": below any real state, >= 0x0400 after - ext
 #define FLAG_BOUNDARY 0x00000080      // bit 7 of table byte 0
 #define FLAG_SNAPSHOT 0x00008000      // bit 7 of table byte 1 (reverse sweep)
@@ -699,7 +700,7 @@ __global__ __launch_bounds__(WAVE * SWEEP_RING_WPB) void k_sweep_ring(int n_task
 // vertical-gap states and, on boundary columns, the S and B accumulators -- goes to a scratch strip that the
 // next block's lane 0 picks up (lane 63 feeds lane 0's ring slot anyway: it hands out the strip's values
 // together with the template column).  W = false: two reads per wave in packed int16 (doubled scores up to
-// 16000); W = true: one read per wave in int32 cells, any length.  A launch has one wave per strip and walks its
+// 27000); W = true: one read per wave in int32 cells, any length.  A launch has one wave per strip and walks its
 // tasks with a wave-uniform grid stride.
 template <int R, bool HAS_N, int DIR, bool W>
 __global__ __launch_bounds__(WAVE) void k_sweep_ringchain(int n_tasks, const NraSweepTask* __restrict__ tasks,

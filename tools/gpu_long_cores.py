@@ -1,4 +1,4 @@
-"""Times the 1D path on long cores (large expansions): 3.7 kb cores (packed chained blocks) and 7.7 kb cores
+"""Times the 1D path on long cores (large expansions): 3.7 and 5.7 kb cores (packed chained blocks) and 7.7 kb cores
 (int32 chained blocks), LDS-ring chain vs the DPP chain (NRA_F_DPP_SWEEP).  Usage: python tools/gpu_long_cores.py [n_reads]"""
 import json, sys, time
 import numpy as np
@@ -7,7 +7,8 @@ from nanorepeat_amd import _capi as A, synth
 
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 2000
 out = {}
-for name, alleles in (("cores_3.7kb", (700, 705)), ("cores_7.7kb", (1500, 1505)), ("cores_2.6kb_unchained", (480, 485))):
+for name, alleles in (("cores_3.7kb", (700, 705)), ("cores_5.7kb", (1100, 1105)), ("cores_7.7kb", (1500, 1505)),
+                      ("cores_2.6kb_unchained", (480, 485))):
     d = synth.make_1d(n, "TATTG", alleles, "ont_q20", kwin=None, seed=77)
     n_align = int((d["kmax"].astype(np.int64) - d["kmin"] + 1).sum())
     row = {"reads": n, "alignments": n_align}
