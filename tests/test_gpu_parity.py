@@ -365,6 +365,22 @@ def test_joint_resident_reads_across_cell_lists(capi, oracle):
                 assert np.array_equal(np.asarray(one[key])[sel], np.asarray(o[key])[sel]), (step, shift, key)
 
 
+def test_more_chained_tasks_than_scratch_strips(capi, oracle):
+    """A chained launch has one wave per scratch strip and walks its tasks with a grid stride: 9000 small reads
+    in forced chained blocks (NRA_F_TEST_CHAIN) are 4500 packed LDS-ring tasks (> 4096 strips) and, with the
+    DPP sweeps, 9000 int32 tasks (> 512 strips).  Same results as the unchained sweeps; a sample equals the oracle."""
+    d = synth.make_1d(9000, "CAG", (6, 11), "ont_q20", kwin=(2, 16), anchor=40, flank=25, seed=88)
+    base = capi.round3_1d(d["regions"], d["reads"], d["kmin"], d["kmax"])
+    for flags in (capi.F_TEST_CHAIN, capi.F_TEST_CHAIN | capi.F_DPP_SWEEP):
+        g = capi.round3_1d(d["regions"], d["reads"], d["kmin"], d["kmax"], flags=flags)
+        for k in ("best_score", "sum_k", "n_ties", "status", "cand_score"):
+            assert np.array_equal(g[k], base[k]), (flags, k)
+    pick = np.arange(0, 9000, 450)
+    o = oracle.round3_1d(d["regions"], [d["reads"][i] for i in pick], d["kmin"][pick], d["kmax"][pick])
+    for k in ("best_score", "sum_k", "n_ties", "status"):
+        assert np.array_equal(base[k][pick], o[k]), k
+
+
 def test_long_joint_reads_uncut_equal_oracle(capi, oracle):
     """Joint reads of 5 kb (beyond one register block) are scored uncut, cell by cell in chained row
     blocks with int64 cells; strands probed (0) or given; short reads of the same batch take the sweeps."""

@@ -92,7 +92,9 @@ def fuzz_1d_multi(rng):
     order = rng.permutation(len(reads))
     reads = [reads[i] for i in order]; kmin = [kmin[i] for i in order]; kmax = [kmax[i] for i in order]; rr = [rr[i] for i in order]
     o = O.round3_1d(regions, reads, kmin, kmax, read_region=rr)
-    for flags in (0, A.F_TIE_EXTENTS, A.F_ALL_EXTENTS):
+    for flags in (0, A.F_TIE_EXTENTS, A.F_ALL_EXTENTS, A.F_TEST_CHAIN, A.F_TEST_CHAIN | A.F_DPP_SWEEP):
+        if flags & A.F_TEST_CHAIN and any(len(L) < 1 or len(R) < 1 for L, _, R in regions):
+            continue
         g = A.round3_1d(regions, reads, kmin, kmax, read_region=rr, flags=flags)
         keys, want = K1, o
         if flags == A.F_ALL_EXTENTS:
