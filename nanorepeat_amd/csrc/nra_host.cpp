@@ -275,6 +275,7 @@ struct Bucket {
     int R = 0;
     bool chain = false;        // reads longer than one register block: chained row blocks
     bool wide = false;         // chained: int32 cells, one read per wave (else packed int16, two reads per wave)
+    bool half = false;         // k_sweep_ring32: two read pairs per wave, 32 lanes each (R = rows per lane of a half)
     int payload_R = 0;         // chained: row block of the extents kernel (NRA_CHAIN_R / NRA_CHAIN_R_TEST)
     size_t strip_off = 0;      // chained: this bucket's scratch strips in chain_sweep (int32 index)
     int n_strips = 0;
@@ -765,11 +766,16 @@ int nra_batch1d_create(int device, const nra_region_t* regions, int32_t n_region
     // the chained reads (every read with NRA_F_TEST_CHAIN): bucket kNumR = int32 cells, one read per wave;
     // bucket kNumR + 1 = packed int16, two reads per wave -- doubled scores up to 27000 (reads of up to 6750
     // bases with the default scoring) in the LDS-ring kernels, which hold units of up to NRA_SWEEP_RING_MAX_M
-    std::vector<std::vector<int32_t>> by_bucket((size_t)kNumR + 2);
+    // buckets kNumR + 2 + i: half-wave sweeps (k_sweep_ring32), i = index of the half's rows per lane in kRList
+    std::vector<std::vector<int32_t>> by_bucket((size_t)2 * kNumR + 2);
+    const bool ring_ok = (flags & NRA_F_DPP_SWEEP) == 0 && !brute;
     int chain_cols = 0;
     for (int32_t r = 0; r < n_reads; ++r) {
         if (kmin[r] > kmax[r] || pr.reads[r].qlen == 0) continue;
         int bi = rows_for_qlen(pr.reads[r].qlen);
+        if (ring_ok && !chained[r] && pr.reads[r].qlen <= 32 * NRA_RING32_MAX_R &&
+            regions[pr.reads[r].region].unit_len <= NRA_SWEEP_RING_MAX_M && (flags & NRA_F_NO_HALF_WAVE) == 0)
+            bi = kNumR + 2 + rows_for_qlen(2 * pr.reads[r].qlen);        // 32 * R >= qlen
         if (chained[r]) {
             const nra_region_t& rg = regions[pr.reads[r].region];
             const bool packed = max_score(sc, pr.reads[r].qlen) <= kScoreCapBit && rg.unit_len <= NRA_SWEEP_RING_MAX_M &&
@@ -783,11 +789,12 @@ int nra_batch1d_create(int device, const nra_region_t* regions, int32_t n_region
     if ((!by_bucket[kNumR].empty() || !by_bucket[kNumR + 1].empty()) && brute)
         return fail(NRA_E_RANGE, "NRA_F_TEST_CHAIN needs the junction decomposition (no brute force / ALL_EXTENTS, flanks >= 1)");
     b->chain_cap = (chain_cols + 127) / 64 * 64 + 64;
-    {
-        std::vector<int32_t> cw(std::move(by_bucket[kNumR])), cp(std::move(by_bucket[kNumR + 1]));
-        by_bucket[kNumR].clear(); by_bucket[kNumR + 1].clear();
-        fold_small_buckets(by_bucket, 1024, 2);    // wider folding (up to 16384 reads / 4 rows) changes nothing in 1D
-        by_bucket[kNumR] = std::move(cw); by_bucket[kNumR + 1] = std::move(cp);
+    {   // small buckets fold into the next instantiation of their own kind
+        std::vector<std::vector<int32_t>> full(by_bucket.begin(), by_bucket.begin() + kNumR);
+        std::vector<std::vector<int32_t>> halfb(by_bucket.begin() + kNumR + 2, by_bucket.end());
+        fold_small_buckets(full, 1024, 2);    // wider folding (up to 16384 reads / 4 rows) changes nothing in 1D
+        fold_small_buckets(halfb, 2048, 2);
+        for (int i = 0; i < kNumR; ++i) { by_bucket[i] = std::move(full[i]); by_bucket[kNumR + 2 + i] = std::move(halfb[i]); }
     }
     size_t strip_total = 0;
     std::vector<NraPairTask> pair_tasks;
@@ -796,13 +803,16 @@ int nra_batch1d_create(int device, const nra_region_t* regions, int32_t n_region
     std::vector<uint32_t> task_base;
     size_t queue_total = 0;
     int64_t alg_cells = 0;
-    const int bucket_order_first = kNumR + 1;
-    for (int bi0 = bucket_order_first; bi0 >= 0; --bi0) {           // longest reads first: int32 chain, packed chain, R = 48 ...
-        const int bi = bi0 == kNumR + 1 ? kNumR : (bi0 == kNumR ? kNumR + 1 : bi0);
+    // longest reads first: int32 chain, packed chain, full-wave R = 48 ... 1, then the half-wave buckets 16 ... 1
+    std::vector<int> bucket_order{kNumR, kNumR + 1};
+    for (int i = kNumR - 1; i >= 0; --i) bucket_order.push_back(i);
+    for (int i = kNumR - 1; i >= 0; --i) bucket_order.push_back(kNumR + 2 + i);
+    for (const int bi : bucket_order) {
         if (by_bucket[bi].empty()) continue;
         Bucket bk;
-        bk.chain = bi >= kNumR;
+        bk.chain = bi == kNumR || bi == kNumR + 1;
         bk.wide = bi == kNumR;
+        bk.half = bi >= kNumR + 2;
         if (bk.chain) {
             // LDS-ring chain unless a unit is too long for the ring (then the DPP chain, int32 only)
             bk.ring = (flags & NRA_F_DPP_SWEEP) == 0;
@@ -811,7 +821,7 @@ int nra_batch1d_create(int device, const nra_region_t* regions, int32_t n_region
             bk.payload_R = test_chain ? NRA_CHAIN_R_TEST : NRA_CHAIN_R;
             bk.R = test_chain ? NRA_CHAIN_R_TEST : (bk.ring ? NRA_RING_CHAIN_R : NRA_CHAIN_R);
         } else {
-            bk.R = kRList[bi];
+            bk.R = kRList[bk.half ? bi - kNumR - 2 : bi];
         }
         bk.pair_off = pair_tasks.size();
         bk.queue_off = queue_total;
@@ -858,9 +868,27 @@ int nra_batch1d_create(int device, const nra_region_t* regions, int32_t n_region
                 for (int32_t r : order)
                     if (dregs[pr.reads[r].region].m1 > NRA_SWEEP_RING_MAX_M) bk.ring = false;
             }
+            if (bk.half) {
+                // four reads of a region per wave: two pairs, one per half, the union of their windows
+                for (size_t i = 0; i < order.size();) {
+                    NraSweepTask t{};
+                    const int32_t g = pr.reads[order[i]].region;
+                    int32_t quad[4] = {-1, -1, -1, -1};
+                    int nq = 0;
+                    while (nq < 4 && i < order.size() && pr.reads[order[i]].region == g) quad[nq++] = order[i++];
+                    t.read_a = quad[0]; t.read_b = quad[1]; t.read_c = quad[2]; t.read_d = quad[3];
+                    t.kmin = kmin[quad[0]]; t.kmax = kmax[quad[0]];
+                    for (int j = 1; j < nq; ++j) { t.kmin = std::min(t.kmin, kmin[quad[j]]); t.kmax = std::max(t.kmax, kmax[quad[j]]); }
+                    const NraDevRegion& d = dregs[g];
+                    bk.cells_sweep += (int64_t)2 * 64 * bk.R * ((d.l1 + d.m1 * t.kmax + 31 * d.m1) + (d.l3 + 31));
+                    t.snap_off = snap_total;
+                    snap_total += (uint64_t)3 * bk.R * 64;
+                    sweep_tasks.push_back(t);
+                }
+            } else
             for (size_t i = 0; i < order.size();) {
                 NraSweepTask t{};
-                t.read_a = order[i]; t.read_b = -1;
+                t.read_a = order[i]; t.read_b = -1; t.read_c = -1; t.read_d = -1;
                 t.kmin = kmin[t.read_a]; t.kmax = kmax[t.read_a];
                 // (the int32 chained sweeps take one read per wave)
                 if (!bk.wide && i + 1 < order.size() && pr.reads[order[i + 1]].region == pr.reads[order[i]].region) {
@@ -993,6 +1021,10 @@ static int run_1d(nra_batch* b)
                                                           b->sweep_tasks.p + bk.sweep_off, b->reads.p, b->regions.p, b->pool.p,
                                                           b->q2bit.p, b->qnmask.p, b->sp, b->kmin.p, b->kmax.p, b->coff.p,
                                                           b->snap.p, b->read_a1d.p, strips, b->chain_cap, bk.n_strips));
+            else if (bk.half)
+                LAUNCH_TRY(nra_launch_sweep_ring32_bwd(bk.R, b->has_n, q, bk.n_sweep, b->sweep_tasks.p + bk.sweep_off,
+                                                       b->reads.p, b->regions.p, b->pool.p, b->q2bit.p, b->qnmask.p, b->sp,
+                                                       b->kmin.p, b->kmax.p, b->coff.p, b->snap.p, b->read_a1d.p));
             else if (bk.ring)
                 LAUNCH_TRY(nra_launch_sweep_ring_bwd(bk.R, b->has_n, q, bk.n_sweep, b->sweep_tasks.p + bk.sweep_off,
                                                      b->reads.p, b->regions.p, b->pool.p, b->q2bit.p, b->qnmask.p, b->sp,
@@ -1010,6 +1042,11 @@ static int run_1d(nra_batch* b)
                                                           b->q2bit.p, b->qnmask.p, b->sp, b->kmin.p, b->kmax.p, b->coff.p,
                                                           b->snap.p, b->read_a1d.p, b->cand_score.p, b->cand_flag.p,
                                                           strips, b->chain_cap, bk.n_strips));
+            else if (bk.half)
+                LAUNCH_TRY(nra_launch_sweep_ring32_fwd(bk.R, b->has_n, q, bk.n_sweep, b->sweep_tasks.p + bk.sweep_off,
+                                                       b->reads.p, b->regions.p, b->pool.p, b->q2bit.p, b->qnmask.p, b->sp,
+                                                       b->kmin.p, b->kmax.p, b->coff.p, b->snap.p, b->read_a1d.p,
+                                                       b->cand_score.p, b->cand_flag.p));
             else if (bk.ring)
                 LAUNCH_TRY(nra_launch_sweep_ring_fwd(bk.R, b->has_n, q, bk.n_sweep, b->sweep_tasks.p + bk.sweep_off,
                                                      b->reads.p, b->regions.p, b->pool.p, b->q2bit.p, b->qnmask.p, b->sp,

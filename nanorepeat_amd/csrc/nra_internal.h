@@ -47,6 +47,7 @@ struct NraSweepTask {
     int32_t read_a, read_b;   // read_b < 0: no second read
     int32_t kmin, kmax;
     uint64_t snap_off;        // the task's R-side snapshot (int32 index): 3 planes of R x 64 per row block
+    int32_t read_c, read_d;   // k_sweep_ring32: the second pair of the wave (lanes 32..63); < 0: none
 };
 
 // Tasks of the joint sweeps (nra_joint.hip).
@@ -174,6 +175,20 @@ int nra_launch_sweep_ring_fwd(int R, int has_n, hipStream_t st, int n_tasks, con
                               const uint32_t* q2bit, const uint32_t* qnmask, NraScoreParams sp,
                               const int32_t* kmin, const int32_t* kmax, const uint32_t* coff,
                               int32_t* snap, int32_t* read_a, int32_t* cand_score, uint8_t* cand_flag);
+
+// half-wave LDS-ring sweeps (k_sweep_ring32): reads of up to 32 * NRA_RING32_MAX_R bases, two read pairs of one
+// region per wave (32 lanes each); R from NRA_R_LIST up to NRA_RING32_MAX_R
+#define NRA_RING32_MAX_R 16
+int nra_launch_sweep_ring32_bwd(int R, int has_n, hipStream_t st, int n_tasks, const NraSweepTask* tasks,
+                                const NraDevRead* reads, const NraDevRegion* regions, const uint8_t* pool,
+                                const uint32_t* q2bit, const uint32_t* qnmask, NraScoreParams sp,
+                                const int32_t* kmin, const int32_t* kmax, const uint32_t* coff,
+                                int32_t* snap, int32_t* read_a);
+int nra_launch_sweep_ring32_fwd(int R, int has_n, hipStream_t st, int n_tasks, const NraSweepTask* tasks,
+                                const NraDevRead* reads, const NraDevRegion* regions, const uint8_t* pool,
+                                const uint32_t* q2bit, const uint32_t* qnmask, NraScoreParams sp,
+                                const int32_t* kmin, const int32_t* kmax, const uint32_t* coff,
+                                int32_t* snap, int32_t* read_a, int32_t* cand_score, uint8_t* cand_flag);
 
 // chained LDS-ring sweeps (k_sweep_ringchain): reads of more than NRA_RING_CHAIN_MIN_ROWS rows as row blocks of
 // 64 * NRA_RING_CHAIN_R; wide = 0: two reads per wave in packed int16, 1: one read per wave in int32 cells.

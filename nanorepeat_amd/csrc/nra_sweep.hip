@@ -692,6 +692,215 @@ __global__ __launch_bounds__(WAVE * SWEEP_RING_WPB) void k_sweep_ring(int n_task
 }
 
 // ------------------------------------------------------------------------------------
+// k_sweep_ring32: the LDS-ring sweep with TWO read pairs of one region per wave, 32 lanes each.
+//
+// Most real cores are a few hundred bases: k_sweep_ring then has 3 to 8 rows per lane, and what does not
+// depend on the rows -- the ~12 instructions of per-step overhead, the 63*skew columns of pipeline fill --
+// is a quarter of the work.  Here a pair occupies half a wave (rows = 32 * R): the two halves run the same
+// template (same region, the union of the four reads' windows) in lock step, each with its own ring
+// (lane 31 hands out what enters lane 0, lane 63 what enters lane 32), so the overhead is paid once for four
+// reads and the pipeline is 32*skew columns deep.
+template <int R, bool HAS_N, int DIR>
+__global__ __launch_bounds__(WAVE) void k_sweep_ring32(int n_tasks, const NraSweepTask* __restrict__ tasks,
+                                                       const NraDevRead* __restrict__ reads,
+                                                       const NraDevRegion* __restrict__ regions,
+                                                       const uint8_t* __restrict__ pool,
+                                                       const uint32_t* __restrict__ q2bit,
+                                                       const uint32_t* __restrict__ qnmask,
+                                                       NraScoreParams sp,
+                                                       const int32_t* __restrict__ kmin_arr,
+                                                       const int32_t* __restrict__ kmax_arr,
+                                                       const uint32_t* __restrict__ coff,
+                                                       int32_t* __restrict__ snap,
+                                                       int32_t* __restrict__ read_a,
+                                                       int32_t* __restrict__ cand_score,
+                                                       uint8_t* __restrict__ cand_flag)
+{
+    constexpr int SC = 2;
+    __shared__ int4 ring[SWEEP_RING_D * 64];
+    __shared__ int2 racc[64];
+    const int task = blockIdx.x;
+    if (task >= n_tasks) return;
+    const int lane = threadIdx.x;
+    const int hoff = lane & 32;                           // first lane of this lane's half
+    const int hl = lane & 31;                             // lane within the half
+    const NraSweepTask tk = tasks[task];
+    // the half's own pair (a half without reads repeats pair a/b and stores nothing)
+    const bool half_on = hoff == 0 || tk.read_c >= 0;
+    const int r0 = (hoff && tk.read_c >= 0) ? tk.read_c : tk.read_a;
+    const int r1x = (hoff && tk.read_c >= 0) ? tk.read_d : tk.read_b;
+    const bool has_b = r1x >= 0;
+    const int ra = r0, rb = has_b ? r1x : r0;
+    const NraDevRead rda = reads[ra], rdb = reads[rb];
+    const NraDevRegion rg = regions[reads[tk.read_a].region];
+    const int m = rg.m1;
+    const int flank = DIR ? rg.l1 : rg.l3;
+    const uint8_t* __restrict__ piece = pool + (DIR ? rg.p1_off : rg.pr_off);
+    const int ncols = DIR ? flank + m * tk.kmax : flank;
+    const int jfirst = DIR ? flank + m * tk.kmin - 1 : flank - 1;
+    const int skew = DIR ? m : 1;
+    const int kmin_a = kmin_arr[ra], kmax_a = kmax_arr[ra];
+    const int kmin_b = kmin_arr[rb], kmax_b = kmax_arr[rb];
+    const uint32_t coff_a = coff[ra], coff_b = coff[rb];
+    int32_t* __restrict__ snap_task = snap + tk.snap_off;
+
+    const int o1 = SC * sp.open1, o2 = SC * sp.open2;
+    const int P1 = 0x00010001;
+    const int v_floor = (BIAS - o1) * P1;
+    const int v_o1 = o1 * P1, v_e1 = SC * sp.ext1 * P1, v_o2 = o2 * P1, v_e2 = SC * sp.ext2 * P1;
+    const int NEG1 = NEGB * P1, NEG2 = 2 * NEGB * P1;
+    const int s_match = SC * sp.match + o1, s_mis = o1 - SC * sp.mismatch, s_ambi = o1 - SC * sp.ambi;
+    const int tbl_hi = s_mis | (s_ambi << 8);
+    const int tbl_mis4 = s_mis * 0x01010101, tbl_ambi4 = s_ambi * 0x01010101;
+
+    auto column_table = [&](int col) {
+        int t = tbl_mis4;
+        if (col >= 0 && col < ncols) {
+            const int code = piece[col];
+            t = code < 4 ? tbl_mis4 + ((s_match - s_mis) << (8 * code)) : tbl_ambi4;
+            if (DIR == 0 && col == flank - 1) t |= FLAG_SNAPSHOT;
+            if (DIR == 1 && col >= flank) t |= FLAG_INREP;
+        }
+        return t;
+    };
+
+    // outputs: lane 31 / 63 produce one value per boundary; each half keeps its last 32 in a lane-indexed
+    // register (rotated within the half through the LDS crossbar) and writes them 32 candidates at a time
+    int out_a = 0, out_b = 0;
+    int n_out = 0, kcur = tk.kmin;                          // wave-uniform
+    const int rot_src = (hoff | ((hl + 1) & 31)) << 2;      // ds_bpermute address: the next lane of the half
+    auto flush = [&](int n_valid) {
+        const int k = kcur - 32 + hl;
+        if (hl < 32 - n_valid || !half_on) return;
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2) {
+            if (s2 == 1 && !has_b) break;
+            const int lo_k = s2 ? kmin_b : kmin_a, hi_k = s2 ? kmax_b : kmax_a;
+            if (k < lo_k || k > hi_k) continue;
+            const uint32_t idx = (s2 ? coff_b : coff_a) + (uint32_t)(k - lo_k);
+            const int v = s2 ? out_b : out_a;
+            cand_score[idx] = v >> 2;
+            cand_flag[idx] = (uint8_t)(v & 3);
+        }
+    };
+
+    int qc[R];
+#pragma unroll
+    for (int i = 0; i < R; ++i) {
+        const int gi = hl * R + i;
+        const int ca = sweep_query_sel<HAS_N>(rda, q2bit, qnmask, gi, DIR == 0);
+        const int cb = sweep_query_sel<HAS_N>(rdb, q2bit, qnmask, gi, DIR == 0);
+        qc[i] = ca | (0x0c << 8) | (cb << 16) | (0x0c << 24);
+    }
+    int Hbo[DIR ? R : 1], Ebo[DIR ? R : 1], E2bo[DIR ? R : 1];
+    if (DIR) {
+        const int q1 = SC * (sp.open1 - sp.ext1), q2 = SC * (sp.open2 - sp.ext2);
+#pragma unroll
+        for (int i = 0; i < R; ++i) {
+            const int r = hl * R + i;
+            int h[2], e[2], e2[2];
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+                const int a = (s ? rdb.qlen : rda.qlen) - 2 - r;
+                if (a >= 0) {
+                    const int al = a / R, ai = a - al * R;      // reverse-sweep row a sits in lane al of this half
+                    const int32_t* __restrict__ p = snap_task + (size_t)ai * 64 + hoff + al;
+                    const int vh = p[0], ve = p[R * 64], ve2 = p[2 * R * 64];
+                    h[s] = (s ? half_hi(vh) : half_lo(vh)) + 2 * o1;
+                    e[s] = (s ? half_hi(ve) : half_lo(ve)) + q1;
+                    e2[s] = (s ? half_hi(ve2) : half_lo(ve2)) + q2;
+                } else { h[s] = BIAS + o1 - SC; e[s] = BIAS - SC; e2[s] = BIAS - SC; }
+            }
+            Hbo[i] = pack2(h[0], h[1]);
+            Ebo[i] = pack2(e[0], e[1]);
+            E2bo[i] = pack2(e2[0], e2[1]);
+        }
+    }
+    int Hq[R], Hq2[R], E[R], E2[R];
+#pragma unroll
+    for (int i = 0; i < R; ++i) { Hq[i] = v_floor; Hq2[i] = NEG1; E[i] = NEG1; E2[i] = NEG1; }
+
+#pragma unroll
+    for (int s = 0; s < SWEEP_RING_D; ++s) ring[s * 64 + lane] = make_int4(v_floor, NEG1, NEG1, tbl_mis4);
+    racc[lane] = make_int2(NEG2, NEG1);
+    if (hl < skew) ring[hl * 64 + hoff] = make_int4(v_floor, NEG1, NEG1, column_table(hl));
+
+    int Hup_prev = v_floor, M = BIAS * P1;
+    int feed = tbl_mis4;
+    const int nsteps = ncols + 31 * skew;                   // lanes 31 / 63 finish the last column at step ncols - 1 + 31*skew
+    const int wr = hoff | ((hl + 1) & 31);
+    int slot = 0;
+    const int a_of_a = DIR ? read_a[ra] : 0, a_of_b = DIR ? read_a[rb] : 0;
+    int phase = jfirst % m;
+    int pcnt = 0;
+    int bidx = 0;
+#pragma unroll 1
+    for (int step = 0; step < nsteps; ++step) {
+        // both halves sweep the same template: the column tables repeat with period 32 across the wave, and a
+        // full-wave rotation keeps them so
+        if ((step & 31) == 0) feed = column_table(step + skew + ((hl + 1) & 31));
+        const int4 in = ring[slot * 64 + lane];
+        int F = in.y, F2 = in.z;
+        const int tt = in.w;
+        const int floor_c = DIR == 1 ? (int)((((unsigned)tt >> 15) & (unsigned)P1) | (unsigned)v_floor) : v_floor;
+        sweep_cell<0, R, R>(Hq, Hq2, E, E2, qc, Hup_prev, F, F2, M, tt & 0x7f7f7f7f, tbl_hi, floor_c, v_e1, v_e2, v_o1, v_o2);
+        Hup_prev = in.x;
+        ring[slot * 64 + wr] = make_int4(Hq[R - 1], F, F2, tt);
+        if (hl == 31) ring[slot * 64 + hoff] = make_int4(v_floor, NEG1, NEG1, feed);
+        feed = dpp_rol1(feed);
+        if (++slot == skew) slot = 0;
+
+        if constexpr (DIR == 0) {
+            if (tt & FLAG_SNAPSHOT) sweep_snapshot<0, R, R>(Hq, E, E2, snap_task, lane);
+        } else {
+            if (pcnt == phase && step >= jfirst) {          // every lane is on a unit boundary: wave-uniform
+                const int tS = sweep_combine<0, R, R>(Hq, E, E2, Hbo, Ebo, E2bo, NEG2);
+                const int2 acc = racc[lane];
+                const int accS = pmaxi(acc.x, tS), accB = pmaxi(acc.y, M);
+                racc[wr] = make_int2(accS, accB);
+                if (hl == 31) racc[hoff] = make_int2(NEG2, NEG1);
+                if (bidx >= 31 && kcur <= tk.kmax) {        // lanes 31 and 63 are on the boundary of k = kcur
+                    int va = 0, vb = 0;
+                    if (hl == 31) {
+#pragma unroll
+                        for (int s2 = 0; s2 < 2; ++s2) {
+                            const int B = (s2 ? half_hi(accB) : half_lo(accB)) - BIAS;
+                            const int S = (s2 ? half_hi(accS) : half_lo(accS)) - 2 * BIAS;
+                            const int lo = sp.min_score > 1 ? sp.min_score : 1;
+                            const int V = imax(imax(S, B), (s2 ? a_of_b : a_of_a) + 1);
+                            const int best = V >> 1;
+                            int flag = 1;
+                            if (V & 1) flag = 0;
+                            else if ((B >> 1) >= best) flag = ((S >> 1) >= best) ? 2 : 0;
+                            const int v = ((best >= lo ? best : -1) << 2) | flag;
+                            if (s2) vb = v; else va = v;
+                        }
+                    }
+                    out_a = __builtin_amdgcn_ds_bpermute(rot_src, out_a);
+                    out_b = __builtin_amdgcn_ds_bpermute(rot_src, out_b);
+                    if (hl == 31) { out_a = va; out_b = vb; }
+                    ++kcur; ++n_out;
+                    if (n_out == 32) { flush(32); n_out = 0; }
+                }
+                ++bidx;
+            }
+            if (++pcnt == m) pcnt = 0;
+        }
+    }
+    if (DIR == 0) {
+        // A = best alignment inside R (doubled) = the maximum over every cell of the half's sweep
+#pragma unroll
+        for (int off = 16; off > 0; off >>= 1) M = pmaxi(M, __shfl_xor(M, off, 64));
+        if (hl == 0 && half_on) {
+            read_a[ra] = half_lo(M) - BIAS;
+            if (has_b) read_a[rb] = half_hi(M) - BIAS;
+        }
+    } else if (n_out > 0) {
+        flush(n_out);
+    }
+}
+
+// ------------------------------------------------------------------------------------
 // k_sweep_ringchain: the LDS-ring sweep for reads of more than NRA_RING_CHAIN_MIN_ROWS rows.
 //
 // k_sweep_ring keeps all rows of a read pair in the registers of one wave: from 28 rows per lane on that is one
@@ -1034,6 +1243,53 @@ static int launch_sweep_ringchain(int R, int has_n, int wide, hipStream_t st, in
 #undef ARGS
     return (int)hipGetLastError();
 }
+
+template <int DIR>
+static int launch_sweep_ring32(int R, int has_n, hipStream_t st, int n_tasks, const NraSweepTask* tasks,
+                               const NraDevRead* reads, const NraDevRegion* regions, const uint8_t* pool,
+                               const uint32_t* q2bit, const uint32_t* qnmask, NraScoreParams sp,
+                               const int32_t* kmin, const int32_t* kmax, const uint32_t* coff,
+                               int32_t* snap, int32_t* read_a, int32_t* cand_score, uint8_t* cand_flag)
+{
+    if (n_tasks <= 0) return 0;
+#define ARGS n_tasks, tasks, reads, regions, pool, q2bit, qnmask, sp, kmin, kmax, coff, snap, read_a, cand_score, cand_flag
+#define CASE(r)                                                                          \
+    case r:                                                                              \
+        if (has_n) k_sweep_ring32<r, true, DIR><<<n_tasks, WAVE, 0, st>>>(ARGS);         \
+        else k_sweep_ring32<r, false, DIR><<<n_tasks, WAVE, 0, st>>>(ARGS);              \
+        break;
+    switch (R) {
+        CASE(1) CASE(2) CASE(3) CASE(4) CASE(5) CASE(6) CASE(7) CASE(8) CASE(9) CASE(10) CASE(11) CASE(12) CASE(13)
+        CASE(14) CASE(15) CASE(16)
+    default: return (int)hipErrorInvalidValue;
+    }
+#undef CASE
+#undef ARGS
+    return (int)hipGetLastError();
+}
+
+#if NRA_HAS_PART(15)
+extern "C" int nra_launch_sweep_ring32_bwd(int R, int has_n, hipStream_t st, int n_tasks, const NraSweepTask* tasks,
+                                           const NraDevRead* reads, const NraDevRegion* regions, const uint8_t* pool,
+                                           const uint32_t* q2bit, const uint32_t* qnmask, NraScoreParams sp,
+                                           const int32_t* kmin, const int32_t* kmax, const uint32_t* coff,
+                                           int32_t* snap, int32_t* read_a)
+{
+    return launch_sweep_ring32<0>(R, has_n, st, n_tasks, tasks, reads, regions, pool, q2bit, qnmask, sp, kmin, kmax,
+                                  coff, snap, read_a, nullptr, nullptr);
+}
+#endif
+#if NRA_HAS_PART(16)
+extern "C" int nra_launch_sweep_ring32_fwd(int R, int has_n, hipStream_t st, int n_tasks, const NraSweepTask* tasks,
+                                           const NraDevRead* reads, const NraDevRegion* regions, const uint8_t* pool,
+                                           const uint32_t* q2bit, const uint32_t* qnmask, NraScoreParams sp,
+                                           const int32_t* kmin, const int32_t* kmax, const uint32_t* coff,
+                                           int32_t* snap, int32_t* read_a, int32_t* cand_score, uint8_t* cand_flag)
+{
+    return launch_sweep_ring32<1>(R, has_n, st, n_tasks, tasks, reads, regions, pool, q2bit, qnmask, sp, kmin, kmax,
+                                  coff, snap, read_a, cand_score, cand_flag);
+}
+#endif
 
 #if NRA_HAS_PART(13)
 extern "C" int nra_launch_sweep_ringchain_bwd(int R, int has_n, int wide, hipStream_t st, int n_tasks,

@@ -424,7 +424,7 @@ def _modes_agree(capi, oracle, d, sc_over=None):
     o = oracle.round3_1d(d["regions"], d["reads"], d["kmin"], d["kmax"], read_region=d.get("read_region"),
                          sc=oracle.default_scoring(**(sc_over or {})))
     res = {}
-    for flags in (0, capi.F_TIE_EXTENTS, capi.F_BRUTE_FORCE, capi.F_ALL_EXTENTS, capi.F_DPP_SWEEP):
+    for flags in (0, capi.F_TIE_EXTENTS, capi.F_BRUTE_FORCE, capi.F_ALL_EXTENTS, capi.F_DPP_SWEEP, capi.F_NO_HALF_WAVE):
         with capi.Batch.create_1d(d["regions"], d["reads"], d["kmin"], d["kmax"],
                                   read_region=d.get("read_region"), sc=sc_g, flags=flags) as b:
             b.run(); b.sync()
