@@ -55,7 +55,7 @@ extern "C" {
                                  longer than 3072 bases use with 1536-row blocks) */
 #define NRA_F_DPP_SWEEP    16 /* testing / comparison: sweep unchained reads with k_sweep_pk16 (DPP hand-off, combine on
                                  every step) instead of k_sweep_ring (LDS hand-off, combine on every m-th step) */
-#define NRA_F_NO_HALF_WAVE 32 /* testing / comparison: reads of up to 512 bases take one pair per wave (k_sweep_ring) instead of
+#define NRA_F_NO_HALF_WAVE 32 /* testing / comparison: reads of up to 768 bases take one pair per wave (k_sweep_ring) instead of
                                  two pairs per wave, 32 lanes each (k_sweep_ring32) */
 #define NRA_F_BRUTE_FORCE  4  /* score the K candidates of a read as K independent alignments
                                  (k_score_pk16) instead of the junction decomposition (k_sweep_pk16) */

@@ -18,7 +18,7 @@ F_TIE_EXTENTS = 2     # explicit extents DP for every top-score tie (fills cand_
 F_BRUTE_FORCE = 4     # K independent alignments per read instead of the junction decomposition
 F_TEST_CHAIN = 8      # testing only: every read in chained 128-row blocks
 F_DPP_SWEEP = 16      # testing / comparison: k_sweep_pk16 instead of k_sweep_ring for unchained reads
-F_NO_HALF_WAVE = 32   # testing / comparison: one read pair per wave also for reads of up to 512 bases
+F_NO_HALF_WAVE = 32   # testing / comparison: one read pair per wave also for reads of up to 768 bases
 
 # every symbol include/nanorepeat_amd.h declares
 EXPORTS = ("nra_abi_version", "nra_version", "nra_last_error", "nra_device_count",

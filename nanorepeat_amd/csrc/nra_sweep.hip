@@ -1260,7 +1260,7 @@ static int launch_sweep_ring32(int R, int has_n, hipStream_t st, int n_tasks, co
         break;
     switch (R) {
         CASE(1) CASE(2) CASE(3) CASE(4) CASE(5) CASE(6) CASE(7) CASE(8) CASE(9) CASE(10) CASE(11) CASE(12) CASE(13)
-        CASE(14) CASE(15) CASE(16)
+        CASE(14) CASE(15) CASE(16) CASE(18) CASE(20) CASE(22) CASE(24)
     default: return (int)hipErrorInvalidValue;
     }
 #undef CASE
