@@ -57,6 +57,8 @@ extern "C" {
                                  every step) instead of k_sweep_ring (LDS hand-off, combine on every m-th step) */
 #define NRA_F_NO_HALF_WAVE 32 /* testing / comparison: reads of up to 768 bases take one pair per wave (k_sweep_ring) instead of
                                  two pairs per wave, 32 lanes each (k_sweep_ring32) */
+#define NRA_F_NO_JOINT_PACK 64 /* testing / comparison, 2D: sweep the columns outside the scoring window in the int32 payload
+                                 cells too, instead of packed int16 cells with two reads per wave (k_joint_pk16) */
 #define NRA_F_BRUTE_FORCE  4  /* score the K candidates of a read as K independent alignments
                                  (k_score_pk16) instead of the junction decomposition (k_sweep_pk16) */
 

@@ -289,6 +289,8 @@ struct Bucket {
     bool ring = false;         // k_sweep_ring (LDS hand-off) instead of k_sweep_pk16 (DPP hand-off)
     int n_jbwd = 0;            // 2D decomposition: reverse sweeps (one per read)
     size_t jbwd_off = 0;
+    int n_jlpk = 0, n_jrpk = 0;    // ... packed sweeps of the payload-free columns of L / rev(R) (one per pair of reads)
+    size_t jlpk_off = 0, jrpk_off = 0;
     int n_probe = 0;           // 2D, chained reads: strand-probe payload tasks (two per read)
     size_t probe_off = 0;
     int64_t cells_pair = 0;    // executed cells per run, pk16
@@ -360,6 +362,16 @@ struct nra_batch {
     // only: a later cell list of the same batch reuses it (rev_strand: strand it was made for, 0 = not made)
     std::vector<int8_t> rev_strand;
     std::vector<std::pair<int32_t, int8_t>> rev_pending;    // made by the next run
+    // 2D: rows-per-lane bucket and partner of every read, fixed when the reads are packed: the packed sweeps
+    // (k_joint_pk16) take two reads per wave, and the state they leave at the end of L depends on the read and
+    // its strand only, so it is kept like the reverse sweeps (lst_strand / lst_pending)
+    std::vector<int32_t> jbucket, jpair_of;
+    std::vector<NraJointPairTask> jpairs;
+    bool jpack_l = false, jpack_r = false;
+    std::vector<int8_t> lst_strand;
+    std::vector<std::pair<int32_t, int8_t>> lst_pending;
+    DevBuf<int32_t> jlstate, jrstate;            // packed wave states at the end of L / of rev(R) outside the window
+    DevBuf<NraJointPairTask> jlpk_tasks, jrpk_tasks;
     int kind = 0;              // 1 = 1D, 2 = 2D
     int device = 0;
     int flags = 0;
@@ -1193,13 +1205,54 @@ int nra_batch2d_create_reads(int device, const nra_joint_region_t* reg, int32_t 
     b->chained_reads.assign((size_t)n_reads, 0);
     for (int32_t r = 0; r < n_reads; ++r)
         b->chained_reads[r] = pr.reads[r].qlen > NRA_MAX_QLEN_1BLOCK || max_score(sc, pr.reads[r].qlen) > kScoreCapPk16;
-    b->arena.expect(pr.q2bit.size() * 6 + (size_t)n_reads * 64 + (1u << 20));
+    b->lst_strand.assign((size_t)n_reads, 0);
+    uint64_t jpack_ints = 0;
+    {
+        // rows-per-lane bucket of every read (measured on config 3, 5000 reads, R = 13..28: folding buckets of
+        // fewer than 2048 reads into the next within 4 rows beats (1024, 2) and wider spans), and its partner
+        std::vector<std::vector<int32_t>> by_bucket((size_t)kNumR);
+        for (int32_t r = 0; r < n_reads; ++r)
+            if (pr.reads[r].qlen > 0 && !b->chained_reads[r]) by_bucket[rows_for_qlen(pr.reads[r].qlen)].push_back(r);
+        fold_small_buckets(by_bucket, 2048, 4);
+        b->jbucket.assign((size_t)n_reads, -1);
+        b->jpair_of.assign((size_t)n_reads, -1);
+        uint64_t ints = 0;
+        for (int bi = 0; bi < kNumR; ++bi) {
+            const auto& v = by_bucket[bi];
+            for (size_t i = 0; i < v.size(); i += 2) {
+                NraJointPairTask t{};
+                t.read_a = v[i]; t.read_b = i + 1 < v.size() ? v[i + 1] : -1;
+                t.state = ints;
+                ints += (uint64_t)NRA_JOINT_NPSTATE(kRList[bi]) * 64;
+                b->jpair_of[t.read_a] = (int32_t)b->jpairs.size();
+                if (t.read_b >= 0) b->jpair_of[t.read_b] = (int32_t)b->jpairs.size();
+                b->jpairs.push_back(t);
+            }
+            for (int32_t r : v) b->jbucket[r] = bi;
+        }
+        // the packed cells hold what the 1D sweeps hold (nra_pk16.h), without the doubling of the origin bit
+        const int o1 = sc->gap_open1 + sc->gap_ext1, o2 = sc->gap_open2 + sc->gap_ext2;
+        const bool fits = o1 >= sc->mismatch && o1 >= sc->sc_ambi && sc->match + o1 <= 127 && sc->gap_ext1 <= 256 &&
+                          sc->gap_ext2 <= 256 && o2 + sc->mismatch + sc->sc_ambi <= 700 &&
+                          (flags & (NRA_F_BRUTE_FORCE | NRA_F_NO_JOINT_PACK)) == 0 && ints * 4 <= (4ull << 30);
+        auto cols_ok = [&](int64_t flank) {
+            const int64_t c = NRA_JOINT_PACKED_COLS(flank);
+            return c >= NRA_JOINT_PACKED_MIN_COLS && max_score(sc, std::min<int64_t>(c, NRA_MAX_QLEN_1BLOCK)) <= 27000;
+        };
+        b->jpack_l = fits && ints > 0 && cols_ok(reg->left_len);
+        b->jpack_r = fits && ints > 0 && cols_ok(reg->right_len);
+        jpack_ints = ints;
+    }
+    b->arena.expect(pr.q2bit.size() * 6 + (size_t)n_reads * 64 + (1u << 20) +
+                    ((b->jpack_l ? jpack_ints : 0) + (b->jpack_r ? jpack_ints : 0)) * 4);
     HIP_TRY(b->q2bit.upload(pr.q2bit));
     HIP_TRY(b->qnmask.upload(pr.nmask));
     b->n_q2bit_words = pr.q2bit.size();
     b->reads_have_n = pr.has_n;
     b->host_reads = std::move(pr.reads);
     b->rev_strand.assign((size_t)n_reads, 0);
+    if (b->jpack_l) HIP_TRY(b->jlstate.alloc((size_t)jpack_ints));
+    if (b->jpack_r) HIP_TRY(b->jrstate.alloc((size_t)jpack_ints));
     HIP_TRY(b->jsnap.alloc(b->n_q2bit_words * 16 * 3));    // R side of the junction per read base: kept across cell lists
     HIP_TRY(b->jread_a.alloc((size_t)n_reads));
     rc = alloc_results(b, (size_t)n_reads, true);      // best_wscore, n_ties, sum_k, sum_k2, status, strand_out
@@ -1229,6 +1282,7 @@ int nra_batch2d_set_cells(nra_batch_t* b, const int8_t* read_strand, int64_t n_c
     b->have_cells = false;
     b->ran = false;
     b->rev_pending.clear();
+    b->lst_pending.clear();
     b->cell_arena.reset();
     ArenaScope arena_scope(&b->cell_arena);
     b->buckets.clear();
@@ -1278,20 +1332,20 @@ int nra_batch2d_set_cells(nra_batch_t* b, const int8_t* read_strand, int64_t n_c
     b->has_n = has_n ? 1 : 0;
     std::vector<NraDevRegion> dregs(1, d);
 
+    // (the rows-per-lane bucket of a read was fixed when the reads were packed)
     std::vector<std::vector<int32_t>> by_bucket((size_t)kNumR + 1);
     for (int32_t r = 0; r < n_reads; ++r) {
         if (cnt[r] == 0 || reads[r].qlen == 0) continue;
-        by_bucket[b->chained_reads[r] ? kNumR : rows_for_qlen(reads[r].qlen)].push_back(r);
+        by_bucket[b->chained_reads[r] ? kNumR : b->jbucket[r]].push_back(r);
     }
-    const std::vector<int32_t> chain_reads = by_bucket[kNumR];
-    by_bucket[kNumR].clear();
-    // measured on config 3 (5000 reads, R = 13..28): (2048, 4) beats (1024, 2) and wider spans
-    fold_small_buckets(by_bucket, 2048, 4);
-    by_bucket[kNumR] = chain_reads;            // (not folded)
+    const std::vector<int32_t>& chain_reads = by_bucket[kNumR];
     std::vector<NraPairTask> pair_tasks;
     std::vector<NraTask> queue_tasks, probe_tasks;
     std::vector<int32_t> queue_count, probe_count;
     std::vector<NraJointTask> jbwd, jpre, jtail;
+    std::vector<NraJointPairTask> jlpk, jrpk;
+    std::vector<uint8_t> pair_l((size_t)b->jpairs.size(), 0), pair_r((size_t)b->jpairs.size(), 0);
+    const int colsL = NRA_JOINT_PACKED_COLS(left_len), colsR = NRA_JOINT_PACKED_COLS(right_len);
     std::vector<int32_t> k1list;
     // junction decomposition needs a base left of the window and two bases of R
     b->brute = (flags & NRA_F_BRUTE_FORCE) != 0 || left_len < 1 || right_len < 2;
@@ -1313,6 +1367,7 @@ int nra_batch2d_set_cells(nra_batch_t* b, const int8_t* read_strand, int64_t n_c
         bk.pair_off = pair_tasks.size();
         bk.queue_off = queue_tasks.size();
         bk.jbwd_off = jbwd.size();
+        bk.jlpk_off = jlpk.size(); bk.jrpk_off = jrpk.size();
         bk.probe_off = probe_tasks.size();
         const bool per_cell = b->brute || bk.chain;      // one DP per (read, cell) instead of the joint sweeps
         const uint64_t slot = (uint64_t)NRA_JOINT_NSTATE(bk.R) * 64;
@@ -1325,10 +1380,16 @@ int nra_batch2d_set_cells(nra_batch_t* b, const int8_t* read_strand, int64_t n_c
                 // leaves the wave state at each of the read's k1 values; one tail sweep per run of cells
                 // with the same k1 and k2 in arithmetic progression (how the grid rounds list them)
                 const int8_t given = read_strand ? read_strand[r] : 0;
+                const int32_t pi = b->jpair_of[r];
+                const NraJointPairTask& pair = b->jpairs[(size_t)pi];
                 if (given == 0 || b->rev_strand[r] != given) {      // not made yet (or for the other strand)
                     NraJointTask tb{}; tb.read = r; tb.k2step = 1; tb.n2 = 1;
+                    if (b->jpack_r) {
+                        tb.resume = 1; tb.pstate = pair.state; tb.phalf = pair.read_b == r ? 1 : 0;
+                        if (!pair_r[pi]) { pair_r[pi] = 1; jrpk.push_back(pair); bk.cells_sweep += (int64_t)2 * 64 * bk.R * colsR; }
+                    }
                     jbwd.push_back(tb);
-                    bk.cells_sweep += sweep_cells(bk.R, d.l3);
+                    bk.cells_sweep += sweep_cells(bk.R, d.l3 - (b->jpack_r ? colsR : 0));
                     b->rev_strand[r] = 0;
                     b->rev_pending.push_back({r, given});
                 }
@@ -1343,8 +1404,20 @@ int nra_batch2d_set_cells(nra_batch_t* b, const int8_t* read_strand, int64_t n_c
                 }
                 NraJointTask tp{}; tp.read = r; tp.k1_off = (int32_t)k1list.size(); tp.nk1 = (int32_t)ks.size();
                 tp.state = used; tp.k2step = 1;
+                if (b->jpack_l) {
+                    // the L side up to the window: swept once per pair and strand, kept for later cell lists
+                    tp.resume = 1; tp.pstate = pair.state; tp.phalf = pair.read_b == r ? 1 : 0;
+                    if ((given == 0 || b->lst_strand[r] != given) && !pair_l[pi]) {
+                        pair_l[pi] = 1; jlpk.push_back(pair); bk.cells_sweep += (int64_t)2 * 64 * bk.R * colsL;
+                        for (int32_t q : {pair.read_a, pair.read_b}) {
+                            if (q < 0) continue;
+                            b->lst_strand[q] = 0;
+                            b->lst_pending.push_back({q, read_strand ? read_strand[q] : (int8_t)0});
+                        }
+                    }
+                }
                 jpre.push_back(tp);
-                bk.cells_sweep += (int64_t)64 * bk.R * (d.l1 + d.m1 * ks.back() - 1);
+                bk.cells_sweep += (int64_t)64 * bk.R * (d.l1 + d.m1 * ks.back() - 1 - (b->jpack_l ? colsL : 0));
                 for (uint32_t c = first[r]; c < first[r] + cnt[r];) {
                     NraJointTask t{}; t.read = r; t.k1 = cell_k1[c]; t.k2lo = cell_k2[c]; t.k2step = 1; t.n2 = 1;
                     t.out = (int32_t)c;
@@ -1400,6 +1473,8 @@ int nra_batch2d_set_cells(nra_batch_t* b, const int8_t* read_strand, int64_t n_c
         bk.n_pair = (int)(pair_tasks.size() - bk.pair_off);
         bk.n_queue = (int)(queue_tasks.size() - bk.queue_off);
         bk.n_jbwd = (int)(jbwd.size() - bk.jbwd_off);
+        bk.n_jlpk = (int)(jlpk.size() - bk.jlpk_off);
+        bk.n_jrpk = (int)(jrpk.size() - bk.jrpk_off);
         bk.n_probe = (int)(probe_tasks.size() - bk.probe_off);
         bk.queue_cap = (size_t)bk.n_queue;
         queue_count.push_back(bk.n_queue);
@@ -1412,6 +1487,7 @@ int nra_batch2d_set_cells(nra_batch_t* b, const int8_t* read_strand, int64_t n_c
     // one chunk for everything but the wave states, which get their own (all of it reused by the next cell list)
     b->cell_arena.expect(b->n_q2bit_words * 16 * 13 + (size_t)n_cells * 20 + pool.size() + (size_t)n_reads * 128 +
                          (jbwd.size() + jpre.size() + jtail.size()) * sizeof(NraJointTask) + k1list.size() * 4 +
+                         (jlpk.size() + jrpk.size()) * sizeof(NraJointPairTask) +
                          queue_tasks.size() * sizeof(NraTask) + (4u << 20));
     HIP_TRY(b->pool.upload(pool));
     HIP_TRY(b->regions.upload(dregs));
@@ -1431,6 +1507,8 @@ int nra_batch2d_set_cells(nra_batch_t* b, const int8_t* read_strand, int64_t n_c
         HIP_TRY(b->jbwd_tasks.upload(jbwd));
         HIP_TRY(b->jpre_tasks.upload(jpre));
         HIP_TRY(b->jtail_tasks.upload(jtail));
+        HIP_TRY(b->jlpk_tasks.upload(jlpk));
+        HIP_TRY(b->jrpk_tasks.upload(jrpk));
         HIP_TRY(b->jk1list.upload(k1list));
         HIP_TRY(b->jstate.alloc((size_t)state_base));
     }
@@ -1451,7 +1529,7 @@ int nra_batch2d_set_cells(nra_batch_t* b, const int8_t* read_strand, int64_t n_c
     clk.mark("2D cells: device buffers, H2D");
     // events and streams: kept from one cell list to the next, more taken from the pool when needed
     {
-        const size_t n_ev = 2 + 6 * nb + 4 * b->jgroups.size() + 2;
+        const size_t n_ev = 2 + 10 * nb + 4 * b->jgroups.size() + 2;
         while (b->ev.size() < n_ev) { hipEvent_t e; HIP_TRY(g_handles.event(b->device, true, &e)); b->ev.push_back(e); }
         // two streams per bucket: the buckets' chains overlap, and so do a bucket's reverse and prefix sweeps
         while (b->bstreams.size() < 2 * nb) { hipStream_t q; HIP_TRY(g_handles.stream(b->device, &q)); b->bstreams.push_back(q); }
@@ -1464,7 +1542,9 @@ int nra_batch2d_set_cells(nra_batch_t* b, const int8_t* read_strand, int64_t n_c
     for (const Bucket& bk : b->buckets) ex += bk.cells_pair + bk.cells_queue + bk.cells_sweep;
     b->stats.executed_cells = ex;
     b->stats.algorithmic_bytes = (int64_t)b->n_q2bit_words * 4 + (int64_t)pool.size() + n_cells * 8 + (int64_t)n_reads * 25;
-    b->stats.intermediate_bytes = b->brute ? 0 : 2 * ((int64_t)state_base * 4 + (int64_t)b->n_q2bit_words * 16 * 3 * 4);
+    int64_t packed_ints = 0;
+    for (const Bucket& bk : b->buckets) packed_ints += (int64_t)(bk.n_jlpk + bk.n_jrpk) * NRA_JOINT_NPSTATE(bk.R) * 64;
+    b->stats.intermediate_bytes = b->brute ? 0 : 2 * ((int64_t)state_base * 4 + (int64_t)b->n_q2bit_words * 16 * 3 * 4 + packed_ints * 4);
     b->have_cells = true;
     return NRA_OK;
 }
@@ -1475,6 +1555,7 @@ int nra_batch2d_invalidate(nra_batch_t* b)
 {
     if (!b || b->kind != 2) return fail(NRA_E_ARG, "not a 2D batch");
     std::fill(b->rev_strand.begin(), b->rev_strand.end(), (int8_t)0);
+    std::fill(b->lst_strand.begin(), b->lst_strand.end(), (int8_t)0);
     return NRA_OK;
 }
 
@@ -1562,10 +1643,24 @@ static int run_2d(nra_batch* b)
             hipStream_t qa = b->bstreams[2 * i], qb = b->bstreams[2 * i + 1];
             HIP_TRY(hipStreamWaitEvent(qa, b->fork2_ev, 0));
             HIP_TRY(hipStreamWaitEvent(qb, b->fork2_ev, 0));
+            if (bk.n_jrpk > 0) {
+                HIP_TRY(hipEventRecord(b->ev[ev++], qa));
+                LAUNCH_TRY(nra_launch_joint_pk16(bk.R, b->has_n, qa, bk.n_jrpk, b->jrpk_tasks.p + bk.jrpk_off, b->reads.p,
+                                                 b->regions.p, b->pool.p, b->q2bit.p, b->qnmask.p, b->sp, 0, b->jrstate.p));
+                HIP_TRY(hipEventRecord(b->ev[ev++], qa));
+                b->n_score_ev++;
+            }
+            if (bk.n_jlpk > 0) {
+                HIP_TRY(hipEventRecord(b->ev[ev++], qb));
+                LAUNCH_TRY(nra_launch_joint_pk16(bk.R, b->has_n, qb, bk.n_jlpk, b->jlpk_tasks.p + bk.jlpk_off, b->reads.p,
+                                                 b->regions.p, b->pool.p, b->q2bit.p, b->qnmask.p, b->sp, 1, b->jlstate.p));
+                HIP_TRY(hipEventRecord(b->ev[ev++], qb));
+                b->n_score_ev++;
+            }
             HIP_TRY(hipEventRecord(b->ev[ev++], qa));
             LAUNCH_TRY(nra_launch_joint_bwd(bk.R, b->has_n, qa, bk.n_jbwd, b->jbwd_tasks.p + bk.jbwd_off,
                                             b->reads.p, b->regions.p, b->pool.p, b->q2bit.p, b->qnmask.p,
-                                            b->sp, b->jsnap.p, b->jread_a.p));
+                                            b->sp, b->jsnap.p, b->jread_a.p, b->jrstate.p));
             HIP_TRY(hipEventRecord(b->ev[ev++], qa));
             b->n_score_ev++;
             HIP_TRY(hipEventRecord(b->bdone[3 * i], qa));
@@ -1576,7 +1671,7 @@ static int run_2d(nra_batch* b)
                 HIP_TRY(hipEventRecord(b->ev[ev++], qb));
                 LAUNCH_TRY(nra_launch_joint_prefix(g.R, b->has_n, qb, g.n_pre, b->jpre_tasks.p + g.pre_off,
                                                    b->reads.p, b->regions.p, b->pool.p, b->q2bit.p, b->qnmask.p,
-                                                   b->sp, b->jk1list.p, b->jstate.p));
+                                                   b->sp, b->jk1list.p, b->jstate.p, b->jlstate.p));
                 HIP_TRY(hipEventRecord(b->ev[ev++], qb));
                 b->n_score_ev++;
                 if (first) HIP_TRY(hipStreamWaitEvent(qb, b->bdone[3 * i], 0));     // the tails read the R side
@@ -1597,6 +1692,8 @@ static int run_2d(nra_batch* b)
     // a probed strand is not known on the host)
     for (const auto& pr2 : b->rev_pending) b->rev_strand[(size_t)pr2.first] = pr2.second;
     b->rev_pending.clear();
+    for (const auto& pr2 : b->lst_pending) b->lst_strand[(size_t)pr2.first] = pr2.second;
+    b->lst_pending.clear();
     HIP_TRY(hipEventRecord(b->phase_ev[1], st));
     LAUNCH_TRY(nra_launch_select_2d(st, b->n_reads, b->cell_first.p, b->cell_cnt.p, b->cell_k1.p, b->cell_k2.p,
                                     b->cand_score.p, b->cand_tstart.p, b->best_score.p, b->sum_k.p,

@@ -57,6 +57,8 @@ struct NraSweepTask {
 //   prefix sweep: one per read; its nk1 distinct k1 values, ascending, start at k1list[k1_off];
 //     state of the i-th goes to state + i * (3R+7) * 64;
 //   reverse sweep over R: one per read, only `read` is used.
+//   resume != 0 (reverse and prefix sweeps): the first NRA_JOINT_PACKED_COLS columns were swept by k_joint_pk16;
+//     the wave state it left is at pstate (index into the packed-state buffer), this read in half `phalf`.
 struct NraJointTask {
     int32_t read;
     int32_t k1;
@@ -64,7 +66,22 @@ struct NraJointTask {
     int32_t out;
     int32_t k1_off, nk1;
     uint64_t state;
+    uint64_t pstate;
+    int32_t phalf, resume;
 };
+
+// Two reads of one rows-per-lane bucket whose payload-free columns -- L up to the scoring window, or rev(R) up to
+// it -- are swept together in packed int16 cells (k_joint_pk16); the wave state goes to `state` (index into the
+// packed-state buffer): NRA_JOINT_NPSTATE(R) planes of 64 dwords, both reads in the halves of every dword.
+struct NraJointPairTask {
+    int32_t read_a, read_b;   // read_b < 0: no second read
+    uint64_t state;
+};
+#define NRA_JOINT_NPSTATE(R) (3 * (R) + 4)     // Hq, E_in, E2_in per row; diagonal, F, F2, running maximum
+// columns without window payload at the start of a joint sweep: the window takes the last 10 bases of L
+// (forward, dir 1) and the first 10 of R (the reverse sweep reads R backwards, dir 0)
+#define NRA_JOINT_PACKED_COLS(flank) ((flank) > 10 ? (flank) - 10 : 0)
+#define NRA_JOINT_PACKED_MIN_COLS 64           // shorter stretches stay in the int32 sweep
 
 // One (query, target) pair whose path is wanted (nra_trace.hip).
 struct NraTraceTask {
@@ -214,11 +231,16 @@ int nra_launch_sweep_ringchain_fwd(int R, int has_n, int wide, hipStream_t st, i
 int nra_launch_joint_bwd(int R, int has_n, hipStream_t st, int n_tasks, const NraJointTask* tasks,
                          const NraDevRead* reads, const NraDevRegion* regions, const uint8_t* pool,
                          const uint32_t* q2bit, const uint32_t* qnmask, NraScoreParams sp,
-                         int32_t* snap, int32_t* read_a);
+                         int32_t* snap, int32_t* read_a, const int32_t* pstate);
 int nra_launch_joint_prefix(int R, int has_n, hipStream_t st, int n_tasks, const NraJointTask* tasks,
                             const NraDevRead* reads, const NraDevRegion* regions, const uint8_t* pool,
                             const uint32_t* q2bit, const uint32_t* qnmask, NraScoreParams sp,
-                            const int32_t* k1list, int32_t* state);
+                            const int32_t* k1list, int32_t* state, const int32_t* pstate);
+// packed int16 sweep of the payload-free columns (dir 1: L, dir 0: rev(R)), two reads per wave
+int nra_launch_joint_pk16(int R, int has_n, hipStream_t st, int n_tasks, const NraJointPairTask* tasks,
+                          const NraDevRead* reads, const NraDevRegion* regions, const uint8_t* pool,
+                          const uint32_t* q2bit, const uint32_t* qnmask, NraScoreParams sp, int dir,
+                          int32_t* pstate);
 int nra_launch_joint_tail(int R, int has_n, hipStream_t st, int n_tasks, const NraJointTask* tasks,
                           const NraDevRead* reads, const NraDevRegion* regions, const uint8_t* pool,
                           const uint32_t* q2bit, const uint32_t* qnmask, NraScoreParams sp,

@@ -33,9 +33,17 @@
 //     that last column followed by mid + u2^k2hi -- bit for bit the uninterrupted sweep over
 //     L + u1^k1 + mid + u2^k2hi, for 1 + |mid| + m2*k2hi + 63 steps instead of all of them.
 //
+// Columns without window payload.  The window takes the last 10 bases of L and the first 10 of R; before
+// it every cell's payload is the constant 0, so the first |L| - 10 columns of the prefix sweep and the first
+// |R| - 10 of the reverse sweep are plain score cells: k_joint_pk16 sweeps them in packed int16, TWO reads per
+// wave at 15.5 instead of 2 x 20 instructions per row and column (the cell of the 1D sweeps, nra_pk16.h, no
+// origin bit), and leaves the wave state -- every lane's rows and hand-off values as they stand when lane 0 is
+// about to take the first window column -- for the int32 sweep of each read to resume from (`resume`).  The
+// L side depends on the read alone, not on the cell list: it is kept from one grid round to the next.
+//
 // Preconditions checked on the host (else the cell goes to the brute-force kernel):
 // |L| >= 1, |R| >= 2, the k2 values of a (read, k1) form an arithmetic progression.
-#include "nra_device.h"
+#include "nra_pk16.h"
 
 #ifndef NRA_PART
 #define NRA_PART 0
@@ -85,7 +93,8 @@ __global__ __launch_bounds__(WAVE, joint_waves(R, DIR)) void k_joint_sweep(int n
                                                       int32_t* __restrict__ snap,      // 3 x int32 per read base
                                                       int32_t* __restrict__ read_a,    // A per read (packed)
                                                       int32_t* __restrict__ cell_score,
-                                                      int32_t* __restrict__ cell_wscore)
+                                                      int32_t* __restrict__ cell_wscore,
+                                                      const int32_t* __restrict__ pstate)   // DIR 0 / 1: packed states
 {
     const int task = blockIdx.x;
     if (task >= n_tasks) return;
@@ -169,15 +178,42 @@ __global__ __launch_bounds__(WAVE, joint_waves(R, DIR)) void k_joint_sweep(int n
         accB = sv[(size_t)(3 * R + 5) * 64]; tt = sv[(size_t)(3 * R + 6) * 64];
     }
 
+    // resume behind k_joint_pk16: lane l has finished column step0 - 1 - l; values are (score + BIAS) halves,
+    // H is stored minus the gap open (nra_pk16.h), the accumulator chains start empty (no boundary before step0)
+    int step0 = 0;
+    if (DIR != 2) {
+        if (tk.resume) {
+            step0 = NRA_JOINT_PACKED_COLS(DIR ? rg.l1 : lenR);
+            const int32_t* __restrict__ pv = pstate + tk.pstate + lane;
+            const int hi = tk.phalf;
+            const int O1 = sp.open1 << 16;
+            auto cell_of = [&](int v) { return (((hi ? half_hi(v) : half_lo(v)) - BIAS) << 16) + JBIAS; };
+#pragma unroll
+            for (int i = 0; i < R; ++i) {
+                Hprev[i] = cell_of(pv[(size_t)i * 64]) + O1;
+                E[i] = cell_of(pv[(size_t)(R + i) * 64]);
+                E2[i] = cell_of(pv[(size_t)(2 * R + i) * 64]);
+            }
+            Hup_prev = cell_of(pv[(size_t)(3 * R) * 64]) + O1;
+            Fout = cell_of(pv[(size_t)(3 * R + 1) * 64]);
+            F2out = cell_of(pv[(size_t)(3 * R + 2) * 64]);
+            M = cell_of(pv[(size_t)(3 * R + 3) * 64]);
+            Hbot = Hprev[R - 1];
+            const int col = step0 - 1 - lane;
+            tt = col >= 0 ? (int)p1[col] : NRA_PAD_T;
+            j = step0 - lane;
+        }
+    }
+
     // DIR 0 / 2 drain the pipeline (ncols + 63 steps); DIR 1 leaves at its last dump (step t_last)
     // One flat step loop (a chunk loop around a 64-step loop made the compiler keep two copies of
     // the row registers).  Every 64 steps the lanes fetch the next 64 template columns.
-    const int nsteps = DIR == 1 ? ncols + 1 : ((ncols + 63 + 63) >> 6) << 6;
+    const int nsteps = DIR == 1 ? ncols + 1 : step0 + (((ncols - step0 + 63 + 63) >> 6) << 6);
     int feed = NRA_PAD_T;
 #pragma unroll 1   // unrolling the step loop twice takes minutes to compile at R >= 20
-    for (int step = 0; step < nsteps; ++step) {
+    for (int step = step0; step < nsteps; ++step) {
         {
-            if ((step & 63) == 0) {
+            if (((step - step0) & 63) == 0) {
                 const int col = step + lane;
                 feed = NRA_PAD_T;
                 if (col < ncols) {
@@ -312,18 +348,99 @@ __global__ __launch_bounds__(WAVE, joint_waves(R, DIR)) void k_joint_sweep(int n
 }
 
 // ------------------------------------------------------------------------------------
+// k_joint_pk16: the payload-free columns of a prefix (dir 1) or reverse (dir 0) sweep, two reads per wave in
+// packed int16 cells.  One systolic cell per lane, skew 1, lane-to-lane hand-off through a one-slot LDS ring
+// (k_sweep_ring's, nra_sweep.hip).  Runs exactly `cols` steps: lane l ends on column cols - 1 - l.
+template <int R, bool HAS_N>
+__global__ __launch_bounds__(WAVE) void k_joint_pk16(int n_tasks, const NraJointPairTask* __restrict__ tasks,
+                                                     const NraDevRead* __restrict__ reads,
+                                                     const NraDevRegion* __restrict__ regions,
+                                                     const uint8_t* __restrict__ pool,
+                                                     const uint32_t* __restrict__ q2bit,
+                                                     const uint32_t* __restrict__ qnmask,
+                                                     NraScoreParams sp, int dir,
+                                                     int32_t* __restrict__ pstate)
+{
+    __shared__ int4 ring[64];
+    const int task = blockIdx.x;
+    if (task >= n_tasks) return;
+    const int lane = threadIdx.x;
+    const NraJointPairTask tk = tasks[task];
+    const int ra = tk.read_a, rb = tk.read_b >= 0 ? tk.read_b : tk.read_a;
+    const NraDevRead rda = reads[ra], rdb = reads[rb];
+    const NraDevRegion rg = regions[rda.region];
+    const uint8_t* __restrict__ piece = pool + (dir ? rg.p1_off : rg.pr_off);
+    const int cols = NRA_JOINT_PACKED_COLS(dir ? rg.l1 : rg.l3);
+
+    const int o1 = sp.open1, o2 = sp.open2;
+    const int P1 = 0x00010001;
+    const int v_floor = (BIAS - o1) * P1;
+    const int v_o1 = o1 * P1, v_e1 = sp.ext1 * P1, v_o2 = o2 * P1, v_e2 = sp.ext2 * P1;
+    const int NEG1 = NEGB * P1;
+    // substitution scores + o1 (the diagonal is read from Hq = H - o1): all in [0, 127] (host: joint_pack_ok)
+    const int s_match = sp.match + o1, s_mis = o1 - sp.mismatch, s_ambi = o1 - sp.ambi;
+    const int tbl_hi = s_mis | (s_ambi << 8);               // selector 4: padding row, 5: N in the read
+    const int tbl_mis4 = s_mis * 0x01010101, tbl_ambi4 = s_ambi * 0x01010101;
+    auto column_table = [&](int col) {
+        int t = tbl_mis4;
+        if (col >= 0 && col < cols) {
+            const int code = piece[col];
+            t = code < 4 ? tbl_mis4 + ((s_match - s_mis) << (8 * code)) : tbl_ambi4;
+        }
+        return t;
+    };
+    auto selector = [&](const NraDevRead& rd, int r) {
+        const int c = oriented_code<HAS_N>(rd, q2bit, qnmask, dir ? r : (r < rd.qlen ? rd.qlen - 1 - r : -1));
+        return c == NRA_PAD_Q ? 4 : (c == NRA_CODE_N ? 5 : c);
+    };
+    int qc[R];
+#pragma unroll
+    for (int i = 0; i < R; ++i)
+        qc[i] = selector(rda, lane * R + i) | (0x0c << 8) | (selector(rdb, lane * R + i) << 16) | (0x0c << 24);
+
+    int Hq[R], Hq2[R], E[R], E2[R];
+#pragma unroll
+    for (int i = 0; i < R; ++i) { Hq[i] = v_floor; Hq2[i] = NEG1; E[i] = NEG1; E2[i] = NEG1; }
+    ring[lane] = make_int4(v_floor, NEG1, NEG1, lane == 0 ? column_table(0) : tbl_mis4);
+
+    int Hup_prev = v_floor, M = BIAS * P1;
+    int F = NEG1, F2 = NEG1;
+    int feed = tbl_mis4;
+    const int wr = (lane + 1) & 63;
+#pragma unroll 1
+    for (int step = 0; step < cols; ++step) {
+        if ((step & 63) == 0) feed = column_table(step + 1 + wr);      // lane 63 hands out column step + 1
+        const int4 in = ring[lane];
+        F = in.y; F2 = in.z;
+        sweep_cell<0, R, R>(Hq, Hq2, E, E2, qc, Hup_prev, F, F2, M, in.w, tbl_hi, v_floor, v_e1, v_e2, v_o1, v_o2);
+        Hup_prev = in.x;
+        ring[wr] = make_int4(Hq[R - 1], F, F2, in.w);
+        if (lane == 63) ring[0] = make_int4(v_floor, NEG1, NEG1, feed);
+        feed = dpp_rol1(feed);
+    }
+    int32_t* __restrict__ pv = pstate + tk.state + lane;
+#pragma unroll
+    for (int i = 0; i < R; ++i) {
+        pv[(size_t)i * 64] = Hq[i]; pv[(size_t)(R + i) * 64] = E[i]; pv[(size_t)(2 * R + i) * 64] = E2[i];
+    }
+    pv[(size_t)(3 * R) * 64] = Hup_prev; pv[(size_t)(3 * R + 1) * 64] = F; pv[(size_t)(3 * R + 2) * 64] = F2;
+    pv[(size_t)(3 * R + 3) * 64] = M;
+}
+
+// ------------------------------------------------------------------------------------
 template <int DIR>
 static int launch_joint(int R, int has_n, hipStream_t st, int n_tasks, const NraJointTask* tasks,
                         const NraDevRead* reads, const NraDevRegion* regions, const uint8_t* pool,
                         const uint32_t* q2bit, const uint32_t* qnmask, NraScoreParams sp,
                         const int32_t* k1list, int32_t* state,
-                        int32_t* snap, int32_t* read_a, int32_t* cell_score, int32_t* cell_wscore)
+                        int32_t* snap, int32_t* read_a, int32_t* cell_score, int32_t* cell_wscore,
+                        const int32_t* pstate)
 {
     if (n_tasks <= 0) return 0;
 #define CASE(r)                                                                                     \
     case r:                                                                                         \
-        if (has_n) k_joint_sweep<r, true, DIR><<<n_tasks, WAVE, 0, st>>>(n_tasks, tasks, reads, regions, pool, q2bit, qnmask, sp, k1list, state, snap, read_a, cell_score, cell_wscore); \
-        else k_joint_sweep<r, false, DIR><<<n_tasks, WAVE, 0, st>>>(n_tasks, tasks, reads, regions, pool, q2bit, qnmask, sp, k1list, state, snap, read_a, cell_score, cell_wscore);       \
+        if (has_n) k_joint_sweep<r, true, DIR><<<n_tasks, WAVE, 0, st>>>(n_tasks, tasks, reads, regions, pool, q2bit, qnmask, sp, k1list, state, snap, read_a, cell_score, cell_wscore, pstate); \
+        else k_joint_sweep<r, false, DIR><<<n_tasks, WAVE, 0, st>>>(n_tasks, tasks, reads, regions, pool, q2bit, qnmask, sp, k1list, state, snap, read_a, cell_score, cell_wscore, pstate);       \
         break;
     switch (R) {
         NRA_R_LIST(CASE)
@@ -337,20 +454,20 @@ static int launch_joint(int R, int has_n, hipStream_t st, int n_tasks, const Nra
 extern "C" int nra_launch_joint_bwd(int R, int has_n, hipStream_t st, int n_tasks, const NraJointTask* tasks,
                                     const NraDevRead* reads, const NraDevRegion* regions, const uint8_t* pool,
                                     const uint32_t* q2bit, const uint32_t* qnmask, NraScoreParams sp,
-                                    int32_t* snap, int32_t* read_a)
+                                    int32_t* snap, int32_t* read_a, const int32_t* pstate)
 {
     return launch_joint<0>(R, has_n, st, n_tasks, tasks, reads, regions, pool, q2bit, qnmask, sp, nullptr, nullptr,
-                           snap, read_a, nullptr, nullptr);
+                           snap, read_a, nullptr, nullptr, pstate);
 }
 #endif
 #if NRA_HAS_PART(8)
 extern "C" int nra_launch_joint_prefix(int R, int has_n, hipStream_t st, int n_tasks, const NraJointTask* tasks,
                                        const NraDevRead* reads, const NraDevRegion* regions, const uint8_t* pool,
                                        const uint32_t* q2bit, const uint32_t* qnmask, NraScoreParams sp,
-                                       const int32_t* k1list, int32_t* state)
+                                       const int32_t* k1list, int32_t* state, const int32_t* pstate)
 {
     return launch_joint<1>(R, has_n, st, n_tasks, tasks, reads, regions, pool, q2bit, qnmask, sp, k1list, state,
-                           nullptr, nullptr, nullptr, nullptr);
+                           nullptr, nullptr, nullptr, nullptr, pstate);
 }
 #endif
 #if NRA_HAS_PART(10)
@@ -361,6 +478,26 @@ extern "C" int nra_launch_joint_tail(int R, int has_n, hipStream_t st, int n_tas
                                      int32_t* cell_wscore)
 {
     return launch_joint<2>(R, has_n, st, n_tasks, tasks, reads, regions, pool, q2bit, qnmask, sp, nullptr, state,
-                           snap, read_a, cell_score, cell_wscore);
+                           snap, read_a, cell_score, cell_wscore, nullptr);
+}
+#endif
+#if NRA_HAS_PART(17)
+extern "C" int nra_launch_joint_pk16(int R, int has_n, hipStream_t st, int n_tasks, const NraJointPairTask* tasks,
+                                     const NraDevRead* reads, const NraDevRegion* regions, const uint8_t* pool,
+                                     const uint32_t* q2bit, const uint32_t* qnmask, NraScoreParams sp, int dir,
+                                     int32_t* pstate)
+{
+    if (n_tasks <= 0) return 0;
+#define CASE(r)                                                                                     \
+    case r:                                                                                         \
+        if (has_n) k_joint_pk16<r, true><<<n_tasks, WAVE, 0, st>>>(n_tasks, tasks, reads, regions, pool, q2bit, qnmask, sp, dir, pstate); \
+        else k_joint_pk16<r, false><<<n_tasks, WAVE, 0, st>>>(n_tasks, tasks, reads, regions, pool, q2bit, qnmask, sp, dir, pstate);       \
+        break;
+    switch (R) {
+        NRA_R_LIST(CASE)
+    default: return (int)hipErrorInvalidValue;
+    }
+#undef CASE
+    return (int)hipGetLastError();
 }
 #endif

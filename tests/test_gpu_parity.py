@@ -365,6 +365,40 @@ def test_joint_resident_reads_across_cell_lists(capi, oracle):
                 assert np.array_equal(np.asarray(one[key])[sel], np.asarray(o[key])[sel]), (step, shift, key)
 
 
+def test_joint_packed_flank_sweeps(capi, oracle):
+    """The columns of L and rev(R) outside the scoring window are swept in packed int16 cells, two reads per
+    wave, and the int32 sweeps resume from the state they leave: flanks just below / at / above the 64-column
+    threshold, N in flanks and reads, an odd number of reads, several row buckets, a scoring scheme the packed
+    cells cannot hold (falls back to int32 cells)."""
+    rng = np.random.default_rng(97)
+    u1, u2, mid = "CAG", "CCG", "CAACAGCCGCCAC"
+    for fl, fr, sc_over in ((73, 300, None), (74, 74, None), (200, 90, None), (150, 150, dict(mismatch=9)),
+                            (300, 120, dict(match=3, gap_open2=30))):
+        L, R = synth.rand_seq(rng, fl), synth.rand_seq(rng, fr)
+        if fl >= 150:
+            L = L[:40] + "N" + L[41:120] + "NN" + L[122:]
+        reads, cr, k1, k2 = [], [], [], []
+        for r in range(7):
+            a, b = int(rng.integers(3, 20)), int(rng.integers(2, 9))
+            cut_l, cut_r = int(rng.integers(0, fl // 2)), int(rng.integers(0, fr // 2))
+            s = synth.apply_errors(rng, L[cut_l:] + u1 * a + mid + u2 * b + R[:fr - cut_r], "ont")
+            if r == 2:
+                s = s[:30] + "N" + s[31:]
+            if r == 5:
+                s = synth.rand_seq(rng, 900) + s              # another rows-per-lane bucket
+            if rng.random() < 0.5:
+                s = synth.revcomp(s)
+            reads.append(s)
+            for x in range(max(0, a - 3), a + 3):
+                for y in range(max(0, b - 2), b + 3, 2):
+                    cr.append(r); k1.append(x); k2.append(y)
+        o = oracle.joint_2d((L, u1, mid, u2, R), reads, cr, k1, k2, sc=oracle.default_scoring(**(sc_over or {})))
+        for flags in (0, capi.F_NO_JOINT_PACK):
+            g = capi.joint_2d((L, u1, mid, u2, R), reads, cr, k1, k2, sc=capi.default_scoring(**(sc_over or {})), flags=flags)
+            for k in KEYS_2D:
+                assert np.array_equal(g[k], o[k]), (fl, fr, flags, k, np.nonzero(g[k] != o[k])[0][:8])
+
+
 def test_more_chained_tasks_than_scratch_strips(capi, oracle):
     """A chained launch has one wave per scratch strip and walks its tasks with a grid stride: 9000 small reads
     in forced chained blocks (NRA_F_TEST_CHAIN) are 4500 packed LDS-ring tasks (> 4096 strips) and, with the
@@ -603,7 +637,7 @@ def test_2d_decomposition_matches_oracle_and_brute_force(capi, oracle):
         j = synth.make_joint(8, alleles=alleles, read_len=500 if anchor < 1000 else 800, read_sd=30, anchor=anchor, seed=seed)
         cr, k1, k2 = _cells(j, step=2)
         o = oracle.joint_2d(j["region"], j["reads"], cr, k1, k2)
-        for flags in (0, capi.F_BRUTE_FORCE):
+        for flags in (0, capi.F_BRUTE_FORCE, capi.F_NO_JOINT_PACK):
             g = capi.joint_2d(j["region"], j["reads"], cr, k1, k2, flags=flags)
             for k in KEYS_2D:
                 assert np.array_equal(g[k], o[k]), (seed, flags, k, np.nonzero(g[k] != o[k])[0][:8], g[k][:10], o[k][:10])

@@ -142,7 +142,8 @@ def fuzz_pairs(rng):
 
 def fuzz_2d(rng):
     u1 = synth.rand_unit(rng, int(rng.integers(1, 6))); u2 = synth.rand_unit(rng, int(rng.integers(1, 6)))
-    L = synth.rand_seq(rng, int(rng.choice([1, 3, 9, 10, 11, 60, 300]))); R = synth.rand_seq(rng, int(rng.choice([1, 2, 3, 9, 10, 11, 60, 300])))
+    # (flanks of 74 bases and more: their first |flank| - 10 >= 64 columns are swept in packed cells)
+    L = synth.rand_seq(rng, int(rng.choice([1, 3, 9, 10, 11, 60, 73, 74, 75, 140, 300]))); R = synth.rand_seq(rng, int(rng.choice([1, 2, 3, 9, 10, 11, 60, 73, 74, 75, 140, 300])))
     mid = synth.rand_seq(rng, int(rng.choice([0, 1, 5, 13, 40])))
     n = int(rng.integers(1, 7)); reads, cr, k1, k2 = [], [], [], []
     for r in range(n):
@@ -162,7 +163,7 @@ def fuzz_2d(rng):
         o = O.joint_2d((L, u1, mid, u2, R), reads, cr, k1, k2, sc=O.default_scoring(**sc))
     except ValueError:
         return None
-    for flags in (0, A.F_BRUTE_FORCE, A.F_TEST_CHAIN):
+    for flags in (0, A.F_BRUTE_FORCE, A.F_TEST_CHAIN, A.F_NO_JOINT_PACK):
         g = A.joint_2d((L, u1, mid, u2, R), reads, cr, k1, k2, sc=A.default_scoring(**sc), flags=flags)
         for k in K2:
             if not np.array_equal(g[k], o[k]):
