@@ -137,9 +137,19 @@ __global__ __launch_bounds__(WAVE, joint_waves(R, DIR)) void k_joint_sweep(int n
     const int o2 = -(sp.open2 << 16), x2 = -(sp.ext2 << 16);
     const int fresh = JBIAS;
 
+    // Cells keep H plus the cost of opening a vertical gap in their own column, Hq = H + fo1 (and Hq2 = H + fo2):
+    // that is what F takes, and -- the open of a horizontal gap in the NEXT column costing the same but for the
+    // window's first column (forward) or two (reverse) -- also what E of the next column takes, and the diagonal
+    // and the floor take it with the constant folded into the substitution scores: 16.5 instructions per cell
+    // instead of 20.  fo1, fo2 differ by the window payload (0 or -4) from column to column, never between the
+    // two gap pieces: Hq2 = Hq + (o2 - o1).
+    const int o21 = o2 - o1;
+
     // forward sweep: the R side, row r pairs with reverse-sweep row Q-2-r.  The stored values carry
     // one JBIAS each; the combine adds two packed words, so one bias is taken out here, and the
-    // gap-spanning terms get the refunds (one gap open, +2 window).
+    // gap-spanning terms get the refunds (one gap open, +2 window).  Boundary columns lie inside the window
+    // (fo1 = o1 - 4): the forward H arrives as Hq, so the R side's H takes that constant out again.
+    const int fo1_win = o1 - 4;
     int Hbo[DIR == 2 ? R : 1], Ebo[DIR == 2 ? R : 1], E2bo[DIR == 2 ? R : 1];
     if (DIR == 2) {
         const int q1 = (sp.open1 - sp.ext1) << 16, q2 = (sp.open2 - sp.ext2) << 16;
@@ -149,16 +159,19 @@ __global__ __launch_bounds__(WAVE, joint_waves(R, DIR)) void k_joint_sweep(int n
             const int a = Q - 2 - r;
             if (a >= 0) {
                 const int32_t* s3 = snap + ((size_t)rd.qoff + a) * 3;
-                Hbo[i] = s3[0] - JBIAS;
+                Hbo[i] = s3[0] - JBIAS - fo1_win;
                 Ebo[i] = s3[1] - JBIAS + q1 + 2;
                 E2bo[i] = s3[2] - JBIAS + q2 + 2;
             } else { Hbo[i] = JNEG; Ebo[i] = JNEG; E2bo[i] = JNEG; }
         }
     }
 
-    int Hprev[R], E[R], E2[R];          // after a step: H(i,j), and E_in / E2_in of column j
+    // (Hq2 is kept in registers while a wave's 256 arch VGPRs hold 8 -- tail sweep -- or 5 values per row, else
+    // recomputed from Hq where E2 needs it)
+    constexpr bool KEEP_HQ2 = (DIR == 2 ? 8 : 5) * R + 45 <= 256;
+    int Hq[R], Hq2[KEEP_HQ2 ? R : 1], E[R], E2[R];     // after a step: H(i,j) + fo1 / + fo2, and E_in / E2_in of column j
 #pragma unroll
-    for (int i = 0; i < R; ++i) { Hprev[i] = JNEG; E[i] = JNEG; E2[i] = JNEG; }
+    for (int i = 0; i < R; ++i) { Hq[i] = JNEG; E[i] = JNEG; E2[i] = JNEG; if (KEEP_HQ2) Hq2[i] = JNEG; }
     int Hbot = JNEG, Fout = JNEG, F2out = JNEG, Hup_prev = JNEG;
     int M = fresh;                      // running lexicographic max of this lane's cells ((0, 0) to start)
     int accS = JNEG, accB = JNEG;
@@ -171,7 +184,8 @@ __global__ __launch_bounds__(WAVE, joint_waves(R, DIR)) void k_joint_sweep(int n
         const int32_t* __restrict__ sv = state + tk.state + lane;
 #pragma unroll
         for (int i = 0; i < R; ++i) {
-            Hprev[i] = sv[(size_t)i * 64]; E[i] = sv[(size_t)(R + i) * 64]; E2[i] = sv[(size_t)(2 * R + i) * 64];
+            Hq[i] = sv[(size_t)i * 64]; E[i] = sv[(size_t)(R + i) * 64]; E2[i] = sv[(size_t)(2 * R + i) * 64];
+            if (KEEP_HQ2) Hq2[i] = Hq[i] + o21;
         }
         Hbot = sv[(size_t)(3 * R) * 64]; Fout = sv[(size_t)(3 * R + 1) * 64]; F2out = sv[(size_t)(3 * R + 2) * 64];
         Hup_prev = sv[(size_t)(3 * R + 3) * 64]; M = sv[(size_t)(3 * R + 4) * 64];
@@ -179,26 +193,27 @@ __global__ __launch_bounds__(WAVE, joint_waves(R, DIR)) void k_joint_sweep(int n
     }
 
     // resume behind k_joint_pk16: lane l has finished column step0 - 1 - l; values are (score + BIAS) halves,
-    // H is stored minus the gap open (nra_pk16.h), the accumulator chains start empty (no boundary before step0)
+    // H is stored minus the gap open there too (nra_pk16.h; no payload before the window), the accumulator
+    // chains start empty (no boundary before step0)
     int step0 = 0;
     if (DIR != 2) {
         if (tk.resume) {
             step0 = NRA_JOINT_PACKED_COLS(DIR ? rg.l1 : lenR);
             const int32_t* __restrict__ pv = pstate + tk.pstate + lane;
             const int hi = tk.phalf;
-            const int O1 = sp.open1 << 16;
             auto cell_of = [&](int v) { return (((hi ? half_hi(v) : half_lo(v)) - BIAS) << 16) + JBIAS; };
 #pragma unroll
             for (int i = 0; i < R; ++i) {
-                Hprev[i] = cell_of(pv[(size_t)i * 64]) + O1;
+                Hq[i] = cell_of(pv[(size_t)i * 64]);
+                if (KEEP_HQ2) Hq2[i] = Hq[i] + o21;
                 E[i] = cell_of(pv[(size_t)(R + i) * 64]);
                 E2[i] = cell_of(pv[(size_t)(2 * R + i) * 64]);
             }
-            Hup_prev = cell_of(pv[(size_t)(3 * R) * 64]) + O1;
+            Hup_prev = cell_of(pv[(size_t)(3 * R) * 64]);
             Fout = cell_of(pv[(size_t)(3 * R + 1) * 64]);
             F2out = cell_of(pv[(size_t)(3 * R + 2) * 64]);
             M = cell_of(pv[(size_t)(3 * R + 3) * 64]);
-            Hbot = Hprev[R - 1];
+            Hbot = Hq[R - 1];
             const int col = step0 - 1 - lane;
             tt = col >= 0 ? (int)p1[col] : NRA_PAD_T;
             j = step0 - lane;
@@ -208,7 +223,7 @@ __global__ __launch_bounds__(WAVE, joint_waves(R, DIR)) void k_joint_sweep(int n
     // DIR 0 / 2 drain the pipeline (ncols + 63 steps); DIR 1 leaves at its last dump (step t_last)
     // One flat step loop (a chunk loop around a 64-step loop made the compiler keep two copies of
     // the row registers).  Every 64 steps the lanes fetch the next 64 template columns.
-    const int nsteps = DIR == 1 ? ncols + 1 : step0 + (((ncols - step0 + 63 + 63) >> 6) << 6);
+    const int nsteps = DIR == 1 ? ncols + 1 : ncols + 63;
     int feed = NRA_PAD_T;
 #pragma unroll 1   // unrolling the step loop twice takes minutes to compile at R >= 20
     for (int step = step0; step < nsteps; ++step) {
@@ -231,7 +246,7 @@ __global__ __launch_bounds__(WAVE, joint_waves(R, DIR)) void k_joint_sweep(int n
                     int32_t* __restrict__ sv = state + tk.state + (size_t)si * (NSTATE * 64) + lane;
 #pragma unroll
                     for (int i = 0; i < R; ++i) {
-                        sv[(size_t)i * 64] = Hprev[i]; sv[(size_t)(R + i) * 64] = E[i]; sv[(size_t)(2 * R + i) * 64] = E2[i];
+                        sv[(size_t)i * 64] = Hq[i]; sv[(size_t)(R + i) * 64] = E[i]; sv[(size_t)(2 * R + i) * 64] = E2[i];
                     }
                     sv[(size_t)(3 * R) * 64] = Hbot; sv[(size_t)(3 * R + 1) * 64] = Fout; sv[(size_t)(3 * R + 2) * 64] = F2out;
                     sv[(size_t)(3 * R + 3) * 64] = Hup_prev; sv[(size_t)(3 * R + 4) * 64] = M;
@@ -248,14 +263,22 @@ __global__ __launch_bounds__(WAVE, joint_waves(R, DIR)) void k_joint_sweep(int n
             const int accB_in = dpp_shr1(JNEG, accB);
             const int tcode = tt & 0xff;
 
-            // window payload increments of THIS column (tk.py:464-485; mirrored for the reverse sweep)
-            int pe, pn, eo, ex, fo, fx;
+            // window payload increments of THIS column (tk.py:464-485; mirrored for the reverse sweep), and the
+            // vertical-gap open of the PREVIOUS column, which the stored Hq carry (fo_prev)
+            int pe, pn, eo, ex, fo, fx, fo_prev;
             if (DIR) {
                 const bool inw = j >= wa;                                    // every column from wa on
                 pe = inw ? 2 : 0; pn = inw ? -4 : 0;
                 eo = inw ? -4 : 0; ex = inw ? (j == wa ? -4 : -2) : 0;        // deletion onto base j
-                const bool fin = j + 1 > wa;                                 // insertion at ref_pos = j+1
-                fo = fin ? -4 : 0; fx = fin ? -2 : 0;
+                fo = inw ? -4 : 0; fx = inw ? -2 : 0;                         // insertion at ref_pos = j+1 > wa
+                // The one column where opening a horizontal gap (eo of column wa) and the vertical open of the
+                // column before (0) differ: the lane re-bases what it holds of column wa - 1, once per sweep.
+                fo_prev = inw ? -4 : 0;
+                if (j == wa) {
+#pragma unroll
+                    for (int i = 0; i < R; ++i) { Hq[i] -= 4; if (KEEP_HQ2) Hq2[i] -= 4; }
+                    Hup_prev -= 4;
+                }
             } else {
                 const int p = lenR - 1 - j;                                  // forward position inside R
                 const bool inw = p < wr && p >= 0;
@@ -263,10 +286,14 @@ __global__ __launch_bounds__(WAVE, joint_waves(R, DIR)) void k_joint_sweep(int n
                 eo = inw ? -4 : 0; ex = inw ? (p == wr - 1 ? -4 : -2) : 0;   // read backwards: first base met
                 const bool fin = p < wr - 1 && p >= 0;                       // insertion before R[p]
                 fo = fin ? -4 : 0; fx = fin ? -2 : 0;
+                fo_prev = (p + 1 < wr - 1 && p + 1 >= 0) ? -4 : 0;
             }
-            const int s_eq = sA + pe, s_ne = sB + pn, n_eq = sN + pe, n_ne = sN + pn;
-            const int eo1 = o1 + eo, ex1 = x1 + ex, eo2 = o2 + eo, ex2 = x2 + ex;
-            const int fo1 = o1 + fo, fx1 = x1 + fx, fo2 = o2 + fo, fx2 = x2 + fx;
+            const int fo1p = o1 + fo_prev;
+            const int floorq = fresh + fo1p;
+            const int s_eq = sA + pe - fo1p, s_ne = sB + pn - fo1p, n_eq = sN + pe - fo1p, n_ne = sN + pn - fo1p;
+            const int ex1 = x1 + ex, ex2 = x2 + ex;
+            const int fo1 = o1 + fo, fx1 = x1 + fx, fx2 = x2 + fx;
+            const int dq = DIR == 0 ? eo - fo_prev : 0;                      // reverse: two columns at the window's edge
 #define NRA_SUBST(i, out)                                                                          \
             {                                                                                      \
                 const int qc_ = (int)((qcp[(i) >> 2] >> (8 * ((i) & 3))) & 0xffu);                 \
@@ -278,37 +305,44 @@ __global__ __launch_bounds__(WAVE, joint_waves(R, DIR)) void k_joint_sweep(int n
             }
             int sc;
             NRA_SUBST(0, sc);
-            int d = imax(Hup_prev, fresh) + sc;
+            int d = imax(Hup_prev, floorq) + sc;
             Hup_prev = dpp_shr1(JNEG, Hbot);
-            int h = JNEG;
+            int h = JNEG, h_prev = JNEG;
             const bool at_boundary = (tt & JFLAG_BOUNDARY) != 0;
 #pragma unroll
             for (int i = 0; i < R; ++i) {
                 int d_next = d;
                 if (i + 1 < R) {
                     NRA_SUBST(i + 1, sc);
-                    d_next = imax(Hprev[i], fresh) + sc;
+                    d_next = imax(Hq[i], floorq) + sc;
                 }
                 // E(i,j) from column j-1, lazily: E_in stays in the register for the combine
-                const int ein = imax(E[i] + ex1, Hprev[i] + eo1);
-                const int e2in = imax(E2[i] + ex2, Hprev[i] + eo2);
+                const int ein = DIR == 0 ? imax(E[i] + ex1, Hq[i] + dq) : imax(E[i] + ex1, Hq[i]);
+                const int hq2_prev = KEEP_HQ2 ? Hq2[i] : Hq[i] + o21;
+                const int e2in = DIR == 0 ? imax(E2[i] + ex2, hq2_prev + dq) : imax(E2[i] + ex2, hq2_prev);
                 h = imax(imax(d, ein), F);
                 h = imax(imax(h, e2in), F2);
-                M = imax(M, h);
-                Hprev[i] = h;
+                if (i & 1) M = imax(imax(M, h_prev), h);                     // two rows per 3-input max
+                else if (i == R - 1) M = imax(M, h);
+                else h_prev = h;
                 E[i] = ein;
                 E2[i] = e2in;
-                F = imax(F + fx1, h + fo1);
-                F2 = imax(F2 + fx2, h + fo2);
+                const int hq = h + fo1;
+                Hq[i] = hq;
+                const int hq2 = hq + o21;
+                if (KEEP_HQ2) Hq2[i] = hq2;
+                F = imax(F + fx1, hq);
+                F2 = imax(F2 + fx2, hq2);
                 d = d_next;
             }
 #undef NRA_SUBST
             int tS = JNEG;
             if (DIR == 2) {
                 if (__builtin_amdgcn_ballot_w64(at_boundary) != 0) {
+                    const int floor_b = fresh + fo1_win;
 #pragma unroll
                     for (int i = 0; i < R; ++i) {
-                        const int t1 = imax(Hprev[i], fresh) + Hbo[i];
+                        const int t1 = imax(Hq[i], floor_b) + Hbo[i];
                         const int t2 = E[i] + Ebo[i];
                         const int t3 = E2[i] + E2bo[i];
                         tS = imax(imax(tS, t1), imax(t2, t3));
@@ -320,11 +354,11 @@ __global__ __launch_bounds__(WAVE, joint_waves(R, DIR)) void k_joint_sweep(int n
                     const int a = lane * R + i;
                     if (a < Q) {
                         int32_t* s3 = snap + ((size_t)rd.qoff + a) * 3;
-                        s3[0] = Hprev[i]; s3[1] = E[i]; s3[2] = E2[i];
+                        s3[0] = Hq[i] - fo1; s3[1] = E[i]; s3[2] = E2[i];
                     }
                 }
             }
-            Hbot = h; Fout = F; F2out = F2;
+            Hbot = Hq[R - 1]; Fout = F; F2out = F2;
             accS = imax(accS_in, tS);
             accB = imax(accB_in, M);
 
@@ -411,9 +445,9 @@ __global__ __launch_bounds__(WAVE) void k_joint_pk16(int n_tasks, const NraJoint
     for (int step = 0; step < cols; ++step) {
         if ((step & 63) == 0) feed = column_table(step + 1 + wr);      // lane 63 hands out column step + 1
         const int4 in = ring[lane];
-        F = in.y; F2 = in.z;
-        sweep_cell<0, R, R>(Hq, Hq2, E, E2, qc, Hup_prev, F, F2, M, in.w, tbl_hi, v_floor, v_e1, v_e2, v_o1, v_o2);
-        Hup_prev = in.x;
+        F = pmaxi(in.y, BIAS * P1); F2 = in.z;              // the floor lives in F (sweep_cell, FF); lane 0 takes constants
+        sweep_cell<0, R, R, false, true>(Hq, Hq2, E, E2, qc, Hup_prev, F, F2, M, in.w, tbl_hi, BIAS * P1, v_e1, v_e2, v_o1, v_o2);
+        Hup_prev = pmaxi(in.x, v_floor);
         ring[wr] = make_int4(Hq[R - 1], F, F2, in.w);
         if (lane == 63) ring[0] = make_int4(v_floor, NEG1, NEG1, feed);
         feed = dpp_rol1(feed);

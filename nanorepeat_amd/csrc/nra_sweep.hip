@@ -483,7 +483,7 @@ __global__ __launch_bounds__(WAVE * SWEEP_RING_WPB) void k_sweep_ring(int n_task
             const int code = piece[col];
             t = code < 4 ? tbl_mis4 + ((s_match - s_mis) << (8 * code)) : tbl_ambi4;
             if (DIR == 0 && col == flank - 1) t |= FLAG_SNAPSHOT;
-            if (DIR == 1 && col >= flank) t |= FLAG_INREP;
+            if (DIR == 1 && col + 1 >= flank) t |= FLAG_INREP;     // origin bit of an alignment starting at the NEXT column
         }
         return t;
     };
@@ -562,11 +562,13 @@ __global__ __launch_bounds__(WAVE * SWEEP_RING_WPB) void k_sweep_ring(int n_task
     for (int step = 0; step < nsteps; ++step) {
         if ((step & 63) == 0) feed = column_table(step + skew + wr);      // lane 63 hands out column step + skew
         const int4 in = ring[slot * 64 + lane];
-        int F = in.y, F2 = in.z;
         const int tt = in.w;
-        const int floor_c = DIR == 1 ? (int)((((unsigned)tt >> 15) & (unsigned)P1) | (unsigned)v_floor) : v_floor;
-        sweep_cell<0, R, R>(Hq, Hq2, E, E2, qc, Hup_prev, F, F2, M, tt & 0x7f7f7f7f, tbl_hi, floor_c, v_e1, v_e2, v_o1, v_o2);
-        Hup_prev = in.x;
+        // the floor lives in F (sweep_cell, FF): score 0 with the origin bit of the next column.  What enters a
+        // lane's first row is at the floor already, but for lane 0, which takes constants: one max each
+        const int fl = DIR == 1 ? (int)((((unsigned)tt >> 15) & (unsigned)P1) | (unsigned)(BIAS * P1)) : BIAS * P1;
+        int F = pmaxi(in.y, fl), F2 = in.z;
+        sweep_cell<0, R, R, false, true>(Hq, Hq2, E, E2, qc, Hup_prev, F, F2, M, tt & 0x7f7f7f7f, tbl_hi, fl, v_e1, v_e2, v_o1, v_o2);
+        Hup_prev = pmaxi(in.x, fl - v_o1);
         ring[slot * 64 + wr] = make_int4(Hq[R - 1], F, F2, tt);
         if (lane == 63) ring[slot * 64] = make_int4(v_floor, NEG1, NEG1, feed);
         feed = dpp_rol1(feed);
@@ -691,7 +693,7 @@ __global__ __launch_bounds__(WAVE) void k_sweep_ring32(int n_tasks, const NraSwe
             const int code = piece[col];
             t = code < 4 ? tbl_mis4 + ((s_match - s_mis) << (8 * code)) : tbl_ambi4;
             if (DIR == 0 && col == flank - 1) t |= FLAG_SNAPSHOT;
-            if (DIR == 1 && col >= flank) t |= FLAG_INREP;
+            if (DIR == 1 && col + 1 >= flank) t |= FLAG_INREP;     // origin bit of an alignment starting at the NEXT column
         }
         return t;
     };
@@ -772,11 +774,11 @@ __global__ __launch_bounds__(WAVE) void k_sweep_ring32(int n_tasks, const NraSwe
         // full-wave rotation keeps them so
         if ((step & 31) == 0) feed = column_table(step + skew + ((hl + 1) & 31));
         const int4 in = ring[slot * 64 + lane];
-        int F = in.y, F2 = in.z;
         const int tt = in.w;
-        const int floor_c = DIR == 1 ? (int)((((unsigned)tt >> 15) & (unsigned)P1) | (unsigned)v_floor) : v_floor;
-        sweep_cell<0, R, R>(Hq, Hq2, E, E2, qc, Hup_prev, F, F2, M, tt & 0x7f7f7f7f, tbl_hi, floor_c, v_e1, v_e2, v_o1, v_o2);
-        Hup_prev = in.x;
+        const int fl = DIR == 1 ? (int)((((unsigned)tt >> 15) & (unsigned)P1) | (unsigned)(BIAS * P1)) : BIAS * P1;   // as in k_sweep_ring
+        int F = pmaxi(in.y, fl), F2 = in.z;
+        sweep_cell<0, R, R, false, true>(Hq, Hq2, E, E2, qc, Hup_prev, F, F2, M, tt & 0x7f7f7f7f, tbl_hi, fl, v_e1, v_e2, v_o1, v_o2);
+        Hup_prev = pmaxi(in.x, fl - v_o1);
         ring[slot * 64 + wr] = make_int4(Hq[R - 1], F, F2, tt);
         if (hl == 31) ring[slot * 64 + hoff] = make_int4(v_floor, NEG1, NEG1, feed);
         feed = dpp_rol1(feed);
