@@ -902,7 +902,7 @@ __global__ __launch_bounds__(WAVE) void k_sweep_ringchain(int n_tasks, const Nra
             const int code = piece[col];
             t = code < 4 ? tbl_mis4 + ((s_match - s_mis) << (8 * code)) : tbl_ambi4;
             if (DIR == 0 && col == flank - 1) t |= FLAG_SNAPSHOT;
-            if (DIR == 1 && col >= flank) t |= FLAG_INREP;
+            if (DIR == 1 && col + 1 >= flank) t |= FLAG_INREP;     // origin bit of an alignment starting at the NEXT column
         }
         return t;
     };
@@ -998,11 +998,11 @@ __global__ __launch_bounds__(WAVE) void k_sweep_ringchain(int n_tasks, const Nra
             if (DIR == 1) { sS = strip_in(col, 3, NEG2); sB = strip_in(col, 4, NEG1); }
         }
         const int4 in = ring[slot * 64 + lane];
-        int F = in.y, F2 = in.z;
         const int tt = in.w;
-        const int floor_c = DIR == 1 ? (int)((((unsigned)tt >> 15) & (unsigned)P1) | (unsigned)v_floor) : v_floor;
-        sweep_cell<0, R, R, W>(Hq, Hq2, E, E2, qc, Hup_prev, F, F2, M, tt & 0x7f7f7f7f, tbl_hi, floor_c, v_e1, v_e2, v_o1, v_o2);
-        Hup_prev = in.x;
+        const int fl = DIR == 1 ? (int)((((unsigned)tt >> 15) & (unsigned)P1) | (unsigned)(BIASW * P1)) : BIASW * P1;   // as in k_sweep_ring
+        int F = mx2<W>(in.y, fl), F2 = in.z;
+        sweep_cell<0, R, R, W, true>(Hq, Hq2, E, E2, qc, Hup_prev, F, F2, M, tt & 0x7f7f7f7f, tbl_hi, fl, v_e1, v_e2, v_o1, v_o2);
+        Hup_prev = mx2<W>(in.x, fl - v_o1);
         ring[slot * 64 + wr] = make_int4(Hq[R - 1], F, F2, tt);
         if (lane == 63) ring[slot * 64] = make_int4(sH, sF, sF2, feed);
         const int c63 = step - 63 * skew;                                  // the column lane 63 has just finished
