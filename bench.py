@@ -35,6 +35,9 @@ import subprocess
 import sys
 import time
 
+# before torch starts the HIP runtime: the library's default (nra_host.cpp, g_hw_queues_default)
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
@@ -369,16 +372,30 @@ def bench_joint(args):
     a = J.Repeat.parse(f"chr4:{len(left)}:{len(left) + 57}:{u1}:200")
     b = J.Repeat.parse(f"chr4:{len(left) + 57 + len(mid)}:{len(left) + 57 + len(mid) + 21}:{u2}:20")
     a.max_size += 10; b.max_size += 10                               # nanoRepeat_joint.py:202-203
+    # the product's session: from 2000 reads on two groups of reads in parallel host threads, so that one group's
+    # host work overlaps the other's kernels (joint.GridSession)
     session = J.GridSession(J._joint_region(chrom, a, b), fq, device=local_rank)
     last = {}
 
-    def step():
-        session.new_run()       # every step is a whole run: round 2 makes the reverse sweeps, round 3 reuses them
-        last["est"] = J.fine_tune_read_count(init, fq, chrom, copy.copy(a), copy.copy(b), device=local_rank, session=session)
+    def step(sess=session):
+        sess.new_run()          # every step is a whole run: round 2 makes the reverse sweeps, round 3 reuses them
+        last["est"] = J.fine_tune_read_count(init, fq, chrom, copy.copy(a), copy.copy(b), device=local_rank, session=sess)
 
-    dt = timed_steps(args, dist, step, on_warm=lambda: setattr(session, "rounds", []))
-    rounds = session.rounds
-    per_step = len(rounds) // max(args.steps, 1)
+    dt = timed_steps(args, dist, step)
+    est_split = last["est"]
+    # kernel statistics from an un-split session of the same reads, where the batch's HIP-event times are those of
+    # one stream (in the timed steps the two groups' kernels overlap)
+    serial = J.GridSession(J._joint_region(chrom, a, b), fq, device=local_rank, parts=1)
+    for _ in range(2):
+        step(serial)
+    serial.rounds = []
+    n_serial = 4
+    t_serial = time.perf_counter()
+    for _ in range(n_serial):
+        step(serial)
+    t_serial = (time.perf_counter() - t_serial) / n_serial * 1e3
+    rounds = serial.rounds
+    per_step = len(rounds) // n_serial
     n_cells = sum(c for c, _ in rounds[:per_step])
     # statistics: the batch accumulates event times over its runs; cells are per round
     first, final = rounds[0][1], rounds[-1][1]
@@ -405,13 +422,19 @@ def bench_joint(args):
                      "frac": achieved / VALU_PEAK_TLANEOPS, "traffic": None,
                      "kernel": "k_joint_sweep<R,dir> (reverse, prefix and tail sweeps)",
                      "kernel_ms_per_step": phase_ms, "device_ms_per_step": total_ms,
-                     "host_ms_per_step": dt / args.steps * 1e3 - total_ms,
+                     "host_ms_per_step": t_serial - total_ms, "unsplit_ms_per_step": t_serial,
+                     "read_groups": max(1, len(session.subs)),
                      "executed_cells_per_step": exe, "executed_Tcell_per_s": exe / (phase_ms / 1e3) / 1e12,
                      "laneops_per_cell": LANEOPS_PER_CELL,
                      "note": "int32 cells = (score << 16 | window score): one cell per lane-op slot, priced like the 1D "
-                             "cell (10 lane-ops) against the same 78.6 T lane-op/s; launches are latency- rather than "
-                             "issue-bound at 5000 reads (DESIGN.md)",
+                             "cell (10 lane-ops) against the same 78.6 T lane-op/s; the columns outside the scoring window "
+                             "run in packed int16 cells (k_joint_pk16).  kernel / device / host times are those of an "
+                             "un-split session (unsplit_ms_per_step); ms_per_step is the product path, two read groups "
+                             "in parallel host threads",
                      "algorithmic": {"cells_per_step": alg, "over_executed": alg / max(exe, 1)}},
+        "read_groups_equal_unsplit": bool(est_split.repeat1_count_dict == est.repeat1_count_dict and
+                                          est_split.repeat2_count_dict == est.repeat2_count_dict and
+                                          list(est_split.repeat1_count_dict) == list(est.repeat1_count_dict)),
         "k1_within1": float(np.mean(np.abs(k1 - j["truth"][:, 0]) <= 1)),
         "k2_within1": float(np.mean(np.abs(k2 - j["truth"][:, 1]) <= 1)),
     }
@@ -432,6 +455,7 @@ def bench_joint(args):
                                           "restatement (one optimal DP with window payload per cell), not minimap2"}
     print(json.dumps(line), flush=True)
     session.close()
+    serial.close()
 
 
 def main():

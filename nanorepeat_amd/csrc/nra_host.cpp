@@ -259,6 +259,13 @@ struct HandlePool {
     }
 };
 HandlePool g_handles;
+
+// A batch runs every rows-per-lane bucket's kernels on streams of its own (and the joint mode two batches at a
+// time, joint.py GridSession): with HIP's default of 4 hardware queues, copies and short kernels wait behind
+// another stream's long sweeps that happen to share their queue (config 3: 25.6 -> 19.2 ms per run with 8).
+// Only a default -- the variable counts when the HIP runtime starts, so a host process that wants another
+// value, or has started HIP already, keeps its own.
+const int g_hw_queues_default = setenv("GPU_MAX_HW_QUEUES", "8", 0);
 hipError_t device_chunk_get(int device, size_t bytes, char** out, size_t* got) { return g_handles.chunk_get(device, bytes, out, got); }
 void device_chunk_put(int device, char* p, size_t bytes) { g_handles.chunk_put(device, p, bytes); }
 

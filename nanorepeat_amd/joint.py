@@ -9,6 +9,7 @@ CIGAR walk of `estimate_two_repeats_from_paf` are replaced by ONE call through t
 from dataclasses import dataclass, field
 
 import numpy as np
+from operator import itemgetter
 
 from . import _capi
 
@@ -289,19 +290,46 @@ def _cells_of_ranges(grid1, lo1, hi1, grid2, lo2, hi2):
     return cell_read, k1, k2
 
 
+PIPELINE_MIN_READS = 2000     # from here on the reads of a joint run are scored as two independent halves
+
+
 class GridSession:
     """The reads of a joint run for the grid rounds: packed and uploaded once (`nra_batch2d_create_reads`),
     scored against one cell list per round (`nra_batch2d_set_cells` + run).  With an injected `scorer`
-    (the tests' oracle twin of `_capi.joint_2d`) every round is a one-shot call instead."""
+    (the tests' oracle twin of `_capi.joint_2d`) every round is a one-shot call instead.
 
-    def __init__(self, region, fastq_dict, device=0, scoring=None, scorer=None):
+    `parts` > 1 (default: 2 from PIPELINE_MIN_READS reads on): the reads are cut into that many contiguous
+    groups, each a session of its own (`subs`) with its own resident batch and stream.  A read's grid rounds
+    depend on that read alone, so `fine_tune_read_count` runs the groups in host threads that take turns: a
+    thread holds `host_lock` while it works on the host and lets go of it while it waits for the device, so
+    one group's cell list is built and its results are read while the other group's kernels run -- host and
+    device time overlap instead of adding up.  (Without the lock both threads would share the interpreter
+    evenly, reach the device together and wait together.)"""
+
+    def __init__(self, region, fastq_dict, device=0, scoring=None, scorer=None, parts=None):
         self.region = region
         self.names = list(fastq_dict)
-        self.index = {n: i for i, n in enumerate(self.names)}
-        self.reads = [_read_seq(fastq_dict[n]) for n in self.names]
         self.device, self.scoring, self.scorer = device, scoring, scorer
         self.batch = None
         self.rounds = None          # set to a list to collect (n_cells, batch statistics) of every round
+        self.subs, self.pool, self.host_lock = [], None, None
+        self.in_turn = False        # this group's thread holds host_lock (fine_tune_read_count)
+        if parts is None:
+            parts = 2 if scorer is None and len(self.names) >= PIPELINE_MIN_READS else 1
+        parts = max(1, min(int(parts), max(1, len(self.names))))
+        if parts > 1:
+            from concurrent.futures import ThreadPoolExecutor
+            cuts = [len(self.names) * p // parts for p in range(parts + 1)]
+            self.subs = [GridSession(region, {n: fastq_dict[n] for n in self.names[a:b]}, device, scoring, scorer, parts=1)
+                         for a, b in zip(cuts[:-1], cuts[1:])]
+            self.pool = ThreadPoolExecutor(max_workers=parts, thread_name_prefix="nra-grid")
+            import threading
+            self.host_lock = threading.Lock()
+            for sub in self.subs:
+                sub.host_lock = self.host_lock
+            return
+        self.index = {n: i for i, n in enumerate(self.names)}
+        self.reads = [_read_seq(fastq_dict[n]) for n in self.names]
         if scorer is None:
             self.batch = _capi.Batch.create_2d_reads(region, self.reads, sc=scoring, device=device)
 
@@ -311,17 +339,31 @@ class GridSession:
                                device=self.device)
         self.batch.set_cells(cell_read, k1, k2, read_strand)
         self.batch.run()
-        self.batch.sync()
+        if self.in_turn:
+            self.host_lock.release()               # another group's thread works on the host meanwhile
+            try:
+                self.batch.sync()
+            finally:
+                self.host_lock.acquire()
+        else:
+            self.batch.sync()
         if self.rounds is not None:
             self.rounds.append((len(cell_read), self.batch.stats()))
         return self.batch.fetch(per_candidate=False)
 
     def new_run(self):
         """The grid rounds are about to start over on these reads: nothing of an earlier run is reused."""
+        for sub in self.subs:
+            sub.new_run()
         if self.batch is not None:
             self.batch.invalidate()
 
     def close(self):
+        for sub in self.subs:
+            sub.close()
+        if self.pool is not None:
+            self.pool.shutdown(wait=True)
+            self.pool = None
         if self.batch is not None:
             self.batch.close()
             self.batch = None
@@ -331,6 +373,22 @@ class GridSession:
 
     def __exit__(self, *a):
         self.close()
+
+
+def _rows_with(names, *dicts):
+    """Numbers of the names every dict holds (ascending).  One C-level membership pass per dict."""
+    if all(len(d) >= len(names) and all(map(d.__contains__, names)) for d in dicts):
+        return np.arange(len(names), dtype=np.int64)
+    return np.array([i for i, name in enumerate(names) if all(name in d for d in dicts)], np.int64)
+
+
+def _values_of(d, names, rows, dtype):
+    """d[names[i]] for i in rows as an array (itemgetter: one C-level pass)."""
+    if len(rows) == 0:
+        return np.zeros(0, dtype)
+    keys = names if len(rows) == len(names) else [names[i] for i in rows]
+    got = itemgetter(*keys)(d)
+    return np.array(got if len(keys) > 1 else [got], dtype)
 
 
 def _score_round(session, rows, grid1, lo1, hi1, grid2, lo2, hi2, strands):
@@ -347,7 +405,10 @@ def _score_round(session, rows, grid1, lo1, hi1, grid2, lo2, hi2, strands):
         return est
     st_in = None
     if strands is not None:
-        st_in = np.fromiter((strands.get(name, 0) for name in session.names), np.int8, n)
+        if len(strands) >= n and all(map(strands.__contains__, session.names)):
+            st_in = np.array(itemgetter(*session.names)(strands) if n > 1 else [strands[session.names[0]]], np.int8)
+        else:
+            st_in = np.fromiter((strands.get(name, 0) for name in session.names), np.int8, n)
     out = session.score(cell_read, k1, k2, st_in)
     has_cells = np.zeros(n, bool)
     has_cells[cell_read] = True
@@ -359,6 +420,17 @@ def _score_round(session, rows, grid1, lo1, hi1, grid2, lo2, hi2, strands):
     if strands is not None:
         idx = np.nonzero(has_cells)[0]
         strands.update(zip((session.names[i] for i in idx), np.asarray(out["read_strand"])[idx].tolist()))
+    return est
+
+
+def _merge_parts(parts):
+    """One RepeatSize from those of a session's read groups (in read order, like the un-split run's)."""
+    est = RepeatSize()
+    for e in parts:
+        est.repeat1_count_dict.update(e.repeat1_count_dict)
+        est.repeat2_count_dict.update(e.repeat2_count_dict)
+    scored = next((e for e in parts if len(e.repeat1_count_dict) > 0), parts[0])
+    est.step_size1, est.step_size2 = scored.step_size1, scored.step_size2
     return est
 
 
@@ -378,20 +450,24 @@ def round2_estimation_of_repeat_size(initial_estimation, fastq_dict, repeat_chro
     """Coarse grid (nanoRepeat_joint.py:376-425).  `strands` (dict, optional) carries each read's
     orientation between rounds so round 3 does not probe it again; `session` the resident reads."""
     _check_repeat_order(repeat1, repeat2)
+    if session is not None and session.subs:
+        return _merge_parts(list(session.pool.map(lambda sub: round2_estimation_of_repeat_size(
+            initial_estimation, fastq_dict, repeat_chrom_seq, repeat1, repeat2, data_type, num_threads, out_dir, device,
+            scoring, scorer, strands, sub), session.subs)))
     step_size1 = choose_best_step_size(repeat1, initial_estimation.repeat1_count_range_dict)
     step_size2 = choose_best_step_size(repeat2, initial_estimation.repeat2_count_range_dict)
     own = session is None
     if own:
-        session = GridSession(_joint_region(repeat_chrom_seq, repeat1, repeat2), fastq_dict, device, scoring, scorer)
+        session = GridSession(_joint_region(repeat_chrom_seq, repeat1, repeat2), fastq_dict, device, scoring, scorer, parts=1)
     try:
         # The reference visits grid cell by grid cell and, per cell, the reads whose round-1 ranges hold it
         # (:397-409); per read that is the product of the grid values inside its two ranges.
         grid1 = np.arange(repeat1.round1_min_size, repeat1.round1_max_size + 1, step_size1)
         grid2 = np.arange(repeat2.round1_min_size, repeat2.round1_max_size + 1, step_size2)
         r1, r2 = initial_estimation.repeat1_count_range_dict, initial_estimation.repeat2_count_range_dict
-        rows = np.array([i for i, name in enumerate(session.names) if name in r1 and name in r2], np.int64)
-        rng1 = np.array([r1[session.names[i]] for i in rows], np.int64).reshape(-1, 2)
-        rng2 = np.array([r2[session.names[i]] for i in rows], np.int64).reshape(-1, 2)
+        rows = _rows_with(session.names, r1, r2)
+        rng1 = _values_of(r1, session.names, rows, np.int64).reshape(-1, 2)
+        rng2 = _values_of(r2, session.names, rows, np.int64).reshape(-1, 2)
         est = _score_round(session, rows,
                            grid1, np.searchsorted(grid1, rng1[:, 0]), np.searchsorted(grid1, rng1[:, 1]),
                            grid2, np.searchsorted(grid2, rng2[:, 0]), np.searchsorted(grid2, rng2[:, 1]), strands)
@@ -411,14 +487,18 @@ def round3_estimation_of_repeat_size(initial_estimation, round2_estimation, fast
     if len(done1) == 0 or len(done2) == 0:
         return RepeatSize()
     _check_repeat_order(repeat1, repeat2)
+    if session is not None and session.subs:
+        return _merge_parts(list(session.pool.map(lambda sub: round3_estimation_of_repeat_size(
+            initial_estimation, round2_estimation, fastq_dict, repeat_chrom_seq, repeat1, repeat2, data_type, num_threads,
+            out_dir, device, scoring, scorer, strands, sub), session.subs)))
     buf1, buf2 = round2_estimation.step_size1, round2_estimation.step_size2
     own = session is None
     if own:
-        session = GridSession(_joint_region(repeat_chrom_seq, repeat1, repeat2), fastq_dict, device, scoring, scorer)
+        session = GridSession(_joint_region(repeat_chrom_seq, repeat1, repeat2), fastq_dict, device, scoring, scorer, parts=1)
     try:
-        rows = np.array([i for i, name in enumerate(session.names) if name in done1 and name in done2], np.int64)
-        size1 = np.array([done1[session.names[i]] for i in rows], np.float64)
-        size2 = np.array([done2[session.names[i]] for i in rows], np.float64)
+        rows = _rows_with(session.names, done1, done2)
+        size1 = _values_of(done1, session.names, rows, np.float64)
+        size2 = _values_of(done2, session.names, rows, np.float64)
         # the global grid spans every read's round-2 size +- one coarse step (:298-303) ...
         both = [name for name in done1 if name in done2]
         all1 = np.array([done1[name] for name in both], np.float64)
@@ -426,8 +506,8 @@ def round3_estimation_of_repeat_size(initial_estimation, round2_estimation, fast
         grid1 = np.arange(max(0, int(all1.min() - buf1)), int(all1.max() + buf1 + 2))
         grid2 = np.arange(max(0, int(all2.min() - buf2)), int(all2.max() + buf2 + 2))
         # ... and a read takes the cells within one step of its own size that lie inside its round-1 range (:320-330)
-        r1 = np.array([initial_estimation.repeat1_count_range_dict[session.names[i]] for i in rows], np.float64).reshape(-1, 2)
-        r2 = np.array([initial_estimation.repeat2_count_range_dict[session.names[i]] for i in rows], np.float64).reshape(-1, 2)
+        r1 = _values_of(initial_estimation.repeat1_count_range_dict, session.names, rows, np.float64).reshape(-1, 2)
+        r2 = _values_of(initial_estimation.repeat2_count_range_dict, session.names, rows, np.float64).reshape(-1, 2)
         est = _score_round(session, rows,
                            grid1, np.searchsorted(grid1, np.maximum(size1 - buf1, r1[:, 0])),
                            np.searchsorted(grid1, np.minimum(size1 + buf1, r1[:, 1])),
@@ -453,22 +533,49 @@ def fine_tune_read_count(initial_estimation, fastq_dict, repeat_chrom_seq, repea
         lo = min(rep.max_size, int(span[:, 0].min())) if len(span) else rep.max_size
         hi = max(0, int(span[:, 1].max())) if len(span) else 0
         rep.round1_min_size, rep.round1_max_size = lo, min(hi, rep.max_size)            # :239-259
-    # a read's strand is known from round 1 when that was run here (the left template is forward)
-    strands = dict(getattr(initial_estimation, "read_strand_dict", {}))
     own = session is None
     if own:
         session = GridSession(_joint_region(repeat_chrom_seq, repeat1, repeat2), fastq_dict, device, scoring, scorer)
-    try:
-        est = round2_estimation_of_repeat_size(initial_estimation, fastq_dict, repeat_chrom_seq, repeat1, repeat2,
-                                               data_type, num_threads, out_dir, device, scoring, scorer, strands, session)
+
+    def both_rounds(sess, rep1, rep2):
+        # a read's strand is known from round 1 when that was run here (the left template is forward)
+        strands = dict(getattr(initial_estimation, "read_strand_dict", {}))
+        est = round2_estimation_of_repeat_size(initial_estimation, fastq_dict, repeat_chrom_seq, rep1, rep2,
+                                               data_type, num_threads, out_dir, device, scoring, scorer, strands, sess)
         if est.step_size1 > 1 and est.step_size2 > 1:                                    # :268
-            est = round3_estimation_of_repeat_size(initial_estimation, est, fastq_dict, repeat_chrom_seq, repeat1,
-                                                   repeat2, data_type, num_threads, out_dir, device, scoring, scorer,
-                                                   strands, session)
+            est = round3_estimation_of_repeat_size(initial_estimation, est, fastq_dict, repeat_chrom_seq, rep1,
+                                                   rep2, data_type, num_threads, out_dir, device, scoring, scorer,
+                                                   strands, sess)
+        return est
+
+    try:
+        if not session.subs:
+            return both_rounds(session, repeat1, repeat2)
+        # Groups of reads in parallel threads (GridSession).  Everything global -- the round-1 spans above, the
+        # step sizes -- comes from the round-1 ranges of ALL reads, which every group sees; what a group derives
+        # from its own round-2 results (round 3's grid span) only has to cover its own reads' cells.
+        # (a thread coming back from the device has to get the interpreter from the one building its cell list:
+        # the default hand-over interval, 5 ms, is a third of the whole job)
+        def turn(sub):
+            with session.host_lock:
+                sub.in_turn = True
+                try:
+                    return both_rounds(sub, repeat1, repeat2)
+                finally:
+                    sub.in_turn = False
+
+        # (a thread coming back from the device has to get the interpreter from whatever runs meanwhile:
+        # the default hand-over interval, 5 ms, is a third of the whole job)
+        import sys
+        interval = sys.getswitchinterval()
+        sys.setswitchinterval(min(interval, 2e-4))
+        try:
+            return _merge_parts(list(session.pool.map(turn, session.subs)))
+        finally:
+            sys.setswitchinterval(interval)
     finally:
         if own:
             session.close()
-    return est
 
 
 def output_repeat_size_2d(in_fastq_file, repeat1_id, repeat2_id, out_prefix, repeat1_count_dict,

@@ -580,6 +580,17 @@ def test_config3_joint_sample(capi, oracle):
         res[name] = ({k: float(v) for k, v in fin.repeat1_count_dict.items()},
                      {k: float(v) for k, v in fin.repeat2_count_dict.items()}, fin.step_size1, fin.step_size2)
     assert res["gpu"] == res["oracle"]
+    # the reads as two / four groups in parallel host threads (what fine_tune_read_count does from 2000 reads on),
+    # also on a resident session used twice
+    for parts in (2, 4):
+        with J.GridSession(J._joint_region(chrom, a, b), fq, parts=parts) as sess:
+            assert len(sess.subs) == parts
+            for _ in range(2):
+                sess.new_run()
+                fin = J.fine_tune_read_count(init, fq, chrom, copy.deepcopy(a), copy.deepcopy(b), session=sess)
+                got = ({k: float(v) for k, v in fin.repeat1_count_dict.items()},
+                       {k: float(v) for k, v in fin.repeat2_count_dict.items()}, fin.step_size1, fin.step_size2)
+                assert got == res["gpu"] and list(got[0]) == list(res["gpu"][0])
     k1 = np.array([res["gpu"][0][f"r{i}"] for i in range(6)]); k2 = np.array([res["gpu"][1][f"r{i}"] for i in range(6)])
     assert np.mean(np.abs(k1 - j["truth"][:, 0]) <= 1) >= 0.8 and np.mean(np.abs(k2 - j["truth"][:, 1]) <= 1) >= 0.8
 

@@ -154,6 +154,15 @@ def test_joint_end_to_end_matches_reference(oracle, golden_2d):
         assert want[:2] == got[:2] and sorted(want[2:]) == sorted(got[2:])
         assert [l.split("\t")[1] for l in got[2:] if l] == sorted(
             [l.split("\t")[1] for l in got[2:] if l], key=float)
+        # the same reads as read groups in parallel host threads (GridSession parts): the reference's numbers again
+        a2 = J.Repeat().init_from_string(c["repeat1"]); b2 = J.Repeat().init_from_string(c["repeat2"])
+        a2.max_size += 10; b2.max_size += 10
+        with J.GridSession(J._joint_region(c["chrom"], a2, b2), fq, scorer=oracle.joint_2d, parts=3) as sess:
+            split = J.fine_tune_read_count(init, fq, c["chrom"], a2, b2, scorer=oracle.joint_2d, session=sess)
+        assert [split.step_size1, split.step_size2] == c["final_step"]
+        assert {k: float(v) for k, v in split.repeat1_count_dict.items()} == c["k1"]
+        assert list(split.repeat1_count_dict) == list(final.repeat1_count_dict)
+        assert {k: float(v) for k, v in split.repeat2_count_dict.items()} == c["k2"]
 
 
 def test_joint_selector_on_canned_paf(oracle, golden_2d):

@@ -1,0 +1,58 @@
+"""Host/device timeline of one joint run (config 3) with the reads in groups: when each group's thread builds a cell
+list, sets it, waits for the device and reads the results.  python3 tools/joint_timeline.py [parts]"""
+import copy, os, sys, threading, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from nanorepeat_amd import joint as J, synth
+
+parts = int(sys.argv[1]) if len(sys.argv) > 1 else 2
+if len(sys.argv) > 2 and sys.argv[2] == "torch":      # like bench.py: torch's HIP context first
+    import torch
+    torch.cuda.synchronize()
+n = 5000
+j = synth.config3(n)
+init = J.Round1Estimation(); fq = {}
+for i, s in enumerate(j["reads"]):
+    init.repeat1_count_range_dict[f"r{i}"] = tuple(int(x) for x in j["range1"][i])
+    init.repeat2_count_range_dict[f"r{i}"] = tuple(int(x) for x in j["range2"][i])
+    init.read_strand_dict[f"r{i}"] = int(j["strand"][i])
+    fq[f"r{i}"] = f"@r{i}\n{s}\n+\n{'!' * len(s)}\n"
+left, u1, mid, u2, right = j["region"]
+chrom = left + u1 * 19 + mid + u2 * 7 + right
+a = J.Repeat.parse(f"chr4:{len(left)}:{len(left) + 57}:{u1}:200")
+b = J.Repeat.parse(f"chr4:{len(left) + 57 + len(mid)}:{len(left) + 57 + len(mid) + 21}:{u2}:20")
+a.max_size += 10; b.max_size += 10
+log = []
+orig = J.GridSession.score
+
+
+def score(self, cell_read, k1, k2, read_strand):
+    me = threading.current_thread().name
+    t = [time.perf_counter()]
+    self.batch.set_cells(cell_read, k1, k2, read_strand); t.append(time.perf_counter())
+    self.batch.run(); t.append(time.perf_counter())
+    lk = self.in_turn
+    if lk: self.host_lock.release()
+    self.batch.sync()
+    if lk: self.host_lock.acquire()
+    t.append(time.perf_counter())
+    out = self.batch.fetch(per_candidate=False); t.append(time.perf_counter())
+    log.append((me, t))
+    return out
+
+
+J.GridSession.score = score
+session = J.GridSession(J._joint_region(chrom, a, b), fq, parts=parts)
+runs = []
+for it in range(14):
+    session.new_run()
+    log.clear()
+    t0 = time.perf_counter()
+    J.fine_tune_read_count(init, fq, chrom, copy.copy(a), copy.copy(b), session=session)
+    t1 = time.perf_counter()
+    runs.append(round(1e3 * (t1 - t0), 1))
+print("runs (ms):", runs)
+print(f"parts {parts}: last run {1e3 * (t1 - t0):.2f} ms")
+for me, t in sorted(log, key=lambda x: x[1][0]):
+    print(f"{me:12s} set_cells {1e3 * (t[0] - t0):7.2f} -> {1e3 * (t[1] - t0):7.2f}  run -> {1e3 * (t[2] - t0):7.2f}  "
+          f"sync -> {1e3 * (t[3] - t0):7.2f}  fetch -> {1e3 * (t[4] - t0):7.2f}")
+session.close()
