@@ -158,3 +158,24 @@ def test_joint_command_long_reads_gpu_equals_oracle(capi, oracle, tmp_path):
                             str(tmp_path / "o" / "out"), seed=9, aligner=oracle.align_pairs,
                             cigar_aligner=oracle.align_pairs_cigar, scorer=oracle.joint_2d)
     assert (tmp_path / "out.repeat_size.txt").read_text() == (tmp_path / "o" / "out.repeat_size.txt").read_text()
+
+
+def test_bulk_dict_lookups_of_the_grid_rounds():
+    """joint._rows_with / _values_of: the read numbers every dict holds and their values, with all names
+    present (one C-level pass) and with some missing (the reference skips those reads)."""
+    import numpy as np
+    from nanorepeat_amd import joint as J
+    names = [f"r{i}" for i in range(7)]
+    full = {n: (i, i + 5) for i, n in enumerate(names)}
+    part = {n: float(i) for i, n in enumerate(names) if i not in (2, 5)}
+    assert J._rows_with(names, full).tolist() == list(range(7))
+    assert J._rows_with(names, full, part).tolist() == [0, 1, 3, 4, 6]
+    assert J._rows_with(names, {}).tolist() == []
+    rows = J._rows_with(names, full, part)
+    assert J._values_of(full, names, rows, np.int64).reshape(-1, 2).tolist() == [[i, i + 5] for i in (0, 1, 3, 4, 6)]
+    assert J._values_of(part, names, rows, np.float64).tolist() == [0.0, 1.0, 3.0, 4.0, 6.0]
+    assert J._values_of(full, names, np.arange(7), np.int64).shape == (7, 2)
+    assert J._values_of(full, names[:1], np.arange(1), np.int64).reshape(-1, 2).tolist() == [[0, 5]]
+    assert len(J._values_of(full, names, np.zeros(0, np.int64), np.int64)) == 0
+    bigger = dict(full); bigger["extra"] = (9, 9)                  # more keys than names: still the fast path
+    assert J._rows_with(names, bigger).tolist() == list(range(7))
