@@ -1299,10 +1299,7 @@ int nra_batch2d_set_cells(nra_batch_t* b, const int8_t* read_strand, int64_t n_c
     b->n_cands = n_cells;
     const int32_t n_reads = b->n_reads;
     const int32_t flags = b->flags;
-    const nra_scoring_t* sc = &b->scoring;
-    (void)sc;
     std::vector<NraDevRead> reads(b->host_reads);              // + the shadows of chained reads, below
-    int rc = NRA_OK;
     PhaseClock clk;
 
     std::vector<uint32_t> first((size_t)n_reads, 0), cnt((size_t)n_reads, 0);

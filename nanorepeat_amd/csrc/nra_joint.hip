@@ -143,6 +143,10 @@ __global__ __launch_bounds__(WAVE, joint_waves(R, DIR)) void k_joint_sweep(int n
     // and the floor take it with the constant folded into the substitution scores: 16.5 instructions per cell
     // instead of 20.  fo1, fo2 differ by the window payload (0 or -4) from column to column, never between the
     // two gap pieces: Hq2 = Hq + (o2 - o1).
+    // The floor of the local alignment (an alignment may start anywhere) lives in the vertical-gap state, as in the
+    // packed cell (nra_pk16.h, FF): F never falls below `fresh`, so every H is >= fresh and neither the diagonal
+    // nor the junction combine needs a max with it; lane 0's inputs get the floor through the DPP moves' `old`
+    // operand.  15.5 instructions per cell, + 5 per row on a tail sweep's boundary steps.
     const int o21 = o2 - o1;
 
     // forward sweep: the R side, row r pairs with reverse-sweep row Q-2-r.  The stored values carry
@@ -171,8 +175,8 @@ __global__ __launch_bounds__(WAVE, joint_waves(R, DIR)) void k_joint_sweep(int n
     constexpr bool KEEP_HQ2 = (DIR == 2 ? 8 : 5) * R + 45 <= 256;
     int Hq[R], Hq2[KEEP_HQ2 ? R : 1], E[R], E2[R];     // after a step: H(i,j) + fo1 / + fo2, and E_in / E2_in of column j
 #pragma unroll
-    for (int i = 0; i < R; ++i) { Hq[i] = JNEG; E[i] = JNEG; E2[i] = JNEG; if (KEEP_HQ2) Hq2[i] = JNEG; }
-    int Hbot = JNEG, Fout = JNEG, F2out = JNEG, Hup_prev = JNEG;
+    for (int i = 0; i < R; ++i) { Hq[i] = fresh + o1; E[i] = JNEG; E2[i] = JNEG; if (KEEP_HQ2) Hq2[i] = fresh + o2; }
+    int Hbot = fresh + o1, Fout = fresh, F2out = JNEG, Hup_prev = fresh + o1;     // H = 0 left of and above the matrix
     int M = fresh;                      // running lexicographic max of this lane's cells ((0, 0) to start)
     int accS = JNEG, accB = JNEG;
     int tt = NRA_PAD_T;
@@ -255,7 +259,7 @@ __global__ __launch_bounds__(WAVE, joint_waves(R, DIR)) void k_joint_sweep(int n
                     next_t = rg.l1 + rg.m1 * k1list[tk.k1_off + si] - 1;
                 }
             }
-            int F = dpp_shr1(JNEG, Fout);
+            int F = dpp_shr1(fresh, Fout);
             int F2 = dpp_shr1(JNEG, F2out);
             tt = dpp_shr1(feed, tt);
             feed = dpp_rol1(feed);
@@ -289,7 +293,6 @@ __global__ __launch_bounds__(WAVE, joint_waves(R, DIR)) void k_joint_sweep(int n
                 fo_prev = (p + 1 < wr - 1 && p + 1 >= 0) ? -4 : 0;
             }
             const int fo1p = o1 + fo_prev;
-            const int floorq = fresh + fo1p;
             const int s_eq = sA + pe - fo1p, s_ne = sB + pn - fo1p, n_eq = sN + pe - fo1p, n_ne = sN + pn - fo1p;
             const int ex1 = x1 + ex, ex2 = x2 + ex;
             const int fo1 = o1 + fo, fx1 = x1 + fx, fx2 = x2 + fx;
@@ -305,8 +308,8 @@ __global__ __launch_bounds__(WAVE, joint_waves(R, DIR)) void k_joint_sweep(int n
             }
             int sc;
             NRA_SUBST(0, sc);
-            int d = imax(Hup_prev, floorq) + sc;
-            Hup_prev = dpp_shr1(JNEG, Hbot);
+            int d = Hup_prev + sc;
+            Hup_prev = dpp_shr1(fresh + fo1, Hbot);              // lane 0: the row above the read, H = 0
             int h = JNEG, h_prev = JNEG;
             const bool at_boundary = (tt & JFLAG_BOUNDARY) != 0;
 #pragma unroll
@@ -314,7 +317,7 @@ __global__ __launch_bounds__(WAVE, joint_waves(R, DIR)) void k_joint_sweep(int n
                 int d_next = d;
                 if (i + 1 < R) {
                     NRA_SUBST(i + 1, sc);
-                    d_next = imax(Hq[i], floorq) + sc;
+                    d_next = Hq[i] + sc;
                 }
                 // E(i,j) from column j-1, lazily: E_in stays in the register for the combine
                 const int ein = DIR == 0 ? imax(E[i] + ex1, Hq[i] + dq) : imax(E[i] + ex1, Hq[i]);
@@ -331,7 +334,7 @@ __global__ __launch_bounds__(WAVE, joint_waves(R, DIR)) void k_joint_sweep(int n
                 Hq[i] = hq;
                 const int hq2 = hq + o21;
                 if (KEEP_HQ2) Hq2[i] = hq2;
-                F = imax(F + fx1, hq);
+                F = imax(imax(F + fx1, hq), fresh);
                 F2 = imax(F2 + fx2, hq2);
                 d = d_next;
             }
@@ -339,10 +342,9 @@ __global__ __launch_bounds__(WAVE, joint_waves(R, DIR)) void k_joint_sweep(int n
             int tS = JNEG;
             if (DIR == 2) {
                 if (__builtin_amdgcn_ballot_w64(at_boundary) != 0) {
-                    const int floor_b = fresh + fo1_win;
 #pragma unroll
                     for (int i = 0; i < R; ++i) {
-                        const int t1 = imax(Hq[i], floor_b) + Hbo[i];
+                        const int t1 = Hq[i] + Hbo[i];
                         const int t2 = E[i] + Ebo[i];
                         const int t3 = E2[i] + E2bo[i];
                         tS = imax(imax(tS, t1), imax(t2, t3));
