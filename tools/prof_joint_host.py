@@ -15,7 +15,7 @@ chrom = left + u1 * 19 + mid + u2 * 7 + right
 a = J.Repeat.parse(f"chr4:{len(left)}:{len(left) + 57}:{u1}:200")
 b = J.Repeat.parse(f"chr4:{len(left) + 57 + len(mid)}:{len(left) + 57 + len(mid) + 21}:{u2}:20")
 a.max_size += 10; b.max_size += 10
-session = J.GridSession(J._joint_region(chrom, a, b), fq, device=0)
+session = J.GridSession(J._joint_region(chrom, a, b), fq, device=0, parts=1)
 def step():
     session.new_run()
     return J.fine_tune_read_count(init, fq, chrom, copy.copy(a), copy.copy(b), device=0, session=session)
