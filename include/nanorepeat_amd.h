@@ -255,7 +255,8 @@ int  nra_batch2d_set_cells(nra_batch_t* b, const int8_t* read_strand,
                            int64_t n_cells, const int32_t* cell_read,
                            const int32_t* cell_k1, const int32_t* cell_k2);
 /* A later cell list reuses what an earlier one left on the device for the same read and strand (the reverse
- * sweep over the right flank).  nra_batch2d_invalidate drops that: the next list starts like the first (a
+ * sweep over the right flank, the state of the forward sweep at the end of the left flank).  nra_batch2d_invalidate
+ * drops that: the next list starts like the first (a
  * benchmark repeating the two rounds on one resident batch calls it at the top of every repetition). */
 int  nra_batch2d_invalidate(nra_batch_t* b);
 int  nra_batch_run(nra_batch_t* b);      /* enqueue every kernel of the path; returns at once */
