@@ -350,8 +350,8 @@ void fold_small_buckets(std::vector<std::vector<int32_t>>& by_bucket, size_t min
 // executed cells of one wave sweep with 64 cells in flight (k_score_pk16, payload, joint kernels):
 // 64*R rows x (ceil((tlen+63)/64)*64) columns
 int64_t sweep_cells(int R, int tlen) { return (int64_t)64 * R * (((int64_t)tlen + 126) / 64 * 64); }
-// k_joint_sweep (reverse and tail sweeps): the step loop stops when lane 63 has taken the last column
-int64_t joint_cells(int R, int ncols) { return (int64_t)64 * R * ((int64_t)ncols + 63); }
+// k_joint_sweep (reverse and tail sweeps): the step loop stops when the lane of the read's last row has taken the last column
+int64_t joint_cells(int R, int ncols, int qlen) { return (int64_t)64 * R * ((int64_t)ncols + std::min(63, std::max(qlen - 1, 0) / R)); }
 // k_sweep_pk16: two virtual cells per lane, 128 in flight, the step loop stops with the last column
 int64_t sweep128_cells(int R, int ncols) { return (int64_t)64 * R * ((int64_t)ncols + 127); }
 
@@ -1395,7 +1395,7 @@ int nra_batch2d_set_cells(nra_batch_t* b, const int8_t* read_strand, int64_t n_c
                         if (!pair_r[pi]) { pair_r[pi] = 1; jrpk.push_back(pair); bk.cells_sweep += (int64_t)2 * 64 * bk.R * colsR; }
                     }
                     jbwd.push_back(tb);
-                    bk.cells_sweep += joint_cells(bk.R, d.l3 - (b->jpack_r ? colsR : 0));
+                    bk.cells_sweep += joint_cells(bk.R, d.l3 - (b->jpack_r ? colsR : 0), reads[r].qlen);
                     b->rev_strand[r] = 0;
                     b->rev_pending.push_back({r, given});
                 }
@@ -1436,7 +1436,7 @@ int nra_batch2d_set_cells(nra_batch_t* b, const int8_t* read_strand, int64_t n_c
                     t.n2 = (int32_t)(e - c);
                     t.state = used + slot * (uint64_t)(std::lower_bound(ks.begin(), ks.end(), t.k1) - ks.begin());
                     jtail.push_back(t);
-                    bk.cells_sweep += joint_cells(bk.R, 1 + d.l2 + d.m2 * (t.k2lo + t.k2step * (t.n2 - 1)));
+                    bk.cells_sweep += joint_cells(bk.R, 1 + d.l2 + d.m2 * (t.k2lo + t.k2step * (t.n2 - 1)), reads[r].qlen);
                     c = e;
                 }
                 k1list.insert(k1list.end(), ks.begin(), ks.end());

@@ -181,7 +181,7 @@ __global__ __launch_bounds__(WAVE, joint_waves(R, DIR)) void k_joint_sweep(int n
     int accS = JNEG, accB = JNEG;
     int tt = NRA_PAD_T;
     int j = t0 - lane;                  // real template column of this lane's next cell
-    int ncur = 0;                       // boundary counter, meaningful in lane 63 only
+    int ncur = 0;                       // boundary counter, meaningful in the output lane only
 
     if (DIR == 2) {
         // resume: the registers of every lane as the prefix sweep left them before step t0
@@ -224,10 +224,13 @@ __global__ __launch_bounds__(WAVE, joint_waves(R, DIR)) void k_joint_sweep(int n
         }
     }
 
-    // DIR 0 / 2 drain the pipeline (ncols + 63 steps); DIR 1 leaves at its last dump (step t_last)
+    // DIR 0 / 2 drain the pipeline as far as the read goes: the lanes below its last row hold padding rows only
+    // (every value there lies below one of a real row), so the boundary outputs leave through the lane of the
+    // last row and the loop ends `last_lane` steps after the last column; DIR 1 leaves at its last dump (step t_last)
     // One flat step loop (a chunk loop around a 64-step loop made the compiler keep two copies of
     // the row registers).  Every 64 steps the lanes fetch the next 64 template columns.
-    const int nsteps = DIR == 1 ? ncols + 1 : ncols + 63;
+    const int last_lane = imin(63, imax(Q - 1, 0) / R);
+    const int nsteps = DIR == 1 ? ncols + 1 : ncols + last_lane;
     int feed = NRA_PAD_T;
 #pragma unroll 1   // unrolling the step loop twice takes minutes to compile at R >= 20
     for (int step = step0; step < nsteps; ++step) {
@@ -364,7 +367,7 @@ __global__ __launch_bounds__(WAVE, joint_waves(R, DIR)) void k_joint_sweep(int n
             accS = imax(accS_in, tS);
             accB = imax(accB_in, M);
 
-            if (DIR != 1 && lane == 63 && at_boundary) {
+            if (DIR != 1 && lane == last_lane && at_boundary) {
                 if (DIR == 0) {
                     read_a[tk.read] = accB;                  // best alignment inside R (packed)
                 } else {
