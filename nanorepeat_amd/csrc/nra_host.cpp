@@ -509,6 +509,33 @@ public:
         done.wait(lk, [&] { return pending == 0; });
         fn = nullptr;
     }
+
+    // The same job in two halves: start() hands the n pieces to the workers and returns, finish() -- same thread --
+    // takes what is left of them and waits for the rest.  `f` has to stay alive in between.
+    void start(int n, const std::function<void(int)>& f)
+    {
+        job_mu.lock();
+        std::unique_lock<std::mutex> lk(mu);
+        while ((int)threads.size() < n) { threads.emplace_back([this] { loop(); }); threads.back().detach(); }
+        fn = &f; n_jobs = n; next = 0; pending = n;
+        ++generation;
+        wake.notify_all();
+    }
+    void finish()
+    {
+        std::unique_lock<std::mutex> lk(mu);
+        while (next < n_jobs) {
+            const int i = next++;
+            lk.unlock();
+            (*fn)(i);
+            lk.lock();
+            --pending;
+        }
+        done.wait(lk, [&] { return pending == 0; });
+        fn = nullptr;
+        lk.unlock();
+        job_mu.unlock();
+    }
 };
 // never destroyed: the workers wait on its condition variable for the life of the process, and destroying
 // a condition variable that has waiters blocks (glibc) -- at exit that is a hang
@@ -521,8 +548,10 @@ struct PackedReads {
     bool has_n = false;
 };
 
-int pack_reads(int32_t n_reads, const char* seqs, const int64_t* seq_off, const int32_t* read_region,
-               int32_t n_regions, PackedReads& out, int64_t max_len = NRA_MAX_QLEN_1BLOCK)
+// Layout of the packed reads (offsets, lengths, regions) and the zeroed word arrays; the words themselves are
+// written by PackJob below.
+int pack_layout(int32_t n_reads, const int64_t* seq_off, const int32_t* read_region,
+                int32_t n_regions, PackedReads& out, int64_t max_len = NRA_MAX_QLEN_1BLOCK)
 {
     out.reads.resize((size_t)n_reads);
     uint64_t base = 0;
@@ -543,38 +572,76 @@ int pack_reads(int32_t n_reads, const char* seqs, const int64_t* seq_off, const 
     }
     out.q2bit.assign((size_t)(base / 16) + 1, 0);
     out.nmask.assign((size_t)(base / 32) + 1, 0);
-    // every read starts on a 32-base boundary, so reads write disjoint words: encode in parallel
-    // one worker per ~256 k bases, each a contiguous run of reads
-    const unsigned hw = std::max(1u, std::thread::hardware_concurrency());
-    const int nthreads = (int)std::max<uint64_t>(1, std::min<uint64_t>(std::min<unsigned>(hw, 16), base >> 18));
-    std::vector<uint8_t> saw_n((size_t)nthreads, 0);
-    auto work = [&](int t) {
-        uint32_t any_n = 0;
-        const int32_t r0 = (int32_t)((int64_t)n_reads * t / nthreads), r1 = (int32_t)((int64_t)n_reads * (t + 1) / nthreads);
-        for (int32_t r = r0; r < r1; ++r) {
-            const uint8_t* s = reinterpret_cast<const uint8_t*>(seqs + seq_off[r]);
-            const int32_t len = out.reads[r].qlen;
-            uint32_t* q2 = out.q2bit.data() + (out.reads[r].qoff >> 4);
-            uint32_t* nm = out.nmask.data() + (out.reads[r].qoff >> 5);
-            for (int32_t i = 0; i < len; i += 32) {
-                const int32_t n = std::min(32, len - i);
-                uint64_t w = 0;                    // 32 bases x 2 bits; an N keeps code 0 and sets its mask bit
-                uint32_t mask = 0;
-                for (int32_t j = 0; j < n; ++j) {  // branch-free: code 4 (N) = 0b100 -> bits 0..1 = 0, bit 2 = the mask
-                    const uint32_t c = kBaseCode[s[i + j]];
-                    w |= (uint64_t)(c & 3u) << (2 * j);
-                    mask |= (c >> 2) << j;
+    return NRA_OK;
+}
+
+// The 2-bit packing itself, on the worker pool.  Every read starts on a 32-base boundary, so reads write disjoint
+// words: one piece per ~256 k bases, each a contiguous run of reads.  The constructor starts the workers and
+// returns -- the caller goes on with whatever needs the layout only (buckets, tasks) -- and join() (or the
+// destructor, on an early return) takes the pieces that are left and waits; `has_n` is known after that.
+class PackJob {
+    PackedReads& out;
+    const char* seqs;
+    const int64_t* seq_off;
+    int32_t n_reads;
+    int nthreads = 1;
+    std::vector<uint8_t> saw_n;
+    std::function<void(int)> work;
+    bool running = false;
+
+public:
+    PackJob(int32_t n_reads_, const char* seqs_, const int64_t* seq_off_, PackedReads& out_)
+        : out(out_), seqs(seqs_), seq_off(seq_off_), n_reads(n_reads_)
+    {
+        const uint64_t base = (uint64_t)(out.q2bit.size() - 1) * 16;
+        const unsigned hw = std::max(1u, std::thread::hardware_concurrency());
+        nthreads = (int)std::max<uint64_t>(1, std::min<uint64_t>(std::min<unsigned>(hw, 16), base >> 18));
+        saw_n.assign((size_t)nthreads, 0);
+        work = [this](int t) {
+            uint32_t any_n = 0;
+            const int32_t r0 = (int32_t)((int64_t)n_reads * t / nthreads), r1 = (int32_t)((int64_t)n_reads * (t + 1) / nthreads);
+            for (int32_t r = r0; r < r1; ++r) {
+                const uint8_t* s = reinterpret_cast<const uint8_t*>(seqs + seq_off[r]);
+                const int32_t len = out.reads[r].qlen;
+                uint32_t* q2 = out.q2bit.data() + (out.reads[r].qoff >> 4);
+                uint32_t* nm = out.nmask.data() + (out.reads[r].qoff >> 5);
+                for (int32_t i = 0; i < len; i += 32) {
+                    const int32_t n = std::min(32, len - i);
+                    uint64_t w = 0;                    // 32 bases x 2 bits; an N keeps code 0 and sets its mask bit
+                    uint32_t mask = 0;
+                    for (int32_t j = 0; j < n; ++j) {  // branch-free: code 4 (N) = 0b100 -> bits 0..1 = 0, bit 2 = the mask
+                        const uint32_t c = kBaseCode[s[i + j]];
+                        w |= (uint64_t)(c & 3u) << (2 * j);
+                        mask |= (c >> 2) << j;
+                    }
+                    q2[(i >> 4)] = (uint32_t)w;
+                    if (n > 16) q2[(i >> 4) + 1] = (uint32_t)(w >> 32);
+                    nm[i >> 5] = mask;
+                    any_n |= mask;
                 }
-                q2[(i >> 4)] = (uint32_t)w;
-                if (n > 16) q2[(i >> 4) + 1] = (uint32_t)(w >> 32);
-                nm[i >> 5] = mask;
-                any_n |= mask;
             }
-        }
-        saw_n[(size_t)t] = any_n ? 1 : 0;
-    };
-    g_workers.run(nthreads, work);
-    for (uint8_t v : saw_n) out.has_n |= v != 0;
+            saw_n[(size_t)t] = any_n ? 1 : 0;
+        };
+        if (nthreads > 1) { g_workers.start(nthreads, work); running = true; }
+        else work(0);
+    }
+    void join()
+    {
+        if (running) { g_workers.finish(); running = false; }
+        for (uint8_t v : saw_n) out.has_n |= v != 0;
+    }
+    ~PackJob() { if (running) g_workers.finish(); }
+    PackJob(const PackJob&) = delete;
+    PackJob& operator=(const PackJob&) = delete;
+};
+
+int pack_reads(int32_t n_reads, const char* seqs, const int64_t* seq_off, const int32_t* read_region,
+               int32_t n_regions, PackedReads& out, int64_t max_len = NRA_MAX_QLEN_1BLOCK)
+{
+    const int rc = pack_layout(n_reads, seq_off, read_region, n_regions, out, max_len);
+    if (rc) return rc;
+    PackJob job(n_reads, seqs, seq_off, out);
+    job.join();
     return NRA_OK;
 }
 
@@ -700,10 +767,12 @@ int nra_batch1d_create(int device, const nra_region_t* regions, int32_t n_region
 
     PhaseClock clk;
     clk.mark("device, stream");
+    // the workers pack the reads while this thread builds templates, buckets and tasks from the layout
     PackedReads pr;
-    rc = pack_reads(n_reads, seqs, seq_off, read_region, n_regions, pr, NRA_MAX_QLEN);
+    rc = pack_layout(n_reads, seq_off, read_region, n_regions, pr, NRA_MAX_QLEN);
     if (rc) return rc;
-    clk.mark("2-bit packing");
+    PackJob packing(n_reads, seqs, seq_off, pr);
+    clk.mark("read layout, packing started");
 
     // per-region largest k, candidate offsets
     std::vector<int32_t> region_kmax((size_t)n_regions, 0);
@@ -727,7 +796,7 @@ int nra_batch1d_create(int device, const nra_region_t* regions, int32_t n_region
     // code pool + region table
     std::vector<uint8_t> pool;
     std::vector<NraDevRegion> dregs((size_t)n_regions);
-    bool has_n = pr.has_n;
+    bool has_n = false;                          // templates; the reads' share is known when the packing is over
     for (int32_t g = 0; g < n_regions; ++g) {
         const nra_region_t& rg = regions[g];
         NraDevRegion d{};
@@ -745,7 +814,6 @@ int nra_batch1d_create(int device, const nra_region_t* regions, int32_t n_region
         if (pool.size() > 0xfff00000ull) return fail(NRA_E_RANGE, "template pool exceeds 4 GB");
     }
     pool.push_back(0);
-    b->has_n = has_n ? 1 : 0;
 
     // buckets by rows-per-lane; tasks
     const bool all_ext = (flags & NRA_F_ALL_EXTENTS) != 0;
@@ -950,6 +1018,9 @@ int nra_batch1d_create(int device, const nra_region_t* regions, int32_t n_region
     }
     const size_t nb = b->buckets.size();
     clk.mark("templates, buckets, tasks");
+    packing.join();
+    b->has_n = (has_n || pr.has_n) ? 1 : 0;
+    clk.mark("2-bit packing (rest)");
 
     // one chunk for everything: ~7 B per read base, ~40 B per candidate, the tasks, the chain strips
     b->arena.expect(pr.q2bit.size() * 16 * 2 + (size_t)snap_total * 4 + (size_t)total * 40 + pool.size() + sweep_tasks.size() * sizeof(NraSweepTask) +
