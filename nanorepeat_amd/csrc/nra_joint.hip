@@ -18,7 +18,7 @@
 //     stores H, E_in, E2_in; the running maximum is A = the best alignment inside R.
 //   forward sweep: read vs L + u1^k1 + mid + u2^k2hi, window open from a = max(0,|L|-10)
 //     on.  At every requested k2 boundary each row combines with the R side:
-//        max(H, fresh) + Hb,   E_in + Eb_in + (q, +2),   E2_in + E2b_in + (q2, +2)
+//        H + Hb,   E_in + Eb_in + (q, +2),   E2_in + E2b_in + (q2, +2)        (H >= (0, 0): the floor, below)
 //     -- a gap spanning the junction gets one open refunded, and +2 of window score, because
 //     both sides charged a "first overlapped base" --  and V = max(S, B, A) is the cell's
 //     (score, window score).
@@ -31,12 +31,13 @@
 //     LAST column of L + u1^k1; lane l is l columns behind, still inside the shared prefix);
 //   tail sweep (DIR 2), one per (read, k1) run of cells: loads that state and carries on with
 //     that last column followed by mid + u2^k2hi -- bit for bit the uninterrupted sweep over
-//     L + u1^k1 + mid + u2^k2hi, for 1 + |mid| + m2*k2hi + 63 steps instead of all of them.
+//     L + u1^k1 + mid + u2^k2hi, for 1 + |mid| + m2*k2hi steps + one per lane the read occupies instead of
+//     all of them.
 //
 // Columns without window payload.  The window takes the last 10 bases of L and the first 10 of R; before
 // it every cell's payload is the constant 0, so the first |L| - 10 columns of the prefix sweep and the first
 // |R| - 10 of the reverse sweep are plain score cells: k_joint_pk16 sweeps them in packed int16, TWO reads per
-// wave at 15.5 instead of 2 x 20 instructions per row and column (the cell of the 1D sweeps, nra_pk16.h, no
+// wave at 14.5 instead of 2 x 15.5 instructions per row and column (the cell of the 1D sweeps, nra_pk16.h, no
 // origin bit), and leaves the wave state -- every lane's rows and hand-off values as they stand when lane 0 is
 // about to take the first window column -- for the int32 sweep of each read to resume from (`resume`).  The
 // L side depends on the read alone, not on the cell list: it is kept from one grid round to the next.
