@@ -850,6 +850,7 @@ int nra_batch1d_create(int device, const nra_region_t* regions, int32_t n_region
         }
     }
     b->brute = brute;
+    clk.mark("  candidate offsets, templates, chained flags");
     std::vector<NraSweepTask> sweep_tasks;
     uint64_t snap_total = 0;
     // the chained reads (every read with NRA_F_TEST_CHAIN): bucket kNumR = int32 cells, one read per wave;
@@ -878,6 +879,7 @@ int nra_batch1d_create(int device, const nra_region_t* regions, int32_t n_region
     if ((!by_bucket[kNumR].empty() || !by_bucket[kNumR + 1].empty()) && brute)
         return fail(NRA_E_RANGE, "NRA_F_TEST_CHAIN needs the junction decomposition (no brute force / ALL_EXTENTS, flanks >= 1)");
     b->chain_cap = (chain_cols + 127) / 64 * 64 + 64;
+    clk.mark("  reads to buckets");
     {   // small buckets fold into the next instantiation of their own kind
         std::vector<std::vector<int32_t>> full(by_bucket.begin(), by_bucket.begin() + kNumR);
         std::vector<std::vector<int32_t>> halfb(by_bucket.begin() + kNumR + 2, by_bucket.end());
@@ -885,6 +887,7 @@ int nra_batch1d_create(int device, const nra_region_t* regions, int32_t n_region
         fold_small_buckets(halfb, 2048, 2);
         for (int i = 0; i < kNumR; ++i) { by_bucket[i] = std::move(full[i]); by_bucket[kNumR + 2 + i] = std::move(halfb[i]); }
     }
+    clk.mark("  small buckets folded");
     size_t strip_total = 0;
     std::vector<NraPairTask> pair_tasks;
     std::vector<NraTask> queue_tasks;       // ALL_EXTENTS only; otherwise just capacity
