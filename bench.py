@@ -35,7 +35,7 @@ import subprocess
 import sys
 import time
 
-# before torch starts the HIP runtime: the library's default (nra_host.cpp, g_hw_queues_default)
+# before torch starts the HIP runtime: nanorepeat_amd.RECOMMENDED_ENV (an entry point's choice, not the library's)
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 
 ROOT = os.path.dirname(os.path.abspath(__file__))

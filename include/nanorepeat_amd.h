@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define NRA_ABI_VERSION 2
+#define NRA_ABI_VERSION 3
 
 /* error codes */
 #define NRA_OK            0
@@ -131,6 +131,11 @@ const char* nra_version(void);
 const char* nra_last_error(void);
 int         nra_device_count(void);              /* < 0 on error */
 void        nra_default_scoring(nra_scoring_t* sc);
+/* The library keeps a few device chunks (<= 2 GiB per device), pinned staging buffers, streams and events of
+ * destroyed batches for the next call (hipMalloc / hipStreamCreate dominate a small one-shot call otherwise), and
+ * gives the chunks back by itself when a device allocation fails.  This call gives them back now (device < 0: on
+ * every device); batches that are alive are not touched. */
+int         nra_release_cached_memory(int device);
 
 /* ---- 1D: replaces round3_estimation(data_type, fast_mode, repeat_region, num_cpu)
  *      nanoRepeat_bam.py:446-450 (= round3_align :452-500, one pymm2.main call per

@@ -23,7 +23,7 @@ F_NO_JOINT_PACK = 64  # testing / comparison, 2D: int32 payload cells also outsi
 
 # every symbol include/nanorepeat_amd.h declares
 EXPORTS = ("nra_abi_version", "nra_version", "nra_last_error", "nra_device_count",
-           "nra_default_scoring", "nra_round3_1d", "nra_joint_2d", "nra_align_pairs", "nra_align_pairs_cigar", "nra_batch1d_create",
+           "nra_default_scoring", "nra_release_cached_memory", "nra_round3_1d", "nra_joint_2d", "nra_align_pairs", "nra_align_pairs_cigar", "nra_batch1d_create",
            "nra_batch2d_create", "nra_batch2d_create_reads", "nra_batch2d_set_cells", "nra_batch2d_invalidate", "nra_batch_run", "nra_batch_sync", "nra_batch_stats",
            "nra_batch1d_fetch", "nra_batch2d_fetch", "nra_batch_destroy")
 
@@ -87,6 +87,8 @@ def load():
     lib.nra_last_error.restype = C.c_char_p
     lib.nra_device_count.restype = C.c_int
     lib.nra_default_scoring.argtypes = [C.POINTER(Scoring)]
+    lib.nra_release_cached_memory.restype = C.c_int
+    lib.nra_release_cached_memory.argtypes = [C.c_int]
     lib.nra_round3_1d.restype = C.c_int
     lib.nra_round3_1d.argtypes = [C.c_int, C.POINTER(Region), C.c_int32, C.c_int32, C.c_char_p, pi64,
                                   pi32, pi32, pi32, C.POINTER(Scoring), C.c_int32,
@@ -148,6 +150,11 @@ def device_count():
     if n < 0:
         raise NraError(n, load().nra_last_error().decode(errors="replace"))
     return n
+
+
+def release_cached_memory(device=-1):
+    """Give the library's cached device chunks and pinned buffers back to the runtime (all devices by default)."""
+    _check(load().nra_release_cached_memory(device))
 
 
 def _ptr(a, ty):

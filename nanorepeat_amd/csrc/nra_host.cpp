@@ -153,7 +153,7 @@ struct DevBuf {
         if (count == 0) count = 1;
         if (g_arena) { owned = false; return g_arena->alloc(count * sizeof(T), (void**)&p); }
         owned = true;
-        return hipMalloc((void**)&p, count * sizeof(T));
+        return hipMalloc((void**)&p, count * sizeof(T));      // (outside an arena: small, short-lived buffers only)
     }
     hipError_t upload(const std::vector<T>& v)
     {
@@ -192,10 +192,22 @@ struct HandlePool {
         }
         return timing ? hipEventCreate(out) : hipEventCreateWithFlags(out, hipEventDisableTiming);
     }
-    // device chunks of destroyed arenas (hipMalloc + hipFree cost ~0.5 ms per one-shot call): a few are kept
+    // device chunks of destroyed arenas (hipMalloc + hipFree cost ~0.5 ms per one-shot call): a few are kept,
+    // per device at most kMaxCachedChunks / kMaxCachedBytes; when an allocation fails they are given back first
     std::vector<std::vector<std::pair<char*, size_t>>> chunks;      // [device]
-    size_t cached_bytes = 0;
+    std::vector<size_t> cached_bytes;                                // [device]
     static constexpr size_t kMaxCachedBytes = (size_t)2 << 30;
+    static constexpr size_t kMaxCachedChunks = 6;
+    void chunks_trim(int device)        // give every cached chunk of the device back to the runtime
+    {
+        std::vector<std::pair<char*, size_t>> mine;
+        {
+            std::lock_guard<std::mutex> lk(mu);
+            mine.swap(at(chunks, device));
+            at(cached_bytes, device) = 0;
+        }
+        for (auto& c : mine) (void)hipFree(c.first);
+    }
     hipError_t chunk_get(int device, size_t bytes, char** out, size_t* got)
     {
         {
@@ -204,22 +216,29 @@ struct HandlePool {
             for (size_t i = 0; i < v.size(); ++i)
                 if (v[i].second >= bytes && v[i].second <= 2 * bytes + ((size_t)16 << 20)) {
                     *out = v[i].first; *got = v[i].second;
-                    cached_bytes -= v[i].second;
+                    at(cached_bytes, device) -= v[i].second;
                     v.erase(v.begin() + (long)i);
                     return hipSuccess;
                 }
         }
         *got = bytes;
-        return hipMalloc((void**)out, bytes);
+        hipError_t e = hipMalloc((void**)out, bytes);
+        if (e == hipErrorOutOfMemory) {          // idle cached chunks may be what is missing: release them, try once more
+            (void)hipGetLastError();
+            chunks_trim(device);
+            e = hipMalloc((void**)out, bytes);
+        }
+        return e;
     }
     void chunk_put(int device, char* p, size_t bytes)
     {
         {
             std::lock_guard<std::mutex> lk(mu);
             auto& v = at(chunks, device);
-            if (v.size() < 6 && cached_bytes + bytes <= kMaxCachedBytes) {
+            size_t& held = at(cached_bytes, device);
+            if (v.size() < kMaxCachedChunks && held + bytes <= kMaxCachedBytes) {
                 v.push_back({p, bytes});
-                cached_bytes += bytes;
+                held += bytes;
                 return;
             }
         }
@@ -241,6 +260,12 @@ struct HandlePool {
         *got = bytes;
         return hipHostMalloc(out, bytes, hipHostMallocDefault);
     }
+    void pinned_trim()
+    {
+        std::vector<std::pair<void*, size_t>> mine;
+        { std::lock_guard<std::mutex> lk(mu); mine.swap(pinned); }
+        for (auto& c : mine) (void)hipHostFree(c.first);
+    }
     void pinned_put(void* p, size_t bytes)
     {
         std::lock_guard<std::mutex> lk(mu);
@@ -260,12 +285,10 @@ struct HandlePool {
 };
 HandlePool g_handles;
 
-// A batch runs every rows-per-lane bucket's kernels on streams of its own (and the joint mode two batches at a
-// time, joint.py GridSession): with HIP's default of 4 hardware queues, copies and short kernels wait behind
-// another stream's long sweeps that happen to share their queue (config 3: 25.6 -> 19.2 ms per run with 8).
-// Only a default -- the variable counts when the HIP runtime starts, so a host process that wants another
-// value, or has started HIP already, keeps its own.
-const int g_hw_queues_default = setenv("GPU_MAX_HW_QUEUES", "8", 0);
+// (A batch runs every rows-per-lane bucket's kernels on streams of its own, the joint mode two batches at a time:
+// with HIP's default of 4 hardware queues, copies and short kernels wait behind another stream's long sweeps.
+// GPU_MAX_HW_QUEUES=8 helps -- config 3: 25.6 -> 19.2 ms per run -- but the environment belongs to the host
+// process: the library does not touch it; see nanorepeat_amd.apply_recommended_env and INTEGRATION.md.)
 hipError_t device_chunk_get(int device, size_t bytes, char** out, size_t* got) { return g_handles.chunk_get(device, bytes, out, got); }
 void device_chunk_put(int device, char* p, size_t bytes) { g_handles.chunk_put(device, p, bytes); }
 
@@ -347,6 +370,15 @@ void fold_small_buckets(std::vector<std::vector<int32_t>>& by_bucket, size_t min
     }
 }
 
+// Scratch strips of a chained launch: one per wave, `bytes_per_strip` each (a few values per template column).  As
+// many as there are tasks, at most `most`, and no more than fit the budget: a very wide template (up to
+// NRA_MAX_TLEN_WIDE columns: 160 - 190 MB per strip) gets fewer waves, never none.
+int chain_strips(size_t n_tasks, int most, size_t bytes_per_strip, size_t budget = NRA_CHAIN_SCRATCH_BUDGET)
+{
+    const size_t fit = std::max<size_t>(1, budget / std::max<size_t>(bytes_per_strip, 1));
+    return (int)std::max<size_t>(1, std::min(std::min<size_t>(n_tasks, (size_t)most), fit));
+}
+
 // executed cells of one wave sweep with 64 cells in flight (k_score_pk16, payload, joint kernels):
 // 64*R rows x (ceil((tlen+63)/64)*64) columns
 int64_t sweep_cells(int R, int tlen) { return (int64_t)64 * R * (((int64_t)tlen + 126) / 64 * 64); }
@@ -409,6 +441,7 @@ struct nra_batch {
     std::vector<JointGroup> jgroups;
     bool all_strands_given = false;             // 2D: every read came with its strand, no probe needed
     int chain_cap = 0;
+    int payload_strips = 0;                     // waves of a chained payload launch (strips in chain_payload)
     DevBuf<NraTask> queue_tasks;
     DevBuf<int32_t> queue_count;   // per bucket: prebuilt queue length (constant)
     DevBuf<int32_t> tie_count;     // per bucket: tie queue length (device-written)
@@ -730,6 +763,22 @@ int nra_device_count(void)
     return n;
 }
 
+int nra_release_cached_memory(int device)
+{
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return fail(NRA_E_DEVICE, "no HIP device");
+    if (device >= ndev) return fail(NRA_E_ARG, "device index out of range");
+    int prev = 0;
+    (void)hipGetDevice(&prev);
+    for (int d = device < 0 ? 0 : device; d < (device < 0 ? ndev : device + 1); ++d) {
+        (void)hipSetDevice(d);
+        g_handles.chunks_trim(d);
+    }
+    g_handles.pinned_trim();
+    (void)hipSetDevice(prev);
+    return NRA_OK;
+}
+
 void nra_default_scoring(nra_scoring_t* sc)
 {
     if (!sc) return;
@@ -888,7 +937,7 @@ int nra_batch1d_create(int device, const nra_region_t* regions, int32_t n_region
         for (int i = 0; i < kNumR; ++i) { by_bucket[i] = std::move(full[i]); by_bucket[kNumR + 2 + i] = std::move(halfb[i]); }
     }
     clk.mark("  small buckets folded");
-    size_t strip_total = 0;
+    size_t strip_total = 0, chain_queue_cap = 0;
     std::vector<NraPairTask> pair_tasks;
     std::vector<NraTask> queue_tasks;       // ALL_EXTENTS only; otherwise just capacity
     std::vector<int32_t> queue_count;
@@ -1007,9 +1056,12 @@ int nra_batch1d_create(int device, const nra_region_t* regions, int32_t n_region
             }
             bk.n_sweep = (int)(sweep_tasks.size() - bk.sweep_off);
             if (bk.chain) {
-                bk.n_strips = std::min(bk.n_sweep, bk.ring ? NRA_RING_CHAIN_STRIPS : NRA_CHAIN_STRIPS);
+                // (two chained buckets at most -- packed and int32 -- share the budget)
+                bk.n_strips = chain_strips((size_t)bk.n_sweep, bk.ring ? NRA_RING_CHAIN_STRIPS : NRA_CHAIN_STRIPS,
+                                           (size_t)10 * 4 * (size_t)b->chain_cap, NRA_CHAIN_SCRATCH_BUDGET / 2);
                 bk.strip_off = strip_total;
                 strip_total += (size_t)bk.n_strips * 10 * (size_t)b->chain_cap;
+                chain_queue_cap = std::max(chain_queue_cap, bk.queue_cap);
             }
         }
         bk.n_pair = (int)(pair_tasks.size() - bk.pair_off);
@@ -1028,6 +1080,7 @@ int nra_batch1d_create(int device, const nra_region_t* regions, int32_t n_region
     // one chunk for everything: ~7 B per read base, ~40 B per candidate, the tasks, the chain strips
     b->arena.expect(pr.q2bit.size() * 16 * 2 + (size_t)snap_total * 4 + (size_t)total * 40 + pool.size() + sweep_tasks.size() * sizeof(NraSweepTask) +
                     pair_tasks.size() * sizeof(NraPairTask) + (size_t)n_reads * 64 + (4u << 20));
+    // (the chain strips get chunks of their own: they can be GBs)
     HIP_TRY(b->pool.upload(pool));
     HIP_TRY(b->q2bit.upload(pr.q2bit));
     HIP_TRY(b->qnmask.upload(pr.nmask));
@@ -1042,7 +1095,9 @@ int nra_batch1d_create(int device, const nra_region_t* regions, int32_t n_region
     HIP_TRY(b->cand_flag.alloc((size_t)total));
     if (strip_total) {
         HIP_TRY(b->chain_sweep.alloc(strip_total));
-        HIP_TRY(b->chain_payload.alloc((size_t)NRA_CHAIN_STRIPS * 6 * (size_t)b->chain_cap));   // the buckets' extents launches run in turn
+        // the chained buckets' extents launches run in turn and share these strips (int64 cells)
+        b->payload_strips = chain_strips(chain_queue_cap, NRA_CHAIN_STRIPS, (size_t)6 * 8 * (size_t)b->chain_cap);
+        HIP_TRY(b->chain_payload.alloc((size_t)b->payload_strips * 6 * (size_t)b->chain_cap));
     }
     if (all_ext) HIP_TRY(b->queue_tasks.upload(queue_tasks));
     else HIP_TRY(b->queue_tasks.alloc(queue_total));
@@ -1128,7 +1183,7 @@ static int run_1d(nra_batch* b)
                 LAUNCH_TRY(nra_launch_sweep_bwd(bk.R, b->has_n, bk.chain ? 1 : 0, q, bk.n_sweep, b->sweep_tasks.p + bk.sweep_off,
                                                 b->reads.p, b->regions.p, b->pool.p, b->q2bit.p, b->qnmask.p, b->sp,
                                                 b->kmin.p, b->kmax.p, b->coff.p, b->snap.p,
-                                                b->read_a1d.p, strips, b->chain_cap));
+                                                b->read_a1d.p, strips, b->chain_cap, bk.n_strips));
             HIP_TRY(hipEventRecord(b->ev[ev++], q));
             HIP_TRY(hipEventRecord(b->ev[ev++], q));
             if (bk.ring && bk.chain)
@@ -1152,7 +1207,7 @@ static int run_1d(nra_batch* b)
                                                 b->reads.p, b->regions.p, b->pool.p, b->q2bit.p, b->qnmask.p, b->sp,
                                                 b->kmin.p, b->kmax.p, b->coff.p, b->snap.p,
                                                 b->read_a1d.p, b->cand_score.p, b->cand_flag.p,
-                                                strips, b->chain_cap));
+                                                strips, b->chain_cap, bk.n_strips));
             HIP_TRY(hipEventRecord(b->ev[ev++], q));
             b->n_score_ev += 2;
             HIP_TRY(hipEventRecord(b->bdone[i], q));
@@ -1190,7 +1245,7 @@ static int run_1d(nra_batch* b)
             HIP_TRY(hipEventRecord(b->ev[ev++], st));
             // chained reads: int64 cells (scores and extents of any size)
             LAUNCH_TRY(nra_launch_payload_origin(bk.chain ? bk.payload_R : bk.R, b->has_n, st,
-                                              (int)std::min<size_t>(bk.queue_cap, bk.chain ? NRA_CHAIN_STRIPS : max_waves),
+                                              (int)std::min<size_t>(bk.queue_cap, bk.chain ? (size_t)b->payload_strips : (size_t)max_waves),
                                               b->queue_tasks.p + bk.queue_off, b->tie_count.p + i,
                                               b->reads.p, b->regions.p, b->pool.p,
                                               b->q2bit.p, b->qnmask.p, b->sp, b->cand_score.p,
@@ -1581,7 +1636,9 @@ int nra_batch2d_set_cells(nra_batch_t* b, const int8_t* read_strand, int64_t n_c
     HIP_TRY(b->probe_dummy.alloc(2 * (size_t)n_reads));
     if (!chain_reads.empty()) {
         b->chain_cap = (int)((tlmax + 127) / 64 * 64 + 64);
-        HIP_TRY(b->chain_payload.alloc((size_t)NRA_CHAIN_STRIPS * 6 * (size_t)b->chain_cap));
+        b->payload_strips = chain_strips(std::max(queue_tasks.size(), probe_tasks.size()), NRA_CHAIN_STRIPS,
+                                         (size_t)6 * 8 * (size_t)b->chain_cap);
+        HIP_TRY(b->chain_payload.alloc((size_t)b->payload_strips * 6 * (size_t)b->chain_cap));
     }
     if (!b->brute) {
         HIP_TRY(b->jbwd_tasks.upload(jbwd));
@@ -1680,7 +1737,7 @@ static int run_2d(nra_batch* b)
             if (bk.chain) {
                 NraScoreParams raw = b->sp;
                 raw.min_score = 0;               // the probe compares raw scores
-                LAUNCH_TRY(nra_launch_payload_origin(bk.R, b->has_n, q, std::min(bk.n_probe, NRA_CHAIN_STRIPS),
+                LAUNCH_TRY(nra_launch_payload_origin(bk.R, b->has_n, q, std::min(bk.n_probe, b->payload_strips),
                                                      b->probe_tasks.p + bk.probe_off, b->probe_count.p + i,
                                                      b->reads.p, b->regions.p, b->pool.p, b->q2bit.p, b->qnmask.p,
                                                      raw, b->probe_score.p, b->probe_dummy.p, nullptr,
@@ -1703,7 +1760,7 @@ static int run_2d(nra_batch* b)
         const Bucket& bk = b->buckets[i];
         if (!b->brute && !bk.chain) continue;
         HIP_TRY(hipEventRecord(b->ev[ev++], st));
-        LAUNCH_TRY(nra_launch_payload_window(bk.R, b->has_n, st, std::min(bk.n_queue, bk.chain ? NRA_CHAIN_STRIPS : max_waves),
+        LAUNCH_TRY(nra_launch_payload_window(bk.R, b->has_n, st, std::min(bk.n_queue, bk.chain ? b->payload_strips : max_waves),
                                           b->queue_tasks.p + bk.queue_off, b->queue_count.p + i,
                                           b->reads.p, b->regions.p, b->pool.p,
                                           b->q2bit.p, b->qnmask.p, b->sp, b->cand_score.p,
@@ -1961,7 +2018,10 @@ int nra_align_pairs(int device, int32_t n_seqs, const char* seqs, const int64_t*
     HIP_TRY(d_regs.upload(ps.dregs)); HIP_TRY(d_reads.upload(ps.dreads)); HIP_TRY(d_tasks.upload(tasks));
     HIP_TRY(d_counts.upload(counts));
     HIP_TRY(d_score.alloc((size_t)n_pairs)); HIP_TRY(d_ts.alloc((size_t)n_pairs)); HIP_TRY(d_te.alloc((size_t)n_pairs));
-    if (any_chain) HIP_TRY(d_chain.alloc((size_t)NRA_CHAIN_STRIPS * 6 * (size_t)chain_cap));
+    size_t chain_tasks = 0;
+    for (size_t i = 0; i < groups.size(); ++i) if (groups[i].chain) chain_tasks = std::max(chain_tasks, groups[i].tasks.size());
+    const int pair_strips = chain_strips(chain_tasks, NRA_CHAIN_STRIPS, (size_t)6 * 8 * (size_t)chain_cap);
+    if (any_chain) HIP_TRY(d_chain.alloc((size_t)pair_strips * 6 * (size_t)chain_cap));
     HIP_TRY(hipMemset(d_score.p, 0xff, (size_t)n_pairs * 4));
     HIP_TRY(hipMemset(d_ts.p, 0xff, (size_t)n_pairs * 4));
     HIP_TRY(hipMemset(d_te.p, 0xff, (size_t)n_pairs * 4));
@@ -1969,7 +2029,7 @@ int nra_align_pairs(int device, int32_t n_seqs, const char* seqs, const int64_t*
     for (size_t i = 0; i < groups.size(); ++i) {
         const Group& g = groups[i];
         LAUNCH_TRY(nra_launch_payload_origin(g.R, ps.has_n ? 1 : 0, nullptr,
-                                             std::min(counts[i], g.chain ? NRA_CHAIN_STRIPS : 256 * 16),
+                                             std::min(counts[i], g.chain ? pair_strips : 256 * 16),
                                              d_tasks.p + offs[i], d_counts.p + i, d_reads.p, d_regs.p,
                                              d_pool.p, d_q2.p, d_nm.p, sp, d_score.p, d_ts.p, d_te.p,
                                              g.chain ? d_chain.p : nullptr, g.chain ? chain_cap : 0, g.wide ? 1 : 0));

@@ -119,7 +119,9 @@ struct NraScoreParams {
 // per wave in int32 cells (1D sweeps) or int32 / int64 payload cells (extents, windows, free pairs)
 #define NRA_CHAIN_R 24
 #define NRA_CHAIN_R_TEST 2                     // tiny row blocks, for the tests (NRA_F_TEST_CHAIN)
-#define NRA_CHAIN_STRIPS 512                   // waves of a chained launch = scratch strips
+#define NRA_CHAIN_STRIPS 512                   // waves of a chained launch = scratch strips, at most (the host sizes them by
+                                               // the tasks there are and by NRA_CHAIN_SCRATCH_BUDGET)
+#define NRA_CHAIN_SCRATCH_BUDGET (3ull << 30)  // bytes of scratch strips per buffer: a wider template gets fewer waves
 #define NRA_MAX_QLEN 200000                    // read bases (chained row blocks above NRA_MAX_QLEN_1BLOCK)
 // int32 values per lane in one dumped wave state of the 2D prefix sweep (3 per row + 7), shared by
 // the kernel and the host so that the two cannot disagree
@@ -144,8 +146,8 @@ int nra_launch_score_pk16(int R, int has_n, hipStream_t st, int n_tasks,
                           NraScoreParams sp, int32_t* out_score);
 
 // payload kernels walk a device-side queue of *count tasks with a grid stride.  ORIGIN outputs (score, tstart,
-// tend); WINDOW outputs (score, wscore).  chain_buf != NULL: row-block chaining (n_waves <= NRA_CHAIN_STRIPS
-// strips of 6 * chain_cap cells); wide: int64 cells (R = NRA_WIDE_R_SMALL / NRA_WIDE_R_LARGE, or chained)
+// tend); WINDOW outputs (score, wscore).  chain_buf != NULL: row-block chaining (n_waves strips of
+// 6 * chain_cap cells each); wide: int64 cells (R = NRA_WIDE_R_SMALL / NRA_WIDE_R_LARGE, or chained)
 int nra_launch_payload_origin(int R, int has_n, hipStream_t st, int n_waves,
                               const NraTask* tasks, const int32_t* count,
                               const NraDevRead* reads, const NraDevRegion* regions,
@@ -163,20 +165,20 @@ int nra_launch_payload_window(int R, int has_n, hipStream_t st, int n_waves,
 
 // junction decomposition (nra_sweep.hip): the reverse sweep over rev(R) writes the R-side snapshot and A
 // (per read: read_a); the forward sweep combines and writes Score(k) + the flank-test verdict (0 fail,
-// 1 pass, 2 ambiguous).  chain: int32 cells, one read per task, at most NRA_CHAIN_STRIPS waves
+// 1 pass, 2 ambiguous).  chain: int32 cells, one read per task, min(n_tasks, n_strips) waves
 int nra_launch_sweep_bwd(int R, int has_n, int chain, hipStream_t st, int n_tasks, const NraSweepTask* tasks,
                          const NraDevRead* reads, const NraDevRegion* regions, const uint8_t* pool,
                          const uint32_t* q2bit, const uint32_t* qnmask, NraScoreParams sp,
                          const int32_t* kmin, const int32_t* kmax, const uint32_t* coff,
                          int32_t* snap,
-                         int32_t* read_a, int32_t* chain_buf, int chain_cap);
+                         int32_t* read_a, int32_t* chain_buf, int chain_cap, int n_strips);
 int nra_launch_sweep_fwd(int R, int has_n, int chain, hipStream_t st, int n_tasks, const NraSweepTask* tasks,
                          const NraDevRead* reads, const NraDevRegion* regions, const uint8_t* pool,
                          const uint32_t* q2bit, const uint32_t* qnmask, NraScoreParams sp,
                          const int32_t* kmin, const int32_t* kmax, const uint32_t* coff,
                          int32_t* snap,
                          int32_t* read_a, int32_t* cand_score, uint8_t* cand_flag, int32_t* chain_buf,
-                         int chain_cap);
+                         int chain_cap, int n_strips);
 
 // the same sweeps with the lane-to-lane hand-off through an LDS ring (k_sweep_ring: one read block per wave,
 // forward sweep skewed by the unit length so that the junction combine runs on every m-th step only);

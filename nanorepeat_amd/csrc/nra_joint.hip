@@ -442,6 +442,7 @@ __global__ __launch_bounds__(WAVE) void k_joint_pk16(int n_tasks, const NraJoint
 #pragma unroll
     for (int i = 0; i < R; ++i) { Hq[i] = v_floor; Hq2[i] = NEG1; E[i] = NEG1; E2[i] = NEG1; }
     ring[lane] = make_int4(v_floor, NEG1, NEG1, lane == 0 ? column_table(0) : tbl_mis4);
+    ring_order();
 
     int Hup_prev = v_floor, M = BIAS * P1;
     int F = NEG1, F2 = NEG1;
@@ -456,6 +457,7 @@ __global__ __launch_bounds__(WAVE) void k_joint_pk16(int n_tasks, const NraJoint
         Hup_prev = pmaxi(in.x, v_floor);
         ring[wr] = make_int4(Hq[R - 1], F, F2, in.w);
         if (lane == 63) ring[0] = make_int4(v_floor, NEG1, NEG1, feed);
+        ring_order();                                       // the next step's load stays behind these stores
         feed = dpp_rol1(feed);
     }
     int32_t* __restrict__ pv = pstate + tk.state + lane;

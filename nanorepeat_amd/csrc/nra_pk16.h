@@ -32,6 +32,14 @@ __device__ __forceinline__ int pmax3(int a, int b, int c)
     return __builtin_bit_cast(int, __builtin_elementwise_maximum(__builtin_elementwise_maximum(x, y), z));
 }
 
+// The LDS-ring hand-off (k_sweep_ring*, k_joint_pk16): lane l stores what enters lane l+1 and reads its own place one
+// or more steps later.  The hardware needs no barrier -- a wave's LDS operations execute in program order, and every
+// lane reads its place of a slot before any lane writes that place again -- but the order has to survive the
+// compiler: per thread a step's store (place wr) and the next step's load (place lane) never alias, so nothing in
+// the language keeps the load behind the store.  This fence does: wavefront scope, no instruction on gfx950 (the
+// ISA of every kernel is the same with and without it), only the ordering of the LDS accesses around it.
+__device__ __forceinline__ void ring_order() { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); }
+
 // cell arithmetic of the sweeps: packed int16 pairs (two reads per wave, biased), or -- WIDE, the chained
 // sweeps of reads longer than one register block -- plain int32 (one read per wave, no bias, no range limit)
 template <bool W> __device__ __forceinline__ int mx2(int a, int b) { return W ? imax(a, b) : pmaxi(a, b); }

@@ -547,6 +547,7 @@ __global__ __launch_bounds__(WAVE * SWEEP_RING_WPB) void k_sweep_ring(int n_task
     for (int s = 0; s < SWEEP_RING_D; ++s) ring[s * 64 + lane] = make_int4(v_floor, NEG1, NEG1, tbl_mis4);
     racc[lane] = make_int2(NEG2, NEG1);
     if (lane < skew) ring[lane * 64] = make_int4(v_floor, NEG1, NEG1, column_table(lane));
+    ring_order();
 
     int Hup_prev = v_floor, M = BIAS * P1;
     int feed = tbl_mis4;
@@ -571,6 +572,7 @@ __global__ __launch_bounds__(WAVE * SWEEP_RING_WPB) void k_sweep_ring(int n_task
         Hup_prev = pmaxi(in.x, fl - v_o1);
         ring[slot * 64 + wr] = make_int4(Hq[R - 1], F, F2, tt);
         if (lane == 63) ring[slot * 64] = make_int4(v_floor, NEG1, NEG1, feed);
+        ring_order();                                       // the next steps' loads stay behind these stores
         feed = dpp_rol1(feed);
         if (++slot == skew) slot = 0;
 
@@ -583,6 +585,7 @@ __global__ __launch_bounds__(WAVE * SWEEP_RING_WPB) void k_sweep_ring(int n_task
                 const int accS = pmaxi(acc.x, tS), accB = pmaxi(acc.y, M);
                 racc[wr] = make_int2(accS, accB);
                 if (lane == 63) racc[0] = make_int2(NEG2, NEG1);
+                ring_order();
                 if (bidx >= 63 && kcur <= tk.kmax) {        // lane 63 is on the boundary of k = kcur
                     int va = 0, vb = 0;
                     if (lane == 63) {
@@ -758,6 +761,7 @@ __global__ __launch_bounds__(WAVE) void k_sweep_ring32(int n_tasks, const NraSwe
     for (int s = 0; s < SWEEP_RING_D; ++s) ring[s * 64 + lane] = make_int4(v_floor, NEG1, NEG1, tbl_mis4);
     racc[lane] = make_int2(NEG2, NEG1);
     if (hl < skew) ring[hl * 64 + hoff] = make_int4(v_floor, NEG1, NEG1, column_table(hl));
+    ring_order();
 
     int Hup_prev = v_floor, M = BIAS * P1;
     int feed = tbl_mis4;
@@ -781,6 +785,7 @@ __global__ __launch_bounds__(WAVE) void k_sweep_ring32(int n_tasks, const NraSwe
         Hup_prev = pmaxi(in.x, fl - v_o1);
         ring[slot * 64 + wr] = make_int4(Hq[R - 1], F, F2, tt);
         if (hl == 31) ring[slot * 64 + hoff] = make_int4(v_floor, NEG1, NEG1, feed);
+        ring_order();                                       // the next steps' loads stay behind these stores
         feed = dpp_rol1(feed);
         if (++slot == skew) slot = 0;
 
@@ -793,6 +798,7 @@ __global__ __launch_bounds__(WAVE) void k_sweep_ring32(int n_tasks, const NraSwe
                 const int accS = pmaxi(acc.x, tS), accB = pmaxi(acc.y, M);
                 racc[wr] = make_int2(accS, accB);
                 if (hl == 31) racc[hoff] = make_int2(NEG2, NEG1);
+                ring_order();
                 if (bidx >= 31 && kcur <= tk.kmax) {        // lanes 31 and 63 are on the boundary of k = kcur
                     int va = 0, vb = 0;
                     if (hl == 31) {
@@ -983,6 +989,7 @@ __global__ __launch_bounds__(WAVE) void k_sweep_ringchain(int n_tasks, const Nra
     if (lane < skew)
         ring[lane * 64] = make_int4(strip_in(lane, 0, v_floor), strip_in(lane, 1, NEG1), strip_in(lane, 2, NEG1), column_table(lane));
     if (DIR == 1 && lane == 0) racc[0] = make_int2(strip_in(jfirst, 3, NEG2), strip_in(jfirst, 4, NEG1));
+    ring_order();
 
     int Hup_prev = v_floor, M = BIASW * P1;
     int feed = tbl_mis4, sH = v_floor, sF = NEG1, sF2 = NEG1, sS = NEG2, sB = NEG1;   // what lane 63 hands to lane 0
@@ -1005,6 +1012,7 @@ __global__ __launch_bounds__(WAVE) void k_sweep_ringchain(int n_tasks, const Nra
         Hup_prev = mx2<W>(in.x, fl - v_o1);
         ring[slot * 64 + wr] = make_int4(Hq[R - 1], F, F2, tt);
         if (lane == 63) ring[slot * 64] = make_int4(sH, sF, sF2, feed);
+        ring_order();                                       // the next steps' loads stay behind these stores
         const int c63 = step - 63 * skew;                                  // the column lane 63 has just finished
         if (lane == 63 && !last_blk && c63 >= 0) {
             cout[c63] = Hq[R - 1]; cout[chain_cap + c63] = F; cout[2 * chain_cap + c63] = F2;
@@ -1025,6 +1033,7 @@ __global__ __launch_bounds__(WAVE) void k_sweep_ringchain(int n_tasks, const Nra
                     racc[0] = make_int2(sS, sB);                           // of column step + skew: lane 0's next boundary
                     if (!last_blk && c63 >= 0) { cout[3 * chain_cap + c63] = accS; cout[4 * chain_cap + c63] = accB; }
                 }
+                ring_order();
                 if (last_blk && bidx >= 63 && kcur <= tk.kmax) {           // lane 63 is on the boundary of k = kcur
                     int va = 0, vb = 0;
                     if (lane == 63) {
@@ -1077,12 +1086,13 @@ static int launch_sweep(int R, int has_n, int chain, hipStream_t st, int n_tasks
                         const uint32_t* q2bit, const uint32_t* qnmask, NraScoreParams sp,
                         const int32_t* kmin, const int32_t* kmax, const uint32_t* coff,
                         int32_t* snap, int32_t* read_a,
-                        int32_t* cand_score, uint8_t* cand_flag, int32_t* chain_buf, int chain_cap)
+                        int32_t* cand_score, uint8_t* cand_flag, int32_t* chain_buf, int chain_cap, int n_strips)
 {
     if (n_tasks <= 0) return 0;
 #define ARGS n_tasks, tasks, reads, regions, pool, q2bit, qnmask, sp, kmin, kmax, coff, snap, read_a, cand_score, cand_flag, chain_buf, chain_cap
     if (chain) {      // row-block chaining: only the instantiations long reads (and the tests) use
-        const int n_waves = n_tasks < NRA_CHAIN_STRIPS ? n_tasks : NRA_CHAIN_STRIPS;
+        if (n_strips <= 0) return (int)hipErrorInvalidValue;
+        const int n_waves = n_tasks < n_strips ? n_tasks : n_strips;
         if (R == NRA_CHAIN_R) {
             if (has_n) k_sweep_pk16<NRA_CHAIN_R, true, DIR, true><<<n_waves, WAVE, 0, st>>>(ARGS);
             else k_sweep_pk16<NRA_CHAIN_R, false, DIR, true><<<n_waves, WAVE, 0, st>>>(ARGS);
@@ -1258,10 +1268,10 @@ extern "C" int nra_launch_sweep_bwd(int R, int has_n, int chain, hipStream_t st,
                                     const uint32_t* q2bit, const uint32_t* qnmask, NraScoreParams sp,
                                     const int32_t* kmin, const int32_t* kmax, const uint32_t* coff,
                                     int32_t* snap,
-                                    int32_t* read_a, int32_t* chain_buf, int chain_cap)
+                                    int32_t* read_a, int32_t* chain_buf, int chain_cap, int n_strips)
 {
     return launch_sweep<0>(R, has_n, chain, st, n_tasks, tasks, reads, regions, pool, q2bit, qnmask, sp, kmin, kmax,
-                           coff, snap, read_a, nullptr, nullptr, chain_buf, chain_cap);
+                           coff, snap, read_a, nullptr, nullptr, chain_buf, chain_cap, n_strips);
 }
 #endif
 #if NRA_HAS_PART(6)
@@ -1271,9 +1281,9 @@ extern "C" int nra_launch_sweep_fwd(int R, int has_n, int chain, hipStream_t st,
                                     const int32_t* kmin, const int32_t* kmax, const uint32_t* coff,
                                     int32_t* snap,
                                     int32_t* read_a, int32_t* cand_score, uint8_t* cand_flag, int32_t* chain_buf,
-                                    int chain_cap)
+                                    int chain_cap, int n_strips)
 {
     return launch_sweep<1>(R, has_n, chain, st, n_tasks, tasks, reads, regions, pool, q2bit, qnmask, sp, kmin, kmax,
-                           coff, snap, read_a, cand_score, cand_flag, chain_buf, chain_cap);
+                           coff, snap, read_a, cand_score, cand_flag, chain_buf, chain_cap, n_strips);
 }
 #endif

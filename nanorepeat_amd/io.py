@@ -90,36 +90,45 @@ def read_one_chr_from_fasta_file(fasta_file, target_chr):
     return "".join(chunks)
 
 
+def _lookup_chromosome(ref_fasta_dict, name):
+    """The chromosome under its BED name, or under the other naming convention ("chr4" <-> "4")."""
+    other = name[3:] if name.startswith("chr") else "chr" + name
+    for key in (name, other):
+        if key in ref_fasta_dict:
+            return ref_fasta_dict[key]
+    raise KeyError(f"chromosome {name} of the repeat region bed file is not in the reference fasta file")
+
+
+def _interval_problem(start, end, chr_len):
+    """Why [start, end) is not a usable repeat interval on a chromosome of chr_len bases (None: it is).
+    The reference's four checks (nanoRepeat_bam.py:91-110), which it answers with sys.exit()."""
+    for bad, why in ((start > chr_len, f"the repeat start position is larger than chromosome length: {start}"),
+                     (start < 0, "the repeat start position < 0"),
+                     (end > chr_len + 1, f"the repeat end position is larger than chromosome length: {end}"),
+                     (end < start, "end position is smaller than start position")):
+        if bad:
+            return why
+    return None
+
+
 def extract_ref_sequence(ref_fasta_dict, repeat_region, anchor_len=1000):
-    """nanoRepeat_bam.py:76-137: flanks of at most anchor_len bases on either side (clamped to the
-    chromosome), with the chr-prefix fallback and the reference's bounds checks."""
-    repeat_region.anchor_len = max(anchor_len, MIN_ANCHOR_LEN)
-    chr_name = repeat_region.chrom
-    if chr_name not in ref_fasta_dict:
-        chr_name = chr_name[3:] if chr_name[0:3] == "chr" else "chr" + chr_name
-    if chr_name not in ref_fasta_dict:
-        raise KeyError(f"chromosome {repeat_region.chrom} of the repeat region bed file is not in the reference fasta file")
-    chr_seq = ref_fasta_dict[chr_name]
-    chr_len = len(chr_seq)
-    if repeat_region.start_pos > chr_len:
-        raise ValueError(f"the repeat start position is larger than chromosome length: {repeat_region.start_pos}")
-    if repeat_region.start_pos < 0:
-        raise ValueError("the repeat start position < 0")
-    if repeat_region.end_pos > chr_len + 1:
-        raise ValueError(f"the repeat end position is larger than chromosome length: {repeat_region.end_pos}")
-    if repeat_region.end_pos < repeat_region.start_pos:
-        raise ValueError("end position is smaller than start position")
-    start_pos = max(0, repeat_region.start_pos - repeat_region.anchor_len)
-    end_pos = min(chr_len, repeat_region.end_pos + repeat_region.anchor_len)
-    repeat_region.left_anchor_seq = chr_seq[start_pos:repeat_region.start_pos]
-    repeat_region.left_anchor_len = len(repeat_region.left_anchor_seq)
-    repeat_region.right_anchor_seq = chr_seq[repeat_region.end_pos:end_pos]
-    repeat_region.right_anchor_len = len(repeat_region.right_anchor_seq)
-    repeat_region.mid_ref_seq = chr_seq[repeat_region.start_pos:repeat_region.end_pos]
-    if repeat_region.left_anchor_len == 0 and repeat_region.right_anchor_len == 0:
+    """Mirror of nanoRepeat_bam.py:76-137: sets the region's two anchors (at most anchor_len bases each,
+    clamped to the chromosome) and the reference slice between them; raises where the reference exits."""
+    rr = repeat_region
+    rr.anchor_len = max(anchor_len, MIN_ANCHOR_LEN)
+    chrom = _lookup_chromosome(ref_fasta_dict, rr.chrom)
+    problem = _interval_problem(rr.start_pos, rr.end_pos, len(chrom))
+    if problem:
+        raise ValueError(problem)
+    left = chrom[max(0, rr.start_pos - rr.anchor_len):rr.start_pos]
+    right = chrom[rr.end_pos:min(len(chrom), rr.end_pos + rr.anchor_len)]
+    if not left and not right:
         raise ValueError("there is no flanking sequence around the repeat region")
-    if repeat_region.left_anchor_len < MIN_ANCHOR_LEN and repeat_region.right_anchor_len < MIN_ANCHOR_LEN:
+    if max(len(left), len(right)) < MIN_ANCHOR_LEN:
         raise ValueError(f"both left and right flanking sequences are less than {MIN_ANCHOR_LEN} bp")
+    rr.left_anchor_seq, rr.left_anchor_len = left, len(left)
+    rr.right_anchor_seq, rr.right_anchor_len = right, len(right)
+    rr.mid_ref_seq = chrom[rr.start_pos:rr.end_pos]
 
 
 def edit_distance(a, b):

@@ -390,6 +390,12 @@ int nro_round3_1d(const nro_region_t* regions, int32_t n_regions,
     if (!regions || n_regions <= 0 || n_reads < 0 || !check_scoring(sc)) return -1;
     if (n_reads > 0 && (!seqs || !seq_off || !kmin || !kmax || !best_score || !sum_k || !n_ties || !status)) return -1;
     if (n_regions > 1 && !read_region && n_reads > 0) return -1;
+    /* bad input (a read of an unknown region, a negative k) is refused before anything is allocated or run */
+    for (int32_t r = 0; r < n_reads; ++r) {
+        if (kmin[r] > kmax[r]) continue;
+        const int32_t g = read_region ? read_region[r] : 0;
+        if (g < 0 || g >= n_regions || kmin[r] < 0 || seq_off[r + 1] < seq_off[r]) return -1;
+    }
 
     /* candidate offsets */
     int64_t* coff = (int64_t*)malloc(sizeof(int64_t) * ((size_t)n_reads + 1));
@@ -420,13 +426,11 @@ int nro_round3_1d(const nro_region_t* regions, int32_t n_regions,
     int32_t* S_all = (int32_t*)malloc(sizeof(int32_t) * 3 * (size_t)(total > 0 ? total : 1));
     int32_t* TS_all = S_all + (total > 0 ? total : 1);
     int32_t* TE_all = TS_all + (total > 0 ? total : 1);
-    int32_t* owner = (int32_t*)malloc(sizeof(int32_t) * (size_t)(total > 0 ? total : 1));
+    int32_t* owner = (int32_t*)malloc(sizeof(int32_t) * (size_t)(total > 0 ? total : 1));   /* filled for every candidate below */
     uint8_t** Q = (uint8_t**)calloc((size_t)(n_reads > 0 ? n_reads : 1), sizeof(uint8_t*));
     for (int32_t r = 0; r < n_reads; ++r) {
         best_score[r] = 0; sum_k[r] = 0; n_ties[r] = 0;
         if (kmin[r] > kmax[r]) { status[r] = 3; continue; }
-        const int32_t g = read_region ? read_region[r] : 0;
-        if (g < 0 || g >= n_regions || kmin[r] < 0) { status[r] = 3; bad = 1; continue; }
         status[r] = 0;
         const int32_t ql = (int32_t)(seq_off[r + 1] - seq_off[r]);
         Q[r] = (uint8_t*)malloc((size_t)ql + 1);
