@@ -18,17 +18,23 @@ kernel, the per-read selection (best score, flank test, tie mean) on the device,
 per-read results to the host and -- N > 1 -- the one all_gather that leaves them on every rank.
 The same product class runs at every N; there is no data-path collective.
 
-`value` is that resident-input rate (the contract of this benchmark: inputs in HBM when the clock
-starts).  SURVEY.md 8(d) defines the metric on the wall time of the scorer call from host buffers
-to host results; that figure is measured in the same run and reported beside it as `one_shot`
-(N = 1, config 2: one nra_round3_1d call = 2-bit packing + device buffers + H2D + kernels +
-selection + D2H, median of --one-shot-calls calls).
+Two rates, both at the top level of the one JSON line, named for what they time:
+  `value` / `ms_per_step`                  the resident-input rate the benchmark contract asks for (inputs in
+                                           HBM when the clock starts; what the driver's clock brackets);
+  `value_scorer_call` / `ms_per_scorer_call`  SURVEY.md 8(d)'s metric: read-alignments / wall time of ONE scorer call
+                                           from host buffers (ASCII reads) to host results = 2-bit packing +
+                                           device buffers + H2D over PCIe + kernels + selection + D2H (median of
+                                           --one-shot-calls calls; N = 1).  `cpu_baseline.gpu_over_cpu` is this one.
+The default run (N = 1, config 2) also carries `configs.config3 / config4 / config5`: the same record for the
+other BASELINE workloads at N = 1, a few steps each (--sub-configs none: skip them).
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--config 2|3|4]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--config 2|3|4|5] [--sub-configs 3,4,5|none]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W
 """
 import argparse
+import copy
+import hashlib
 import json
 import os
 import subprocess
@@ -49,7 +55,25 @@ sys.path.insert(0, ROOT)
 VALU_PEAK_TLANEOPS = 256 * 4 * 32 * 2.4e9 / 1e12      # 78.6
 LANEOPS_PER_CELL = 10.0
 HBM_PEAK_GBPS = 8000.0
-PMC_PROFILE = os.path.join("profiles", "r02_pmc_traffic.json")
+PROFILE_ROUND = "r03"
+
+
+def pmc_profile_path(config):
+    """The tracked PMC summary of `bench.py --config N` (tools/profile_bench.sh -> tools/pmc_summary.py)."""
+    tag = PROFILE_ROUND if config == 2 else f"{PROFILE_ROUND}_config{config}"
+    return os.path.join("profiles", f"{tag}_pmc_traffic.json")
+
+
+def kernel_source_sha16():
+    """Identity of the kernel sources a PMC summary belongs to: counters are only quoted when the summary was
+    taken from the sources this run was built from (tools/pmc_summary.py stores the same hash)."""
+    h = hashlib.sha256()
+    csrc = os.path.join(ROOT, "nanorepeat_amd", "csrc")
+    for name in sorted(os.listdir(csrc)):
+        if name.endswith((".hip", ".cpp", ".h")):
+            h.update(name.encode())
+            h.update(open(os.path.join(csrc, name), "rb").read())
+    return h.hexdigest()[:16]
 
 
 def parse():
@@ -67,8 +91,10 @@ def parse():
     ap.add_argument("--same-device", action="store_true",
                     help="rehearsal only: every rank uses GPU 0 (with --backend gloo on a one-GPU box)")
     ap.add_argument("--cpu-sample", type=int, default=-1,
-                    help="reads in the CPU-baseline sample (-1: sized for ~15 s, 0: skip)")
-    ap.add_argument("--one-shot-calls", type=int, default=5, help="host-buffers-in/out calls timed at N = 1 (0: skip)")
+                    help="reads in the CPU-baseline sample (-1: sized for ~15 s, ~6 s in a sub-record; 0: skip)")
+    ap.add_argument("--one-shot-calls", type=int, default=5, help="host-buffers-in/out scorer calls timed at N = 1 (0: skip)")
+    ap.add_argument("--sub-configs", default="3,4,5",
+                    help="default run (N = 1, config 2) only: the other configs measured into `configs` (none: skip)")
     return ap.parse_args()
 
 
@@ -106,7 +132,7 @@ def host_cores():
     return min(n, 16)
 
 
-def cpu_baseline_1d(data, n_sample):
+def cpu_baseline_1d(data, n_sample, seconds):
     """Times the CPU oracle (oracle/, the restatement of the reference algorithm: K independent
     optimal alignments per read) on a bounded sample of the same workload, all host cores."""
     from oracle import oracle as O
@@ -119,7 +145,7 @@ def cpu_baseline_1d(data, n_sample):
     O.round3_1d(data["regions"], data["reads"][:n_cal], data["kmin"][:n_cal], data["kmax"][:n_cal], threads=cores, **sub(n_cal))
     t_cal = max(time.perf_counter() - t0, 1e-3)
     if n_sample < 0:
-        n_sample = int(n_cal * 15.0 / t_cal)
+        n_sample = int(n_cal * seconds / t_cal)
         n_sample = max(cores, n_sample // cores * cores)
     n_sample = min(n_sample, n_total)
     if n_sample == 0:
@@ -136,7 +162,46 @@ def cpu_baseline_1d(data, n_sample):
                       f"OpenMP over reads), not minimap2"}, out
 
 
-def roofline(st0, st1, n_steps, brute, kernel_name):
+def pmc_counters(config, kernel_s, brute):
+    """Counter-derived figures from the tracked rocprofv3 --pmc summary of this command -- quoted only when the
+    summary was taken from the very kernel sources this run was built from (else: stale, nulls)."""
+    rel = pmc_profile_path(config)
+    prof = os.path.join(ROOT, rel)
+    none = {"traffic": None, "counters": None, "frac_issued": None, "issue_ceiling": None}
+    if brute or not os.path.exists(prof):
+        return dict(none, counters={"source": rel, "status": "no PMC summary for this command"})
+    try:
+        pmc = json.load(open(prof))
+    except Exception as e:
+        return dict(none, counters={"source": rel, "status": f"unreadable: {e}"})
+    sha = kernel_source_sha16()
+    if pmc.get("source_sha16") != sha:
+        return dict(none, counters={"source": rel, "status": "stale: taken from other kernel sources "
+                                                             f"({pmc.get('source_sha16')} != {sha}); not quoted"})
+    valu = pmc["sweep_kernels"]["valu_wave_instructions_per_step"]
+    issued = valu * 64.0 / kernel_s / 1e12                  # lane-op slots the issued VALU instructions fill per second
+    cyc = pmc.get("simd_cycles_per_valu_instruction_active")        # 4 x SQ_ACTIVE_INST_VALU / SQ_INSTS_VALU
+    clock = pmc.get("clock_GHz")
+    ceiling = None
+    if cyc and clock:
+        # a SIMD that issues one wave instruction (64 lanes) every `cyc` cycles at `clock`, against 32 lanes/clk at 2.4 GHz
+        c = (64.0 / cyc) / 32.0 * clock / 2.4
+        ceiling = {"cycles_per_valu_instruction": cyc, "clock_GHz": clock, "frac_issued_ceiling": c,
+                   "frac_issued_over_ceiling": issued / VALU_PEAK_TLANEOPS / c,
+                   "note": "measured issue cost of this instruction mix (packed 16-bit, 3-input and perm ops issue "
+                           "every 4 cycles on gfx950: SQ_ACTIVE_INST_VALU / SQ_INSTS_VALU = 1 quad-cycle; "
+                           "tools/ubench) at the shader clock held under this load (GRBM_GUI_ACTIVE)"}
+    return {"traffic": pmc.get("hbm_bytes_per_step_sweep_kernels"),
+            "counters": {"source": rel + " (rocprofv3 --pmc passes of this command, same kernel sources: " + sha + ")",
+                         "status": "current",
+                         "valu_wave_instructions_per_step": valu,
+                         "simd_cycles_per_valu_instruction": pmc.get("simd_cycles_per_valu_instruction"),
+                         "fetch_bytes_per_step": pmc["sweep_kernels"].get("fetch_bytes"),
+                         "write_bytes_per_step": pmc["sweep_kernels"].get("write_bytes")},
+            "frac_issued": issued / VALU_PEAK_TLANEOPS, "issue_ceiling": ceiling}
+
+
+def roofline(config, st0, st1, brute, kernel_name):
     """The dominant kernels against the integer-VALU roof, from the HIP events of the timed steps
     (st0/st1: batch statistics before/after them; the events sit on the streams the kernels run on)."""
     runs = st1["n_runs"] - st0["n_runs"]
@@ -148,30 +213,23 @@ def roofline(st0, st1, n_steps, brute, kernel_name):
     exe_cells_per_s = st1["executed_cells"] / kernel_s
     alg_cells_per_s = st1["algorithmic_cells"] / kernel_s
     achieved = exe_cells_per_s * LANEOPS_PER_CELL / 1e12
-    traffic, counters = None, None
-    prof = os.path.join(ROOT, PMC_PROFILE)
-    if os.path.exists(prof) and not brute:
-        try:
-            pmc = json.load(open(prof))
-            traffic = pmc.get("hbm_bytes_per_step_sweep_kernels")
-            counters = {"source": PMC_PROFILE + " (rocprofv3 --pmc passes of this command)",
-                        "valu_wave_instructions_per_step": pmc["sweep_kernels"]["valu_wave_instructions_per_step"],
-                        "simd_cycles_per_valu_instruction": pmc.get("simd_cycles_per_valu_instruction")}
-        except Exception:
-            traffic, counters = None, None
+    pmc = pmc_counters(config, kernel_s, brute)
     hbm_gbps = st1["algorithmic_bytes"] / kernel_s / 1e9
     return {"bound": "valu", "achieved": achieved, "peak": VALU_PEAK_TLANEOPS, "unit": "Tlane-op/s",
-            "frac": achieved / VALU_PEAK_TLANEOPS, "traffic": traffic, "counters": counters,
+            "frac": achieved / VALU_PEAK_TLANEOPS, "frac_issued": pmc["frac_issued"], "issue_ceiling": pmc["issue_ceiling"],
+            "traffic": pmc["traffic"], "counters": pmc["counters"],
             "kernel": kernel_name,
             "kernel_ms_per_step": phase_ms, "steps_averaged": runs,
             "sum_of_launch_durations_ms": launch_ms, "n_launches_per_step": st1["n_score_launches"],
             "executed_cells_per_step": st1["executed_cells"], "executed_Tcell_per_s": exe_cells_per_s / 1e12,
             "laneops_per_cell": LANEOPS_PER_CELL,
-            "note": "achieved = cells the kernels execute (row padding to 64*R and pipeline fill/drain columns "
-                    "included) x 10 lane-ops / the scoring phase's HIP-event time averaged over the timed steps "
-                    "(launches of different read-length buckets overlap on their own streams). The K-fold "
-                    "algorithmic cell count of SURVEY 8d is in 'algorithmic': the junction decomposition "
-                    "shares L+unit^k and R across the K candidates and never executes those cells",
+            "note": "frac = cells the kernels execute (row padding and pipeline fill/drain columns included) x 10 "
+                    "lane-ops (a PRICE: SURVEY 8d's estimate per two-piece-affine cell) / the scoring phase's HIP-event "
+                    "time averaged over the timed steps (launches of different read-length buckets overlap on their "
+                    "own streams) / peak.  frac_issued = VALU wave instructions actually issued (SQ_INSTS_VALU of the "
+                    "tracked PMC summary, quoted only for the same kernel sources) x 64 lanes / the same time / peak: "
+                    "the counted figure.  The K-fold algorithmic cell count of SURVEY 8d is in 'algorithmic': the "
+                    "junction decomposition shares L+unit^k and R across the K candidates and never executes those cells",
             "algorithmic": {"cells_per_step": st1["algorithmic_cells"], "Tcell_per_s": alg_cells_per_s / 1e12,
                             "over_executed": st1["algorithmic_cells"] / max(st1["executed_cells"], 1)},
             "hbm": {"algorithmic_bytes_per_step": st1["algorithmic_bytes"], "achieved_GBps": hbm_gbps,
@@ -199,10 +257,11 @@ def init_dist(args):
     # the one rank a one-GPU box allows; needs the launcher's MASTER_ADDR / MASTER_PORT / RANK / WORLD_SIZE
     if world > 1 or os.environ.get("NRA_BENCH_FORCE_DIST"):
         import torch.distributed as dist
-        if args.backend == "nccl":
-            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
-        else:
-            dist.init_process_group(backend=args.backend)
+        if not dist.is_initialized():
+            if args.backend == "nccl":
+                dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+            else:
+                dist.init_process_group(backend=args.backend)
     return rank, local_rank, world, dist
 
 
@@ -235,7 +294,13 @@ def timed_steps(args, dist, step, on_warm=None, on_done=None):
     return dt
 
 
+VALUE_DEFINITION = ("value / ms_per_step: inputs resident in HBM when the clock starts (the benchmark contract's timed region). "
+                    "value_scorer_call / ms_per_scorer_call: SURVEY 8(d)'s metric, one scorer call from host buffers to host "
+                    "results (packing + H2D over PCIe + kernels + selection + D2H), median; the CPU ratio uses this one")
+
+
 def bench_1d(args):
+    """Configs 2, 4, 5.  Returns the record (rank 0) or None."""
     import numpy as np
     from nanorepeat_amd import _capi as A, dist as D, synth
     rank, local_rank, world, dist = init_dist(args)
@@ -295,16 +360,19 @@ def bench_1d(args):
         dist.all_reduce(t)
         n_align = int(t.item())
 
+    line = None
     if rank == 0:
         mine = out["status"][index] == 0
         est = out["sum_k"][index][mine] / np.maximum(out["n_ties"][index][mine], 1)
         exact = float(np.mean(est == data["k_true"][mine])) if mine.any() else 0.0
-        kern = "k_score_pk16<R>" if args.brute else "k_sweep_ring<R,dir> (reverse + forward sweeps of all read-length buckets)"
+        kern = ("k_score_pk16<R>" if args.brute else
+                "k_sweep_ring<R,dir> / k_sweep_ring32<R,dir> (reverse + forward sweeps of all read-length buckets)")
         line = {
             "metric": "read-alignments/sec (reads x candidate-k)",
             "value": n_align * args.steps / dt, "unit": "read-alignments/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": dt / args.steps * 1e3,
+            "value_scorer_call": None, "ms_per_scorer_call": None, "value_definition": VALUE_DEFINITION,
             "higher_is_better": True, "scaling": scaling, "vs_baseline": None,
             "dtype": "int16", "data": "synthetic",
             "config": {"workload": workload, "reads": n_total, "alignments": n_align,
@@ -314,45 +382,50 @@ def bench_1d(args):
                                        "results" + (" + all_gather (pass i's exchange overlaps pass i+1's kernels; the last "
                                                     "one is exposed)" if world > 1 else ""),
                        "parallelism": f"region blocks sharded over {world} GPU(s), no data-path collective, one all_gather of 32 B/read"},
-            "roofline": roofline(warm, st, args.steps, args.brute, kern),
+            "roofline": roofline(args.config, warm, st, args.brute, kern),
             "extent_tasks_per_step": st["n_extent_tasks"],
             "exact_k_fraction": exact,
         }
-        if world == 1 and args.config == 2 and args.one_shot_calls > 0 and not args.brute:
-            call, res = A.prepared_round3_1d(data["regions"], data["reads"], data["kmin"], data["kmax"], device=local_rank)
-            call()
-            ts = []
-            for _ in range(args.one_shot_calls):
-                t0 = time.perf_counter(); call(); ts.append(time.perf_counter() - t0)
-            med = float(np.median(ts))
-            same = all(np.array_equal(res[k], out[k]) for k in ("best_score", "sum_k", "n_ties", "status"))
-            line["one_shot"] = {"value": n_align / med, "unit": "read-alignments/s", "ms_per_call": med * 1e3,
-                                "calls": args.one_shot_calls, "ms_all": [t * 1e3 for t in ts],
-                                "equals_resident_results": bool(same),
-                                "what": "SURVEY 8(d) wall time of the scorer call: one nra_round3_1d from host buffers "
-                                        "(ASCII reads) to host results = 2-bit packing + device arena + H2D + kernels + "
-                                        "selection + D2H; median"}
-        if world == 1 and args.cpu_sample != 0:
-            cb = cpu_baseline_1d(data, args.cpu_sample)
-            if cb is not None:
-                base, ref = cb
-                n = len(ref["sum_k"])
-                same = all(np.array_equal(out[k][index][:n], ref[k]) for k in ("sum_k", "n_ties", "status", "best_score"))
-                base["gpu_matches_sample"] = bool(same)
-                line["cpu_baseline"] = base
-        print(json.dumps(line), flush=True)
     sb.close()
+    if rank == 0 and world == 1 and args.one_shot_calls > 0 and not args.brute:
+        # ONE nra_round3_1d call, host buffers (ASCII reads) in, host results out
+        call, res = A.prepared_round3_1d(data["regions"], data["reads"], data["kmin"], data["kmax"],
+                                         read_region=data.get("read_region"), device=local_rank)
+        call()
+        ts = []
+        for _ in range(args.one_shot_calls):
+            t0 = time.perf_counter(); call(); ts.append(time.perf_counter() - t0)
+        med = float(np.median(ts))
+        same = all(np.array_equal(res[k], out[k][index]) for k in ("best_score", "sum_k", "n_ties", "status"))
+        line["value_scorer_call"] = n_align / med
+        line["ms_per_scorer_call"] = med * 1e3
+        line["scorer_call"] = {"value": n_align / med, "unit": "read-alignments/s", "ms_per_call": med * 1e3,
+                               "calls": args.one_shot_calls, "ms_all": [t * 1e3 for t in ts],
+                               "equals_resident_results": bool(same),
+                               "what": "SURVEY 8(d) wall time of the scorer call: one nra_round3_1d from host buffers "
+                                       "(ASCII reads) to host results = 2-bit packing + device arena + H2D + kernels + "
+                                       "selection + D2H; median"}
+    if rank == 0 and world == 1 and args.cpu_sample != 0:
+        cb = cpu_baseline_1d(data, args.cpu_sample, getattr(args, "cpu_seconds", 15.0))
+        if cb is not None:
+            base, ref = cb
+            n = len(ref["sum_k"])
+            same = all(np.array_equal(out[k][index][:n], ref[k]) for k in ("sum_k", "n_ties", "status", "best_score"))
+            base["gpu_matches_sample"] = bool(same)
+            if line["value_scorer_call"]:
+                base["gpu_over_cpu"] = line["value_scorer_call"] / base["value"]
+            line["cpu_baseline"] = base
     if dist is not None:
         dist.barrier()
-        dist.destroy_process_group()
+    return line
 
 
 def bench_joint(args):
     """BASELINE config 3: the two grid rounds of the joint mode (nanoRepeat_joint.py:266-269) on 5000
     HTT-like amplicon reads, through the product host path (joint.fine_tune_read_count) on a resident
-    GridSession.  One step = round 2 + round 3: per round the host builds the cell list from the previous
-    round's estimates, sets it on the resident reads, runs the kernels and fetches the per-read results."""
-    import copy
+    GridSession.  One step = round 2 + round 3: per round the grid routing of the reference, the kernels and the
+    fetch of the per-read results.  The scorer call of SURVEY 8(d) = the same from the reads as host strings
+    (packing + H2D of the reads + both rounds)."""
     import numpy as np
     from nanorepeat_amd import joint as J, synth
     rank, local_rank, world, dist = init_dist(args)
@@ -372,8 +445,6 @@ def bench_joint(args):
     a = J.Repeat.parse(f"chr4:{len(left)}:{len(left) + 57}:{u1}:200")
     b = J.Repeat.parse(f"chr4:{len(left) + 57 + len(mid)}:{len(left) + 57 + len(mid) + 21}:{u2}:20")
     a.max_size += 10; b.max_size += 10                               # nanoRepeat_joint.py:202-203
-    # the product's session: from 2000 reads on two groups of reads in parallel host threads, so that one group's
-    # host work overlaps the other's kernels (joint.GridSession)
     session = J.GridSession(J._joint_region(chrom, a, b), fq, device=local_rank)
     last = {}
 
@@ -381,67 +452,87 @@ def bench_joint(args):
         sess.new_run()          # every step is a whole run: round 2 makes the reverse sweeps, round 3 reuses them
         last["est"] = J.fine_tune_read_count(init, fq, chrom, copy.copy(a), copy.copy(b), device=local_rank, session=sess)
 
-    dt = timed_steps(args, dist, step)
-    est_split = last["est"]
-    # kernel statistics from an un-split session of the same reads, where the batch's HIP-event times are those of
-    # one stream (in the timed steps the two groups' kernels overlap)
-    serial = J.GridSession(J._joint_region(chrom, a, b), fq, device=local_rank, parts=1)
-    for _ in range(2):
-        step(serial)
-    serial.rounds = []
-    n_serial = 4
-    t_serial = time.perf_counter()
-    for _ in range(n_serial):
-        step(serial)
-    t_serial = (time.perf_counter() - t_serial) / n_serial * 1e3
-    rounds = serial.rounds
-    per_step = len(rounds) // n_serial
-    n_cells = sum(c for c, _ in rounds[:per_step])
-    # statistics: the batch accumulates event times over its runs; cells are per round
-    first, final = rounds[0][1], rounds[-1][1]
-    runs = final["n_runs"] - first["n_runs"] + 1
-    phase_ms = (final["sum_score_phase_ms"] - first["sum_score_phase_ms"] + first["score_phase_ms"]) / runs * per_step
-    total_ms = (final["sum_total_ms"] - first["sum_total_ms"] + first["total_ms"]) / runs * per_step
-    exe = sum(st["executed_cells"] for _, st in rounds[:per_step])
-    alg = sum(st["algorithmic_cells"] for _, st in rounds[:per_step])
+    for _ in range(args.warmup):
+        step()
+    session.rounds = []
+    dt = timed_steps(argparse.Namespace(**dict(vars(args), warmup=0)), dist, step)
+    rounds = session.rounds
+    session.rounds = None
+    # statistics: every resident batch (one per read group) accumulates its HIP-event times over its runs
+    n_cells = sum(c for c, _, _ in rounds) // args.steps
+    exe = sum(st["executed_cells"] for _, st, _ in rounds) // args.steps
+    alg = sum(st["algorithmic_cells"] for _, st, _ in rounds) // args.steps
+    cells_per_round = {}
+    phase_ms = total_ms = 0.0
+    for key in sorted({k for _, _, k in rounds}):
+        mine = [(c, st) for c, st, k in rounds if k == key]
+        first, final = mine[0][1], mine[-1][1]
+        phase_ms += (final["sum_score_phase_ms"] - first["sum_score_phase_ms"] + first["score_phase_ms"]) / args.steps
+        total_ms += (final["sum_total_ms"] - first["sum_total_ms"] + first["total_ms"]) / args.steps
+        per_step = len(mine) // args.steps
+        for i, (c, _) in enumerate(mine[:per_step]):
+            cells_per_round[i] = cells_per_round.get(i, 0) + c
+    n_groups = len({k for _, _, k in rounds})
     est = last["est"]
     k1 = np.array([est.repeat1_count_dict.get(f"r{i}", -1) for i in range(n)])
     k2 = np.array([est.repeat2_count_dict.get(f"r{i}", -1) for i in range(n)])
     achieved = exe * LANEOPS_PER_CELL / (phase_ms / 1e3) / 1e12
+    pmc = pmc_counters(3, phase_ms / 1e3, False)
+    ms_step = dt / args.steps * 1e3
     line = {
         "metric": "read-alignments/sec (reads x candidate cells)",
         "value": n_cells * args.steps / dt, "unit": "read-alignments/s",
-        "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
+        "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_step,
+        "value_scorer_call": None, "ms_per_scorer_call": None, "value_definition": VALUE_DEFINITION,
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "int32", "data": "synthetic",
         "config": {"workload": f"config3: HTT-like joint CAG+CCG grid rounds 2+3, {n} amplicon reads (1.2 kb, either strand), "
                                "round-1 ranges [k-20, k+5)", "reads": n, "alignments": n_cells,
-                   "cells_per_round": [c for c, _ in rounds[:per_step]],
-                   "timed_region": "reads resident in HBM; per round: host cell list -> nra_batch2d_set_cells -> kernels -> "
-                                   "on-device selection -> D2H of per-read results"},
+                   "cells_per_round": [cells_per_round[i] for i in sorted(cells_per_round)], "read_groups": n_groups,
+                   "timed_region": "reads resident in HBM; per round: grid routing -> kernels -> on-device selection -> "
+                                   "D2H of per-read results -> the reference's result dicts"},
         "roofline": {"bound": "valu", "achieved": achieved, "peak": VALU_PEAK_TLANEOPS, "unit": "Tlane-op/s",
-                     "frac": achieved / VALU_PEAK_TLANEOPS, "traffic": None,
-                     "kernel": "k_joint_sweep<R,dir> (reverse, prefix and tail sweeps)",
+                     "frac": achieved / VALU_PEAK_TLANEOPS, "frac_issued": pmc["frac_issued"],
+                     "issue_ceiling": pmc["issue_ceiling"], "traffic": pmc["traffic"], "counters": pmc["counters"],
+                     "kernel": "k_joint_pk16<R> + k_joint_sweep<R,dir> (packed flank sweeps; reverse, prefix and tail sweeps)",
                      "kernel_ms_per_step": phase_ms, "device_ms_per_step": total_ms,
-                     "host_ms_per_step": t_serial - total_ms, "unsplit_ms_per_step": t_serial,
-                     "read_groups": max(1, len(session.subs)),
+                     "host_ms_per_step": ms_step - total_ms,
                      "executed_cells_per_step": exe, "executed_Tcell_per_s": exe / (phase_ms / 1e3) / 1e12,
                      "laneops_per_cell": LANEOPS_PER_CELL,
                      "note": "int32 cells = (score << 16 | window score): one cell per lane-op slot, priced like the 1D "
                              "cell (10 lane-ops) against the same 78.6 T lane-op/s; the columns outside the scoring window "
-                             "run in packed int16 cells (k_joint_pk16).  kernel / device / host times are those of an "
-                             "un-split session (unsplit_ms_per_step); ms_per_step is the product path, two read groups "
-                             "in parallel host threads",
+                             "run in packed int16 cells (k_joint_pk16).  kernel / device times are HIP-event times summed "
+                             "over the read groups' batches (their kernels overlap when there are two groups); "
+                             "host_ms_per_step = wall time of a step minus device_ms_per_step",
                      "algorithmic": {"cells_per_step": alg, "over_executed": alg / max(exe, 1)}},
-        "read_groups_equal_unsplit": bool(est_split.repeat1_count_dict == est.repeat1_count_dict and
-                                          est_split.repeat2_count_dict == est.repeat2_count_dict and
-                                          list(est_split.repeat1_count_dict) == list(est.repeat1_count_dict)),
         "k1_within1": float(np.mean(np.abs(k1 - j["truth"][:, 0]) <= 1)),
         "k2_within1": float(np.mean(np.abs(k2 - j["truth"][:, 1]) <= 1)),
     }
+    session.close()
+    if args.one_shot_calls > 0:
+        # the whole scorer call from the reads as host strings: packing + H2D + both grid rounds
+        def call():
+            t0 = time.perf_counter()
+            got = J.fine_tune_read_count(init, fq, chrom, copy.copy(a), copy.copy(b), device=local_rank)
+            return time.perf_counter() - t0, got
+        call()
+        ts, got = [], None
+        for _ in range(args.one_shot_calls):
+            t, got = call()
+            ts.append(t)
+        med = float(np.median(ts))
+        line["value_scorer_call"] = n_cells / med
+        line["ms_per_scorer_call"] = med * 1e3
+        line["scorer_call"] = {"value": n_cells / med, "unit": "read-alignments/s", "ms_per_call": med * 1e3,
+                               "calls": args.one_shot_calls, "ms_all": [t * 1e3 for t in ts],
+                               "equals_resident_results": bool(got.repeat1_count_dict == est.repeat1_count_dict and
+                                                               got.repeat2_count_dict == est.repeat2_count_dict),
+                               "what": "joint.fine_tune_read_count from the FASTQ dict: nra_batch2d_create_reads (packing + "
+                                       "H2D) + rounds 2 and 3 + result dicts; median"}
     if args.cpu_sample != 0:
         from oracle import oracle as O
         cores = host_cores()
-        m = min(n, 64 * cores) if args.cpu_sample < 0 else min(args.cpu_sample, n)      # ~10 s of CPU work
+        secs = getattr(args, "cpu_seconds", 10.0)
+        m = min(n, int(6.4 * secs * cores)) if args.cpu_sample < 0 else min(args.cpu_sample, n)
         cr, c1, c2 = [], [], []
         for r in range(m):
             for x in range(int(j["range1"][r][0]), int(j["range1"][r][1]), 7):
@@ -453,17 +544,44 @@ def bench_joint(args):
         line["cpu_baseline"] = {"value": len(cr) / dtc, "unit": "read-alignments/s", "cores": cores, "kind": "port",
                                 "sample": f"first {m} reads x their step-7 grid = {len(cr)} cells in {dtc:.1f} s; CPU "
                                           "restatement (one optimal DP with window payload per cell), not minimap2"}
-    print(json.dumps(line), flush=True)
-    session.close()
-    serial.close()
+        if line["value_scorer_call"]:
+            line["cpu_baseline"]["gpu_over_cpu"] = line["value_scorer_call"] / line["cpu_baseline"]["value"]
+    return line
+
+
+def sub_record(args, config):
+    """One of the other BASELINE workloads at N = 1 for the default run's `configs`: a few steps, a shorter CPU sample."""
+    sub = argparse.Namespace(**vars(args))
+    sub.config = config
+    sub.steps, sub.warmup = (2, 1) if config == 4 else (3, 1)
+    sub.reads = 10000
+    sub.one_shot_calls = min(args.one_shot_calls, 2 if config == 4 else 3)
+    sub.cpu_seconds = 6.0
+    t0 = time.perf_counter()
+    try:
+        rec = bench_joint(sub) if config == 3 else bench_1d(sub)
+    except Exception as e:          # a sub-record must not take the headline down with it
+        return {"error": f"{type(e).__name__}: {e}"}
+    rec["wall_s_of_this_record"] = time.perf_counter() - t0
+    return rec
 
 
 def main():
     args = parse()
     spawn_ranks_if_needed(args)
-    if args.config == 3:
-        return bench_joint(args)
-    bench_1d(args)
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    line = bench_joint(args) if args.config == 3 else bench_1d(args)
+    if line is not None and world == 1 and args.config == 2 and not args.brute and args.sub_configs not in ("none", ""):
+        line["configs"] = {}
+        for c in (int(x) for x in args.sub_configs.split(",")):
+            if c in (3, 4, 5):
+                line["configs"][f"config{c}"] = sub_record(args, c)
+    if line is not None:
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        import torch.distributed as dist
+        if dist.is_initialized():
+            dist.destroy_process_group()
 
 
 if __name__ == "__main__":

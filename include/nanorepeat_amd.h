@@ -259,6 +259,25 @@ int  nra_batch2d_create_reads(int device,
 int  nra_batch2d_set_cells(nra_batch_t* b, const int8_t* read_strand,
                            int64_t n_cells, const int32_t* cell_read,
                            const int32_t* cell_k1, const int32_t* cell_k2);
+/* A whole grid round in one call -- the reference's routing of reads to grid cells, done by the library
+ * (round 2: nanoRepeat_joint.py:397-409, round 3: :315-330).  Axis a (1, 2) has the grid values
+ * g = start_a + i * step_a, i in [0, count_a) (round 2: range(round1_min, round1_max + 1, step), :397-398;
+ * round 3: range(max(0, int(min size - s)), int(max size + s + 2)), :298-303); read r takes the values with
+ * lo_a[r] <= g < hi_a[r] (round 2: its round-1 range [min, max), :407; round 3: [max(size - s, range min),
+ * min(size + s, range max)), :325-330 -- doubles, because the round-2 sizes are means), and no cells when either
+ * axis gives it none.  A read's cells are listed k1-major, k2 ascending, reads in input order: the order
+ * nra_batch2d_set_cells wants and the per-cell arrays of nra_batch2d_fetch follow.
+ * nra_joint_grid_cells is the routing alone, on the host (no device needed): returns the number of cells and, when
+ * the three arrays are given (cap entries each), the list itself.  nra_batch2d_set_grid = the routing + set_cells,
+ * without per-cell arrays crossing the boundary; *n_cells (optional) receives the number of cells. */
+int64_t nra_joint_grid_cells(int32_t n_reads,
+                             int32_t start1, int32_t step1, int32_t count1, const double* lo1, const double* hi1,
+                             int32_t start2, int32_t step2, int32_t count2, const double* lo2, const double* hi2,
+                             int64_t cap, int32_t* cell_read, int32_t* cell_k1, int32_t* cell_k2);
+int  nra_batch2d_set_grid(nra_batch_t* b, const int8_t* read_strand,
+                          int32_t start1, int32_t step1, int32_t count1, const double* lo1, const double* hi1,
+                          int32_t start2, int32_t step2, int32_t count2, const double* lo2, const double* hi2,
+                          int64_t* n_cells);
 /* A later cell list reuses what an earlier one left on the device for the same read and strand (the reverse
  * sweep over the right flank, the state of the forward sweep at the end of the left flank).  nra_batch2d_invalidate
  * drops that: the next list starts like the first (a

@@ -24,7 +24,7 @@ F_NO_JOINT_PACK = 64  # testing / comparison, 2D: int32 payload cells also outsi
 # every symbol include/nanorepeat_amd.h declares
 EXPORTS = ("nra_abi_version", "nra_version", "nra_last_error", "nra_device_count",
            "nra_default_scoring", "nra_release_cached_memory", "nra_round3_1d", "nra_joint_2d", "nra_align_pairs", "nra_align_pairs_cigar", "nra_batch1d_create",
-           "nra_batch2d_create", "nra_batch2d_create_reads", "nra_batch2d_set_cells", "nra_batch2d_invalidate", "nra_batch_run", "nra_batch_sync", "nra_batch_stats",
+           "nra_batch2d_create", "nra_batch2d_create_reads", "nra_batch2d_set_cells", "nra_joint_grid_cells", "nra_batch2d_set_grid", "nra_batch2d_invalidate", "nra_batch_run", "nra_batch_sync", "nra_batch_stats",
            "nra_batch1d_fetch", "nra_batch2d_fetch", "nra_batch_destroy")
 
 
@@ -117,6 +117,12 @@ def load():
                                              C.POINTER(Scoring), C.c_int32, C.POINTER(vp)]
     lib.nra_batch2d_set_cells.restype = C.c_int
     lib.nra_batch2d_set_cells.argtypes = [vp, pi8, C.c_int64, pi32, pi32, pi32]
+    pf64 = C.POINTER(C.c_double)
+    grid_args = [C.c_int32, C.c_int32, C.c_int32, pf64, pf64, C.c_int32, C.c_int32, C.c_int32, pf64, pf64]
+    lib.nra_joint_grid_cells.restype = C.c_int64
+    lib.nra_joint_grid_cells.argtypes = [C.c_int32] + grid_args + [C.c_int64, pi32, pi32, pi32]
+    lib.nra_batch2d_set_grid.restype = C.c_int
+    lib.nra_batch2d_set_grid.argtypes = [vp, pi8] + grid_args + [pi64]
     for f in (lib.nra_batch_run, lib.nra_batch_sync, lib.nra_batch2d_invalidate):
         f.restype = C.c_int
         f.argtypes = [vp]
@@ -271,6 +277,34 @@ def joint_2d(region, reads, cell_read, cell_k1, cell_k2, read_strand=None, sc=No
     return out
 
 
+class Grid:
+    """One routed grid round (nra_batch2d_set_grid): per axis the grid values start + i * step, i < count, and per
+    read the half-open bounds [lo, hi) (doubles) of the values it takes."""
+
+    def __init__(self, axis1, lo1, hi1, axis2, lo2, hi2):
+        self.axes = (tuple(int(x) for x in axis1), tuple(int(x) for x in axis2))      # (start, step, count)
+        self.bounds = [np.ascontiguousarray(a, np.float64) for a in (lo1, hi1, lo2, hi2)]
+        self.n_reads = len(self.bounds[0])
+        assert all(len(a) == self.n_reads for a in self.bounds)
+
+    def c_args(self):
+        lo1, hi1, lo2, hi2 = (_ptr(a, C.c_double) for a in self.bounds)
+        return (*self.axes[0], lo1, hi1, *self.axes[1], lo2, hi2)
+
+
+def joint_grid_cells(grid):
+    """nra_joint_grid_cells: the cells of a routed grid, (cell_read, k1, k2), on the host."""
+    lib = load()
+    n = lib.nra_joint_grid_cells(grid.n_reads, *grid.c_args(), 0, None, None, None)
+    if n < 0:
+        _check(int(n))
+    cr, k1, k2 = (np.zeros(n, np.int32) for _ in range(3))
+    got = lib.nra_joint_grid_cells(grid.n_reads, *grid.c_args(), n, _ptr(cr, C.c_int32), _ptr(k1, C.c_int32), _ptr(k2, C.c_int32))
+    if got < 0:
+        _check(int(got))
+    return cr, k1, k2
+
+
 def align_pairs(seqs, pair_query, pair_target, sc=None, flags=0, device=0):
     """nra_align_pairs: optimal local alignment of seqs[pair_query[i]] (query) against
     seqs[pair_target[i]] (target) -> dict(score, tstart, tend) in target coordinates."""
@@ -404,6 +438,16 @@ class Batch:
         _check(load().nra_batch2d_set_cells(self._h, _ptr(st, C.c_int8), len(cr), _ptr(cr, C.c_int32),
                                             _ptr(k1, C.c_int32), _ptr(k2, C.c_int32)))
         self.n_cand = len(cr)
+
+    def set_grid(self, grid, read_strand=None):
+        """A whole routed grid round (Grid): the library lists the cells itself.  Returns the number of cells."""
+        if grid.n_reads != self.n_reads:
+            raise ValueError("grid bounds must have one entry per read of the batch")
+        st = None if read_strand is None else np.ascontiguousarray(read_strand, np.int8)
+        n = C.c_int64(0)
+        _check(load().nra_batch2d_set_grid(self._h, _ptr(st, C.c_int8), *grid.c_args(), C.byref(n)))
+        self.n_cand = int(n.value)
+        return self.n_cand
 
     def invalidate(self):
         """Drop what earlier cell lists left for later ones (reverse sweeps): the next list starts like the first."""

@@ -62,6 +62,18 @@ def build_library(force=False, jobs=None, verbose=False):
     objs.append(o)
     cmds.append(common + ["-pthread", "-c", os.path.join(CSRC, "nra_host.cpp"), "-o", o])
 
+    # an object is rebuilt when its source, a header next to it or the public header is newer
+    headers = [os.path.join(CSRC, h) for h in SOURCES if h.endswith(".h")] + [os.path.join(INCLUDE, "nanorepeat_amd.h")]
+
+    def fresh(cmd):
+        obj, src = cmd[-1], cmd[-3]
+        if force or not os.path.exists(obj):
+            return False
+        t = os.path.getmtime(obj)
+        return all(os.path.getmtime(d) <= t for d in [src] + headers)
+
+    cmds = [c for c in cmds if not fresh(c)]
+
     def run(cmd):
         if verbose:
             print(" ".join(cmd), file=sys.stderr)
@@ -69,7 +81,7 @@ def build_library(force=False, jobs=None, verbose=False):
         if r.returncode != 0:
             raise RuntimeError("hipcc failed:\n" + " ".join(cmd) + "\n" + r.stdout + r.stderr)
 
-    jobs = jobs or min(len(cmds), max(1, (os.cpu_count() or 2) - 1))
+    jobs = jobs or max(1, min(len(cmds), max(1, (os.cpu_count() or 2) - 1)))
     with ThreadPoolExecutor(max_workers=jobs) as ex:
         list(ex.map(run, cmds))
     run([hipcc, f"--offload-arch={ARCH}", "-shared", "-fPIC", "-pthread", "-o", LIB] + objs)

@@ -10,6 +10,7 @@
 
 #include <algorithm>
 #include <chrono>
+#include <cmath>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -1402,6 +1403,79 @@ int nra_batch2d_create_reads(int device, const nra_joint_region_t* reg, int32_t 
     return NRA_OK;
 }
 
+}  // extern "C"
+
+namespace {
+
+// One read's share of a routed grid (nra_batch2d_set_grid): its cells are the product of n1 values of k1 from
+// k1lo in steps of the grid's step1 and n2 values of k2 from k2lo in steps of step2, k1-major.
+struct GridRow { int32_t k1lo, n1, k2lo, n2; };
+struct JointGrid { int32_t step1, step2; const GridRow* rows; };
+
+// first index i in [0, count] with start + i * step >= x  (numpy.searchsorted(grid, x, side="left") on the grid values)
+int32_t grid_lower_bound(int32_t start, int32_t step, int32_t count, double x)
+{
+    if (count <= 0) return 0;
+    double f = std::ceil((x - (double)start) / (double)step);
+    int64_t i = f < 0 ? 0 : (f > (double)count ? count : (int64_t)f);
+    while (i > 0 && (double)start + (double)(i - 1) * step >= x) --i;           // rounding of the quotient
+    while (i < count && (double)start + (double)i * step < x) ++i;
+    return (int32_t)i;
+}
+
+// The reference's routing of reads to the cells of one grid round (nanoRepeat_joint.py:397-409 round 2, :315-330
+// round 3): read r takes the grid values g of axis a with lo_a[r] <= g < hi_a[r]; none on one axis = no cells.
+int route_grid(int32_t n_reads, int32_t start1, int32_t step1, int32_t count1, const double* lo1, const double* hi1,
+               int32_t start2, int32_t step2, int32_t count2, const double* lo2, const double* hi2,
+               std::vector<GridRow>& rows, int64_t& n_cells)
+{
+    if (n_reads < 0 || step1 <= 0 || step2 <= 0 || count1 < 0 || count2 < 0 || start1 < 0 || start2 < 0)
+        return fail(NRA_E_ARG, "bad grid (steps > 0, starts and counts >= 0)");
+    if (n_reads > 0 && (!lo1 || !hi1 || !lo2 || !hi2)) return fail(NRA_E_ARG, "NULL grid bound array");
+    if ((int64_t)start1 + (int64_t)step1 * count1 > 0x3fffffff || (int64_t)start2 + (int64_t)step2 * count2 > 0x3fffffff)
+        return fail(NRA_E_RANGE, "grid values too large");
+    rows.assign((size_t)n_reads, GridRow{0, 0, 0, 0});
+    n_cells = 0;
+    for (int32_t r = 0; r < n_reads; ++r) {
+        if (!(lo1[r] < hi1[r]) || !(lo2[r] < hi2[r])) continue;         // (also drops NaN bounds)
+        const int32_t a1 = grid_lower_bound(start1, step1, count1, lo1[r]), b1 = grid_lower_bound(start1, step1, count1, hi1[r]);
+        const int32_t a2 = grid_lower_bound(start2, step2, count2, lo2[r]), b2 = grid_lower_bound(start2, step2, count2, hi2[r]);
+        if (b1 <= a1 || b2 <= a2) continue;
+        rows[(size_t)r] = GridRow{start1 + a1 * step1, b1 - a1, start2 + a2 * step2, b2 - a2};
+        n_cells += (int64_t)(b1 - a1) * (b2 - a2);
+    }
+    return NRA_OK;
+}
+
+int set_cells_common(nra_batch* b, const int8_t* read_strand, int64_t n_cells, const int32_t* cell_read,
+                     const int32_t* cell_k1, const int32_t* cell_k2, const JointGrid* grid);
+
+}  // namespace
+
+extern "C" {
+
+int64_t nra_joint_grid_cells(int32_t n_reads, int32_t start1, int32_t step1, int32_t count1, const double* lo1,
+                             const double* hi1, int32_t start2, int32_t step2, int32_t count2, const double* lo2,
+                             const double* hi2, int64_t cap, int32_t* cell_read, int32_t* cell_k1, int32_t* cell_k2)
+{
+    std::vector<GridRow> rows;
+    int64_t n = 0;
+    const int rc = route_grid(n_reads, start1, step1, count1, lo1, hi1, start2, step2, count2, lo2, hi2, rows, n);
+    if (rc) return rc;
+    if (!cell_read && !cell_k1 && !cell_k2) return n;
+    if (!cell_read || !cell_k1 || !cell_k2) return fail(NRA_E_ARG, "all three cell arrays or none");
+    if (cap < n) return fail(NRA_E_ARG, "cell arrays too small: " + std::to_string(n) + " cells");
+    int64_t c = 0;
+    for (int32_t r = 0; r < n_reads; ++r) {
+        const GridRow& g = rows[(size_t)r];
+        for (int32_t i = 0; i < g.n1; ++i)
+            for (int32_t j = 0; j < g.n2; ++j, ++c) {
+                cell_read[c] = r; cell_k1[c] = g.k1lo + i * step1; cell_k2[c] = g.k2lo + j * step2;
+            }
+    }
+    return n;
+}
+
 // The cell list of one grid round.  May be called again on the same batch (the reads stay packed on the
 // device; the buffers of the previous list are handed out again).
 int nra_batch2d_set_cells(nra_batch_t* b, const int8_t* read_strand, int64_t n_cells, const int32_t* cell_read,
@@ -1410,6 +1484,40 @@ int nra_batch2d_set_cells(nra_batch_t* b, const int8_t* read_strand, int64_t n_c
     if (!b || b->kind != 2) return fail(NRA_E_ARG, "not a 2D batch");
     if (n_cells < 0) return fail(NRA_E_ARG, "bad cell count");
     if (n_cells > 0 && (!cell_read || !cell_k1 || !cell_k2)) return fail(NRA_E_ARG, "NULL cell array");
+    return set_cells_common(b, read_strand, n_cells, cell_read, cell_k1, cell_k2, nullptr);
+}
+
+// The same for a whole routed grid: the library lists the cells itself (no per-cell arrays cross the boundary).
+int nra_batch2d_set_grid(nra_batch_t* b, const int8_t* read_strand,
+                         int32_t start1, int32_t step1, int32_t count1, const double* lo1, const double* hi1,
+                         int32_t start2, int32_t step2, int32_t count2, const double* lo2, const double* hi2,
+                         int64_t* n_cells_out)
+{
+    if (!b || b->kind != 2) return fail(NRA_E_ARG, "not a 2D batch");
+    std::vector<GridRow> rows;
+    int64_t n = 0;
+    int rc = route_grid(b->n_reads, start1, step1, count1, lo1, hi1, start2, step2, count2, lo2, hi2, rows, n);
+    if (rc) return rc;
+    if (n_cells_out) *n_cells_out = n;
+    // k1 / k2 of every cell, for the selector (and whoever fetches per-cell scores); the tasks come from the rows
+    std::vector<int32_t> k1((size_t)n), k2((size_t)n);
+    int64_t c = 0;
+    for (int32_t r = 0; r < b->n_reads; ++r) {
+        const GridRow& g = rows[(size_t)r];
+        for (int32_t i = 0; i < g.n1; ++i)
+            for (int32_t j = 0; j < g.n2; ++j, ++c) { k1[(size_t)c] = g.k1lo + i * step1; k2[(size_t)c] = g.k2lo + j * step2; }
+    }
+    const JointGrid grid{step1, step2, rows.data()};
+    return set_cells_common(b, read_strand, n, nullptr, k1.data(), k2.data(), &grid);
+}
+
+}  // extern "C"
+
+namespace {
+
+int set_cells_common(nra_batch* b, const int8_t* read_strand, int64_t n_cells, const int32_t* cell_read,
+                     const int32_t* cell_k1, const int32_t* cell_k2, const JointGrid* grid)
+{
     if (n_cells > 0x7ff00000ll) return fail(NRA_E_RANGE, "too many cells");
     HIP_TRY(hipSetDevice(b->device));
     if (b->ran) HIP_TRY(hipStreamSynchronize(b->stream));      // the previous list's kernels own the buffers
@@ -1433,6 +1541,18 @@ int nra_batch2d_set_cells(nra_batch_t* b, const int8_t* read_strand, int64_t n_c
 
     std::vector<uint32_t> first((size_t)n_reads, 0), cnt((size_t)n_reads, 0);
     int32_t k1max = 0, k2max = 0;
+    if (grid) {
+        uint32_t c = 0;
+        for (int32_t r = 0; r < n_reads; ++r) {
+            const GridRow& g = grid->rows[(size_t)r];
+            first[r] = c; cnt[r] = (uint32_t)g.n1 * (uint32_t)g.n2;
+            c += cnt[r];
+            if (cnt[r]) {
+                k1max = std::max(k1max, g.k1lo + (g.n1 - 1) * grid->step1);
+                k2max = std::max(k2max, g.k2lo + (g.n2 - 1) * grid->step2);
+            }
+        }
+    } else
     for (int64_t c = 0; c < n_cells; ++c) {
         const int32_t r = cell_read[c];
         if (r < 0 || r >= n_reads || (c > 0 && r < cell_read[c - 1]) || cell_k1[c] < 0 || cell_k2[c] < 0)
@@ -1494,6 +1614,7 @@ int nra_batch2d_set_cells(nra_batch_t* b, const int8_t* read_strand, int64_t n_c
     if (read_strand)
         for (int32_t r = 0; r < n_reads; ++r) if (cnt[r] > 0 && read_strand[r] == 0) b->all_strands_given = false;
     int64_t alg_cells = 0;
+    std::vector<int32_t> ks;
     for (int bi = kNumR; bi >= 0; --bi) {
         if (by_bucket[bi].empty()) continue;
         Bucket bk;
@@ -1528,9 +1649,15 @@ int nra_batch2d_set_cells(nra_batch_t* b, const int8_t* read_strand, int64_t n_c
                     b->rev_strand[r] = 0;
                     b->rev_pending.push_back({r, given});
                 }
-                std::vector<int32_t> ks(cell_k1 + first[r], cell_k1 + first[r] + cnt[r]);
-                std::sort(ks.begin(), ks.end());
-                ks.erase(std::unique(ks.begin(), ks.end()), ks.end());
+                ks.clear();                                      // the read's distinct k1 values, ascending
+                if (grid) {
+                    const GridRow& g = grid->rows[(size_t)r];
+                    for (int32_t i = 0; i < g.n1; ++i) ks.push_back(g.k1lo + i * grid->step1);
+                } else {
+                    ks.assign(cell_k1 + first[r], cell_k1 + first[r] + cnt[r]);
+                    if (!std::is_sorted(ks.begin(), ks.end())) std::sort(ks.begin(), ks.end());
+                    ks.erase(std::unique(ks.begin(), ks.end()), ks.end());
+                }
                 if (used > 0 && used + slot * ks.size() > state_cap) {      // close the group
                     g.n_pre = (int)(jpre.size() - g.pre_off); g.n_tail = (int)(jtail.size() - g.tail_off);
                     b->jgroups.push_back(g);
@@ -1553,6 +1680,17 @@ int nra_batch2d_set_cells(nra_batch_t* b, const int8_t* read_strand, int64_t n_c
                 }
                 jpre.push_back(tp);
                 bk.cells_sweep += (int64_t)64 * bk.R * (d.l1 + d.m1 * ks.back() - 1 - (b->jpack_l ? colsL : 0));
+                if (grid) {
+                    // one tail sweep per k1: the read's k2 values are one arithmetic progression
+                    const GridRow& g = grid->rows[(size_t)r];
+                    for (int32_t i = 0; i < g.n1; ++i) {
+                        NraJointTask t{}; t.read = r; t.k1 = ks[(size_t)i]; t.k2lo = g.k2lo; t.k2step = grid->step2; t.n2 = g.n2;
+                        t.out = (int32_t)(first[r] + (uint32_t)i * (uint32_t)g.n2);
+                        t.state = used + slot * (uint64_t)i;
+                        jtail.push_back(t);
+                        bk.cells_sweep += joint_cells(bk.R, 1 + d.l2 + d.m2 * (t.k2lo + t.k2step * (t.n2 - 1)), reads[r].qlen);
+                    }
+                } else
                 for (uint32_t c = first[r]; c < first[r] + cnt[r];) {
                     NraJointTask t{}; t.read = r; t.k1 = cell_k1[c]; t.k2lo = cell_k2[c]; t.k2step = 1; t.n2 = 1;
                     t.out = (int32_t)c;
@@ -1686,6 +1824,9 @@ int nra_batch2d_set_cells(nra_batch_t* b, const int8_t* read_strand, int64_t n_c
     return NRA_OK;
 }
 
+}  // namespace
+
+extern "C" {
 
 // Forget what earlier cell lists left for later ones (the reverse sweeps): the next list starts like the first.
 int nra_batch2d_invalidate(nra_batch_t* b)

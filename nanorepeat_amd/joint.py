@@ -9,6 +9,7 @@ CIGAR walk of `estimate_two_repeats_from_paf` are replaced by ONE call through t
 from dataclasses import dataclass, field
 
 import numpy as np
+from itertools import chain
 from operator import itemgetter
 
 from . import _capi
@@ -267,56 +268,65 @@ MAX_READ_2D = 3072          # rows one wave holds (NRA_MAX_QLEN_1BLOCK): the lim
                             # cell in chained row blocks, the full read like the reference (nanoRepeat_joint.py:332,408)
 
 
-def _cells_of_ranges(grid1, lo1, hi1, grid2, lo2, hi2):
-    """Per read r the cells grid1[lo1[r]:hi1[r]] x grid2[lo2[r]:hi2[r]], k1-major -- the order the
-    reference's nested loops list a read's cells in -- for all reads at once: (cell_read, k1, k2).
-    Built row by row ((read, k1) pairs first, then each row's k2 run): no per-cell division."""
-    n1 = np.maximum(hi1 - lo1, 0).astype(np.int64)
-    n2 = np.maximum(hi2 - lo2, 0).astype(np.int64)
-    n1 = np.where(n2 > 0, n1, 0)
-    n_rows = int(n1.sum())
-    if n_rows == 0:
-        z = np.zeros(0, np.int32)
-        return z, z, z
-    row_read = np.repeat(np.arange(len(n1), dtype=np.int32), n1)
-    i1 = np.arange(n_rows, dtype=np.int64) - np.repeat(np.cumsum(n1) - n1, n1)
-    row_k1 = grid1[lo1[row_read] + i1].astype(np.int32)
-    row_n2 = n2[row_read]
-    total = int(row_n2.sum())
-    cell_read = np.repeat(row_read, row_n2)
-    k1 = np.repeat(row_k1, row_n2)
-    i2 = np.arange(total, dtype=np.int64) - np.repeat(np.cumsum(row_n2) - row_n2, row_n2)
-    k2 = grid2[np.repeat(lo2[row_read], row_n2) + i2].astype(np.int32)
-    return cell_read, k1, k2
+PIPELINE_MIN_READS = 2000     # (round 2 of the build ran the reads as two groups from here on; see GridSession.parts)
 
 
-PIPELINE_MIN_READS = 2000     # from here on the reads of a joint run are scored as two independent halves
+class LazyRepeatSize(RepeatSize):
+    """A RepeatSize whose two dicts are built from the per-read arrays of a grid round the first time someone
+    looks at them.  Round 3 takes round 2's sizes as arrays (`sizes_for`), so when round 3 follows, round 2's
+    10 000 dict entries are never made."""
+
+    def __init__(self, names=None, size1=None, size2=None, step_size1=1, step_size2=1):
+        object.__setattr__(self, "_names", names if names is not None else [])
+        object.__setattr__(self, "_size1", size1)
+        object.__setattr__(self, "_size2", size2)
+        object.__setattr__(self, "_dicts", None)
+        self.step_size1, self.step_size2 = step_size1, step_size2
+
+    def _build(self):
+        if self._dicts is None:
+            if self._size1 is None:
+                object.__setattr__(self, "_dicts", ({}, {}))
+            else:       # np.float64 values, like np.mean's (nanoRepeat_joint.py:475-476)
+                object.__setattr__(self, "_dicts", (dict(zip(self._names, self._size1)), dict(zip(self._names, self._size2))))
+        return self._dicts
+
+    repeat1_count_dict = property(lambda self: self._build()[0],
+                                  lambda self, v: object.__setattr__(self, "_dicts", (v, self._build()[1])))
+    repeat2_count_dict = property(lambda self: self._build()[1],
+                                  lambda self, v: object.__setattr__(self, "_dicts", (self._build()[0], v)))
+
+    def __len__(self):
+        return len(self._names) if self._dicts is None else len(self._dicts[0])
+
+    def sizes_for(self, names):
+        """(rows, size1, size2): numbers (into `names`) of the reads with an estimate, and their sizes."""
+        if self._dicts is None and self._size1 is not None and getattr(self, "_rows_of", None) is not None and \
+                self._rows_of[0] is names:
+            return self._rows_of[1], self._size1, self._size2
+        return None
 
 
 class GridSession:
     """The reads of a joint run for the grid rounds: packed and uploaded once (`nra_batch2d_create_reads`),
-    scored against one cell list per round (`nra_batch2d_set_cells` + run).  With an injected `scorer`
-    (the tests' oracle twin of `_capi.joint_2d`) every round is a one-shot call instead.
+    scored against one routed grid per round (`nra_batch2d_set_grid` + run).  With an injected `scorer`
+    (the tests' oracle twin of `_capi.joint_2d`) every round is a one-shot call on the grid's cell list instead.
 
-    `parts` > 1 (default: 2 from PIPELINE_MIN_READS reads on): the reads are cut into that many contiguous
-    groups, each a session of its own (`subs`) with its own resident batch and stream.  A read's grid rounds
-    depend on that read alone, so `fine_tune_read_count` runs the groups in host threads that take turns: a
-    thread holds `host_lock` while it works on the host and lets go of it while it waits for the device, so
-    one group's cell list is built and its results are read while the other group's kernels run -- host and
-    device time overlap instead of adding up.  (Without the lock both threads would share the interpreter
-    evenly, reach the device together and wait together.)"""
+    `parts` > 1 (optional; default 1): the reads are cut into that many contiguous groups, each a session of its
+    own (`subs`) with its own resident batch and stream, and `fine_tune_read_count` runs the groups in host
+    threads that take turns: a thread holds `host_lock` while it works on the host and lets go of it while it
+    waits for the device.  That hid the host's share of a round when the cell lists were built in numpy (round 2
+    of the build: 12 of 22 ms); with the routing in the library (`nra_batch2d_set_grid`) one group is faster."""
 
     def __init__(self, region, fastq_dict, device=0, scoring=None, scorer=None, parts=None):
         self.region = region
         self.names = list(fastq_dict)
         self.device, self.scoring, self.scorer = device, scoring, scorer
         self.batch = None
-        self.rounds = None          # set to a list to collect (n_cells, batch statistics) of every round
+        self._rounds = None         # `rounds`: set to a list to collect (n_cells, batch statistics, group) of every round
         self.subs, self.pool, self.host_lock = [], None, None
         self.in_turn = False        # this group's thread holds host_lock (fine_tune_read_count)
-        if parts is None:
-            parts = 2 if scorer is None and len(self.names) >= PIPELINE_MIN_READS else 1
-        parts = max(1, min(int(parts), max(1, len(self.names))))
+        parts = max(1, min(int(parts or 1), max(1, len(self.names))))
         if parts > 1:
             from concurrent.futures import ThreadPoolExecutor
             cuts = [len(self.names) * p // parts for p in range(parts + 1)]
@@ -333,11 +343,27 @@ class GridSession:
         if scorer is None:
             self.batch = _capi.Batch.create_2d_reads(region, self.reads, sc=scoring, device=device)
 
-    def score(self, cell_read, k1, k2, read_strand):
+    @property
+    def rounds(self):
+        return self._rounds
+
+    @rounds.setter
+    def rounds(self, value):        # the read groups append to the same list
+        self._rounds = value
+        for sub in self.subs:
+            sub.rounds = value
+
+    def score_grid(self, grid, read_strand):
+        """One grid round for this session's reads -> per-read tie sums (dict of arrays) and the number of cells."""
         if self.scorer is not None:
+            cell_read, k1, k2 = _capi.joint_grid_cells(grid)
+            if len(cell_read) == 0:
+                return None, 0
             return self.scorer(self.region, self.reads, cell_read, k1, k2, read_strand=read_strand, sc=self.scoring,
-                               device=self.device)
-        self.batch.set_cells(cell_read, k1, k2, read_strand)
+                               device=self.device), len(cell_read)
+        n_cells = self.batch.set_grid(grid, read_strand)
+        if n_cells == 0:
+            return None, 0
         self.batch.run()
         if self.in_turn:
             self.host_lock.release()               # another group's thread works on the host meanwhile
@@ -348,8 +374,8 @@ class GridSession:
         else:
             self.batch.sync()
         if self.rounds is not None:
-            self.rounds.append((len(cell_read), self.batch.stats()))
-        return self.batch.fetch(per_candidate=False)
+            self.rounds.append((n_cells, self.batch.stats(), id(self)))
+        return self.batch.fetch(per_candidate=False), n_cells
 
     def new_run(self):
         """The grid rounds are about to start over on these reads: nothing of an earlier run is reused."""
@@ -382,44 +408,63 @@ def _rows_with(names, *dicts):
     return np.array([i for i, name in enumerate(names) if all(name in d for d in dicts)], np.int64)
 
 
-def _values_of(d, names, rows, dtype):
-    """d[names[i]] for i in rows as an array (itemgetter: one C-level pass)."""
+def _values_of(d, names, rows, dtype, width=1):
+    """d[names[i]] for i in rows as an array of `width` columns.  When the dict lists exactly these names in this
+    order (the usual case: both come from the same FASTQ) its values are read in one flat pass."""
     if len(rows) == 0:
-        return np.zeros(0, dtype)
-    keys = names if len(rows) == len(names) else [names[i] for i in rows]
-    got = itemgetter(*keys)(d)
-    return np.array(got if len(keys) > 1 else [got], dtype)
+        return np.zeros((0, width) if width > 1 else 0, dtype)
+    if len(rows) == len(names) == len(d) and list(d) == names:
+        flat = chain.from_iterable(d.values()) if width > 1 else d.values()
+        out = np.fromiter(flat, dtype, len(names) * width)
+    else:
+        keys = names if len(rows) == len(names) else [names[i] for i in rows]
+        got = itemgetter(*keys)(d)
+        out = np.array(got if len(keys) > 1 else [got], dtype)
+    return out.reshape(-1, width) if width > 1 else out
 
 
-def _score_round(session, rows, grid1, lo1, hi1, grid2, lo2, hi2, strands):
-    """One grid round: `rows` = session read numbers with a cell range each.  Returns a RepeatSize."""
-    est = RepeatSize()
+class _Round1Arrays:
+    """The round-1 knowledge of a session's reads as arrays, made once per fine_tune_read_count call: `rows` = the
+    session read numbers with a range on both axes, their [min, max) ranges, every read's strand (0 = unknown)."""
+
+    def __init__(self, session, initial_estimation, strands):
+        names = session.names
+        r1, r2 = initial_estimation.repeat1_count_range_dict, initial_estimation.repeat2_count_range_dict
+        self.source = initial_estimation
+        self.rows = _rows_with(names, r1, r2)
+        self.range1 = _values_of(r1, names, self.rows, np.int64, 2)
+        self.range2 = _values_of(r2, names, self.rows, np.int64, 2)
+        self.strand = None
+        if strands is not None:
+            if len(strands) == len(names) and list(strands) == names:
+                self.strand = np.fromiter(strands.values(), np.int8, len(names))
+            else:
+                self.strand = np.fromiter((strands.get(name, 0) for name in names), np.int8, len(names))
+
+
+def _score_round(session, ctx, rows, axis1, lo1, hi1, axis2, lo2, hi2, strands, steps):
+    """One grid round: `rows` = session read numbers with bounds [lo, hi) on each axis.  Returns a RepeatSize."""
     if len(rows) == 0:
-        return est
+        return RepeatSize()
     n = len(session.names)
-    full = [np.zeros(n, np.int64) for _ in range(4)]                   # reads without cells: empty ranges
+    full = [np.zeros(n, np.float64) for _ in range(4)]                 # reads without bounds: empty [0, 0)
     for dst, src in zip(full, (lo1, hi1, lo2, hi2)):
         dst[rows] = src
-    cell_read, k1, k2 = _cells_of_ranges(grid1, full[0], full[1], grid2, full[2], full[3])
-    if len(cell_read) == 0:
-        return est
-    st_in = None
-    if strands is not None:
-        if len(strands) >= n and all(map(strands.__contains__, session.names)):
-            st_in = np.array(itemgetter(*session.names)(strands) if n > 1 else [strands[session.names[0]]], np.int8)
-        else:
-            st_in = np.fromiter((strands.get(name, 0) for name in session.names), np.int8, n)
-    out = session.score(cell_read, k1, k2, st_in)
-    has_cells = np.zeros(n, bool)
-    has_cells[cell_read] = True
-    ok = np.nonzero(has_cells & (np.asarray(out["status"]) == _capi.READ_OK))[0]     # nanoRepeat_joint.py:473-476
+    out, n_cells = session.score_grid(_capi.Grid(axis1, full[0], full[1], axis2, full[2], full[3]), ctx.strand)
+    if n_cells == 0:
+        return RepeatSize()
+    # a read with cells has status OK or NO_RECORD; the others are left at OK with no ties (nanoRepeat_joint.py:473-476)
+    ok = np.nonzero((np.asarray(out["status"]) == _capi.READ_OK) & (np.asarray(out["n_ties"]) > 0))[0]
     nt = np.asarray(out["n_ties"], np.float64)[ok]
-    names = [session.names[i] for i in ok]
-    est.repeat1_count_dict = dict(zip(names, np.asarray(out["sum_k1"], np.float64)[ok] / nt))   # np.float64 values,
-    est.repeat2_count_dict = dict(zip(names, np.asarray(out["sum_k2"], np.float64)[ok] / nt))   # like np.mean's
-    if strands is not None:
-        idx = np.nonzero(has_cells)[0]
-        strands.update(zip((session.names[i] for i in idx), np.asarray(out["read_strand"])[idx].tolist()))
+    names = session.names if len(ok) == n else [session.names[i] for i in ok]
+    est = LazyRepeatSize(names, np.asarray(out["sum_k1"], np.float64)[ok] / nt, np.asarray(out["sum_k2"], np.float64)[ok] / nt,
+                         *steps)
+    object.__setattr__(est, "_rows_of", (session.names, ok))
+    if strands is not None and (ctx.strand is None or (ctx.strand == 0).any()):
+        got = np.asarray(out["read_strand"])
+        idx = np.nonzero(got != 0)[0]
+        strands.update(zip((session.names[i] for i in idx), got[idx].tolist()))
+        ctx.strand = np.where(got != 0, got, ctx.strand if ctx.strand is not None else 0).astype(np.int8)
     return est
 
 
@@ -444,9 +489,20 @@ def _check_repeat_order(repeat1, repeat2):
         raise AssertionError("the two repeats must lie on one chromosome, repeat1 first")
 
 
+def _context(session, initial_estimation, strands, ctx):
+    if ctx is not None and ctx.source is initial_estimation:
+        return ctx
+    return _Round1Arrays(session, initial_estimation, strands)
+
+
+def _axis(lo, hi, step):
+    """(start, step, count) of range(lo, hi, step)."""
+    return (int(lo), int(step), max(0, -(-(int(hi) - int(lo)) // int(step))))
+
+
 def round2_estimation_of_repeat_size(initial_estimation, fastq_dict, repeat_chrom_seq, repeat1,
                                      repeat2, data_type="ont", num_threads=1, out_dir=None,
-                                     device=0, scoring=None, scorer=None, strands=None, session=None):
+                                     device=0, scoring=None, scorer=None, strands=None, session=None, _ctx=None):
     """Coarse grid (nanoRepeat_joint.py:376-425).  `strands` (dict, optional) carries each read's
     orientation between rounds so round 3 does not probe it again; `session` the resident reads."""
     _check_repeat_order(repeat1, repeat2)
@@ -460,17 +516,14 @@ def round2_estimation_of_repeat_size(initial_estimation, fastq_dict, repeat_chro
     if own:
         session = GridSession(_joint_region(repeat_chrom_seq, repeat1, repeat2), fastq_dict, device, scoring, scorer, parts=1)
     try:
-        # The reference visits grid cell by grid cell and, per cell, the reads whose round-1 ranges hold it
-        # (:397-409); per read that is the product of the grid values inside its two ranges.
-        grid1 = np.arange(repeat1.round1_min_size, repeat1.round1_max_size + 1, step_size1)
-        grid2 = np.arange(repeat2.round1_min_size, repeat2.round1_max_size + 1, step_size2)
-        r1, r2 = initial_estimation.repeat1_count_range_dict, initial_estimation.repeat2_count_range_dict
-        rows = _rows_with(session.names, r1, r2)
-        rng1 = _values_of(r1, session.names, rows, np.int64).reshape(-1, 2)
-        rng2 = _values_of(r2, session.names, rows, np.int64).reshape(-1, 2)
-        est = _score_round(session, rows,
-                           grid1, np.searchsorted(grid1, rng1[:, 0]), np.searchsorted(grid1, rng1[:, 1]),
-                           grid2, np.searchsorted(grid2, rng2[:, 0]), np.searchsorted(grid2, rng2[:, 1]), strands)
+        # The reference visits grid cell by grid cell (k1 in range(min1, max1 + 1, s1), k2 alike, :397-398) and, per
+        # cell, the reads whose round-1 ranges hold it (min <= k < max on both axes, :407): per read that is the
+        # product of the grid values inside its two ranges -- the routing nra_batch2d_set_grid does
+        ctx = _context(session, initial_estimation, strands, _ctx)
+        est = _score_round(session, ctx, ctx.rows,
+                           _axis(repeat1.round1_min_size, repeat1.round1_max_size + 1, step_size1), ctx.range1[:, 0], ctx.range1[:, 1],
+                           _axis(repeat2.round1_min_size, repeat2.round1_max_size + 1, step_size2), ctx.range2[:, 0], ctx.range2[:, 1],
+                           strands, (step_size1, step_size2))
     finally:
         if own:
             session.close()
@@ -481,10 +534,10 @@ def round2_estimation_of_repeat_size(initial_estimation, fastq_dict, repeat_chro
 def round3_estimation_of_repeat_size(initial_estimation, round2_estimation, fastq_dict,
                                      repeat_chrom_seq, repeat1, repeat2, data_type="ont",
                                      num_threads=1, out_dir=None, device=0, scoring=None,
-                                     scorer=None, strands=None, session=None):
+                                     scorer=None, strands=None, session=None, _ctx=None):
     """Fine grid, step 1 (nanoRepeat_joint.py:275-349)."""
-    done1, done2 = round2_estimation.repeat1_count_dict, round2_estimation.repeat2_count_dict
-    if len(done1) == 0 or len(done2) == 0:
+    if len(round2_estimation) == 0 if isinstance(round2_estimation, LazyRepeatSize) else \
+            (len(round2_estimation.repeat1_count_dict) == 0 or len(round2_estimation.repeat2_count_dict) == 0):
         return RepeatSize()
     _check_repeat_order(repeat1, repeat2)
     if session is not None and session.subs:
@@ -496,23 +549,34 @@ def round3_estimation_of_repeat_size(initial_estimation, round2_estimation, fast
     if own:
         session = GridSession(_joint_region(repeat_chrom_seq, repeat1, repeat2), fastq_dict, device, scoring, scorer, parts=1)
     try:
-        rows = _rows_with(session.names, done1, done2)
-        size1 = _values_of(done1, session.names, rows, np.float64)
-        size2 = _values_of(done2, session.names, rows, np.float64)
+        ctx = _context(session, initial_estimation, strands, _ctx)
+        have = round2_estimation.sizes_for(session.names) if isinstance(round2_estimation, LazyRepeatSize) else None
+        if have is not None:                     # round 2 was scored on this very session: its arrays, no dicts
+            rows, size1, size2 = have
+            all1, all2 = size1, size2
+        else:
+            done1, done2 = round2_estimation.repeat1_count_dict, round2_estimation.repeat2_count_dict
+            rows = _rows_with(session.names, done1, done2)
+            size1 = _values_of(done1, session.names, rows, np.float64)
+            size2 = _values_of(done2, session.names, rows, np.float64)
+            both = [name for name in done1 if name in done2]
+            all1 = np.array([done1[name] for name in both], np.float64)
+            all2 = np.array([done2[name] for name in both], np.float64)
         # the global grid spans every read's round-2 size +- one coarse step (:298-303) ...
-        both = [name for name in done1 if name in done2]
-        all1 = np.array([done1[name] for name in both], np.float64)
-        all2 = np.array([done2[name] for name in both], np.float64)
-        grid1 = np.arange(max(0, int(all1.min() - buf1)), int(all1.max() + buf1 + 2))
-        grid2 = np.arange(max(0, int(all2.min() - buf2)), int(all2.max() + buf2 + 2))
+        axis1 = _axis(max(0, int(all1.min() - buf1)), int(all1.max() + buf1 + 2), 1)
+        axis2 = _axis(max(0, int(all2.min() - buf2)), int(all2.max() + buf2 + 2), 1)
         # ... and a read takes the cells within one step of its own size that lie inside its round-1 range (:320-330)
-        r1 = _values_of(initial_estimation.repeat1_count_range_dict, session.names, rows, np.float64).reshape(-1, 2)
-        r2 = _values_of(initial_estimation.repeat2_count_range_dict, session.names, rows, np.float64).reshape(-1, 2)
-        est = _score_round(session, rows,
-                           grid1, np.searchsorted(grid1, np.maximum(size1 - buf1, r1[:, 0])),
-                           np.searchsorted(grid1, np.minimum(size1 + buf1, r1[:, 1])),
-                           grid2, np.searchsorted(grid2, np.maximum(size2 - buf2, r2[:, 0])),
-                           np.searchsorted(grid2, np.minimum(size2 + buf2, r2[:, 1])), strands)
+        where = np.zeros(0, np.int64)                      # the reads of `rows` all have round-1 ranges
+        if len(rows):
+            if len(ctx.rows) == 0:
+                raise KeyError("a read with a round-2 size has no round-1 range")
+            where = np.minimum(np.searchsorted(ctx.rows, rows), len(ctx.rows) - 1)
+            if not np.array_equal(ctx.rows[where], rows):
+                raise KeyError("a read with a round-2 size has no round-1 range")
+        r1, r2 = ctx.range1[where], ctx.range2[where]
+        est = _score_round(session, ctx, rows,
+                           axis1, np.maximum(size1 - buf1, r1[:, 0]), np.minimum(size1 + buf1, r1[:, 1]),
+                           axis2, np.maximum(size2 - buf2, r2[:, 0]), np.minimum(size2 + buf2, r2[:, 1]), strands, (1, 1))
     finally:
         if own:
             session.close()
@@ -529,7 +593,7 @@ def fine_tune_read_count(initial_estimation, fastq_dict, repeat_chrom_seq, repea
     _check_repeat_order(repeat1, repeat2)
     for rep, ranges in ((repeat1, initial_estimation.repeat1_count_range_dict),
                         (repeat2, initial_estimation.repeat2_count_range_dict)):
-        span = np.array(list(ranges.values()), np.int64).reshape(-1, 2)
+        span = np.fromiter(chain.from_iterable(ranges.values()), np.int64, 2 * len(ranges)).reshape(-1, 2)
         lo = min(rep.max_size, int(span[:, 0].min())) if len(span) else rep.max_size
         hi = max(0, int(span[:, 1].max())) if len(span) else 0
         rep.round1_min_size, rep.round1_max_size = lo, min(hi, rep.max_size)            # :239-259
@@ -540,22 +604,21 @@ def fine_tune_read_count(initial_estimation, fastq_dict, repeat_chrom_seq, repea
     def both_rounds(sess, rep1, rep2):
         # a read's strand is known from round 1 when that was run here (the left template is forward)
         strands = dict(getattr(initial_estimation, "read_strand_dict", {}))
+        ctx = _Round1Arrays(sess, initial_estimation, strands)
         est = round2_estimation_of_repeat_size(initial_estimation, fastq_dict, repeat_chrom_seq, rep1, rep2,
-                                               data_type, num_threads, out_dir, device, scoring, scorer, strands, sess)
+                                               data_type, num_threads, out_dir, device, scoring, scorer, strands, sess, ctx)
         if est.step_size1 > 1 and est.step_size2 > 1:                                    # :268
             est = round3_estimation_of_repeat_size(initial_estimation, est, fastq_dict, repeat_chrom_seq, rep1,
                                                    rep2, data_type, num_threads, out_dir, device, scoring, scorer,
-                                                   strands, sess)
+                                                   strands, sess, ctx)
         return est
 
     try:
         if not session.subs:
             return both_rounds(session, repeat1, repeat2)
-        # Groups of reads in parallel threads (GridSession).  Everything global -- the round-1 spans above, the
+        # Groups of reads in parallel threads (GridSession.parts).  Everything global -- the round-1 spans above, the
         # step sizes -- comes from the round-1 ranges of ALL reads, which every group sees; what a group derives
         # from its own round-2 results (round 3's grid span) only has to cover its own reads' cells.
-        # (a thread coming back from the device has to get the interpreter from the one building its cell list:
-        # the default hand-over interval, 5 ms, is a third of the whole job)
         def turn(sub):
             with session.host_lock:
                 sub.in_turn = True
@@ -564,15 +627,7 @@ def fine_tune_read_count(initial_estimation, fastq_dict, repeat_chrom_seq, repea
                 finally:
                     sub.in_turn = False
 
-        # (a thread coming back from the device has to get the interpreter from whatever runs meanwhile:
-        # the default hand-over interval, 5 ms, is a third of the whole job)
-        import sys
-        interval = sys.getswitchinterval()
-        sys.setswitchinterval(min(interval, 2e-4))
-        try:
-            return _merge_parts(list(session.pool.map(turn, session.subs)))
-        finally:
-            sys.setswitchinterval(interval)
+        return _merge_parts(list(session.pool.map(turn, session.subs)))
     finally:
         if own:
             session.close()

@@ -365,6 +365,40 @@ def test_joint_resident_reads_across_cell_lists(capi, oracle):
                 assert np.array_equal(np.asarray(one[key])[sel], np.asarray(o[key])[sel]), (step, shift, key)
 
 
+def test_joint_routed_grid_equals_its_cell_list(capi, oracle):
+    """nra_batch2d_set_grid (the library routes reads to grid cells and builds the sweeps from the per-read rows)
+    against nra_batch2d_set_cells on the cell list nra_joint_grid_cells gives for the same grid, and the oracle:
+    coarse and fine grids, fractional bounds (round 3 compares means), reads without cells, several rounds on one
+    resident batch, strands given and probed."""
+    j = synth.make_joint(14, alleles=((9, 5), (14, 3)), read_len=520, read_sd=30, anchor=300, seed=74)
+    n = len(j["reads"])
+    t1, t2 = j["truth"][:, 0].astype(np.float64), j["truth"][:, 1].astype(np.float64)
+    strands = j["strand"].astype(np.int8)
+    rounds = [((2, 3, 7), t1 - 5, t1 + 6, (0, 2, 6), t2 - 3, t2 + 4, strands),
+              ((5, 1, 14), t1 - 1.5, t1 + 1.5, (1, 1, 8), t2 - 1 / 3, t2 + 2.5, strands),
+              ((0, 4, 6), t1 - 8, t1 + 3, (0, 1, 9), np.where(np.arange(n) % 5 == 2, 99.0, t2 - 2), t2 + 2, None),
+              ((3, 1, 20), t1 - 2, t1 + 2.5, (2, 1, 2), t2 - 9, t2 + 9, strands)]
+    with capi.Batch.create_2d_reads(j["region"], j["reads"]) as by_grid, \
+            capi.Batch.create_2d_reads(j["region"], j["reads"]) as by_list:
+        for a1, lo1, hi1, a2, lo2, hi2, st in rounds:
+            grid = capi.Grid(a1, lo1, hi1, a2, lo2, hi2)
+            cr, k1, k2 = capi.joint_grid_cells(grid)
+            assert by_grid.set_grid(grid, st) == len(cr) > 0
+            by_grid.run(); by_grid.sync()
+            g = by_grid.fetch()
+            by_list.set_cells(cr, k1, k2, st)
+            by_list.run(); by_list.sync()
+            l = by_list.fetch()
+            o = oracle.joint_2d(j["region"], j["reads"], cr, k1, k2, read_strand=st)
+            has = np.zeros(n, bool); has[cr] = True
+            for key in o:
+                sel = has if len(o[key]) == n else slice(None)
+                assert np.array_equal(np.asarray(g[key])[sel], np.asarray(o[key])[sel]), (a1, key)
+                assert np.array_equal(np.asarray(l[key])[sel], np.asarray(o[key])[sel]), (a1, key)
+        # a grid that gives no read a cell is an empty round, not an error
+        assert by_grid.set_grid(capi.Grid((0, 1, 4), t1 + 50, t1 + 60, (0, 1, 4), t2, t2 + 1), strands) == 0
+
+
 def test_joint_packed_flank_sweeps(capi, oracle):
     """The columns of L and rev(R) outside the scoring window are swept in packed int16 cells, two reads per
     wave, and the int32 sweeps resume from the state they leave: flanks just below / at / above the 64-column
@@ -413,6 +447,29 @@ def test_more_chained_tasks_than_scratch_strips(capi, oracle):
     o = oracle.round3_1d(d["regions"], [d["reads"][i] for i in pick], d["kmin"][pick], d["kmax"][pick])
     for k in ("best_score", "sum_k", "n_ties", "status"):
         assert np.array_equal(base[k][pick], o[k]), k
+
+
+def test_one_read_against_a_megabase_template(capi, oracle):
+    """A template far beyond the 16-bit extents of the int32 cells (1.2 M columns: k = 240 000 units of 5 bases):
+    the read runs as a chained int32 sweep and its ties through the int64 extents kernel.  The scratch strips of
+    the chained kernels are sized by the tasks there are (one here), not by the launch's largest grid -- at
+    512 / 4096 strips this template would ask for tens of GB.  Beside it a short-template read in the same call."""
+    rng = np.random.default_rng(4)
+    L, R = synth.rand_seq(rng, 300), synth.rand_seq(rng, 300)
+    reads = [synth.apply_errors(rng, L[-100:] + "TATTG" * 80 + R[:100], "ont_q20"),
+             synth.apply_errors(rng, L[-100:] + "TATTG" * 30 + R[:100], "ont_q20")]
+    kmin, kmax = [239999, 25], [240000, 35]
+    o = oracle.round3_1d([(L, "TATTG", R)], reads, kmin, kmax)
+    for flags in (0, capi.F_TIE_EXTENTS):
+        g = capi.round3_1d([(L, "TATTG", R)], reads, kmin, kmax, flags=flags)
+        for k in ("best_score", "sum_k", "n_ties", "status", "cand_score"):
+            assert np.array_equal(g[k], o[k]), (flags, k, g[k][:4], o[k][:4])
+        if flags:
+            ties = o["cand_tstart"] >= 0
+            assert np.array_equal(g["cand_tstart"][ties], o["cand_tstart"][ties])
+            assert np.array_equal(g["cand_tend"][ties], o["cand_tend"][ties])
+    assert g["status"][1] == 0 and g["sum_k"][1] == 30 * g["n_ties"][1]
+    capi.release_cached_memory()
 
 
 def test_long_joint_reads_uncut_equal_oracle(capi, oracle):

@@ -172,10 +172,12 @@ def test_bulk_dict_lookups_of_the_grid_rounds():
     assert J._rows_with(names, full, part).tolist() == [0, 1, 3, 4, 6]
     assert J._rows_with(names, {}).tolist() == []
     rows = J._rows_with(names, full, part)
-    assert J._values_of(full, names, rows, np.int64).reshape(-1, 2).tolist() == [[i, i + 5] for i in (0, 1, 3, 4, 6)]
+    assert J._values_of(full, names, rows, np.int64, 2).tolist() == [[i, i + 5] for i in (0, 1, 3, 4, 6)]
     assert J._values_of(part, names, rows, np.float64).tolist() == [0.0, 1.0, 3.0, 4.0, 6.0]
-    assert J._values_of(full, names, np.arange(7), np.int64).shape == (7, 2)
-    assert J._values_of(full, names[:1], np.arange(1), np.int64).reshape(-1, 2).tolist() == [[0, 5]]
-    assert len(J._values_of(full, names, np.zeros(0, np.int64), np.int64)) == 0
+    assert J._values_of(full, names, np.arange(7), np.int64, 2).tolist() == [[i, i + 5] for i in range(7)]   # flat pass
+    shuffled = {n: full[n] for n in reversed(names)}               # same names, another order: looked up by name
+    assert J._values_of(shuffled, names, np.arange(7), np.int64, 2).tolist() == [[i, i + 5] for i in range(7)]
+    assert J._values_of(full, names[:1], np.arange(1), np.int64, 2).tolist() == [[0, 5]]
+    assert len(J._values_of(full, names, np.zeros(0, np.int64), np.int64, 2)) == 0
     bigger = dict(full); bigger["extra"] = (9, 9)                  # more keys than names: still the fast path
     assert J._rows_with(names, bigger).tolist() == list(range(7))

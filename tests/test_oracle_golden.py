@@ -112,6 +112,30 @@ def test_grid_routing_matches_reference(golden_2d):
         assert cr == sorted(cr), "cells must be grouped by read for the C ABI"
 
 
+def test_grid_routing_in_the_library_equals_a_plain_enumeration(capi):
+    """nra_joint_grid_cells (the routing nra_batch2d_set_grid applies) against the nested loops it replaces: grid
+    values inside half-open float bounds, reads without a value on one axis dropped, k1-major order."""
+    rng = np.random.default_rng(3)
+    for trial in range(60):
+        n = int(rng.integers(0, 40))
+        a1 = (int(rng.integers(0, 30)), int(rng.integers(1, 8)), int(rng.integers(0, 25)))
+        a2 = (int(rng.integers(0, 10)), int(rng.integers(1, 4)), int(rng.integers(0, 12)))
+        bounds = []
+        for start, step, count in (a1, a2):
+            lo = rng.integers(-5, start + step * count + 5, size=n).astype(np.float64) + rng.choice([0.0, 0.5, 1 / 3, 0.25], size=n)
+            hi = lo + rng.integers(-3, 40, size=n) + rng.choice([0.0, 0.5, 2 / 3], size=n)
+            bounds += [lo, hi]
+        got = capi.joint_grid_cells(capi.Grid(a1, bounds[0], bounds[1], a2, bounds[2], bounds[3]))
+        want = []
+        for r in range(n):
+            g1 = [k for k in range(a1[0], a1[0] + a1[1] * a1[2], a1[1]) if bounds[0][r] <= k < bounds[1][r]]
+            g2 = [k for k in range(a2[0], a2[0] + a2[1] * a2[2], a2[1]) if bounds[2][r] <= k < bounds[3][r]]
+            want += [(r, x, y) for x in g1 for y in g2]
+        assert list(zip(*[v.tolist() for v in got])) == want, (trial, a1, a2)
+    with pytest.raises(capi.NraError):
+        capi.joint_grid_cells(capi.Grid((0, 0, 3), [0.0], [1.0], (0, 1, 3), [0.0], [1.0]))
+
+
 # ------------------------------------------------------------------ end to end with the oracle as scorer
 def test_round3_end_to_end_matches_reference(oracle, golden_1d):
     for c in golden_1d["e2e"]:

@@ -81,14 +81,21 @@ def main():
             sweep[c] += v
     fetch, write = sweep.get("FETCH_SIZE", 0.0) * 1024 / steps, sweep.get("WRITE_SIZE", 0.0) * 1024 / steps
     valu = sweep.get("SQ_INSTS_VALU", 0.0) / steps
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from bench import kernel_source_sha16
     res = {"command": "rocprofv3 --pmc <group> --kernel-trace --output-format csv -- python3 bench.py --steps "
-                      f"{steps} --warmup 0 --cpu-sample 0 --one-shot-calls 0 (one pass per counter group)",
+                      f"{steps} --warmup 0 --cpu-sample 0 --one-shot-calls 0 --sub-configs none {opts.get('--flags', '')} "
+                      "(one pass per counter group)",
+           "source_sha16": kernel_source_sha16(),       # bench.py quotes these counters only for the same kernel sources
            "kernel": kern, "steps": steps,
            "hbm_bytes_per_step_sweep_kernels": fetch + write,
            "sweep_kernels": {"fetch_bytes": fetch, "fetch_bytes_x2_upper_bound": 2 * fetch, "write_bytes": write,
                              "valu_wave_instructions_per_step": valu,
                              "counters_per_step": {c: v / steps for c, v in sorted(sweep.items())}}}
     res["per_kernel_serialised"] = per_kernel
+    ns = sum(e["ns"] for e in per_kernel.values())
+    if ns > 0:      # shader clock over the sweep kernels' dispatches (serialised in the counter passes)
+        res["clock_GHz"] = sum(e["gui_active"] for e in per_kernel.values()) / 8.0 / ns
     if sweep.get("SQ_ACTIVE_INST_VALU") and valu:
         # quad-cycles of VALU activity per wave instruction (MI355X_MICROARCH.md: SQ_ACTIVE_INST_* count quad-cycles)
         res["simd_cycles_per_valu_instruction_active"] = 4.0 * sweep["SQ_ACTIVE_INST_VALU"] / sweep["SQ_INSTS_VALU"]
