@@ -59,6 +59,8 @@ extern "C" {
                                  two pairs per wave, 32 lanes each (k_sweep_ring32) */
 #define NRA_F_NO_JOINT_PACK 64 /* testing / comparison, 2D: sweep the columns outside the scoring window in the int32 payload
                                  cells too, instead of packed int16 cells with two reads per wave (k_joint_pk16) */
+#define NRA_F_SERIAL_CHAIN 128 /* testing / comparison, 1D: sweep the row blocks of a long read one after the other in one wave
+                                 (k_sweep_ringchain) instead of as concurrent waves (k_sweep_ringmt) */
 #define NRA_F_BRUTE_FORCE  4  /* score the K candidates of a read as K independent alignments
                                  (k_score_pk16) instead of the junction decomposition (k_sweep_pk16) */
 

@@ -9,6 +9,7 @@
 #include "nra_internal.h"
 
 #include <algorithm>
+#include <atomic>
 #include <chrono>
 #include <cmath>
 #include <cstdio>
@@ -310,6 +311,8 @@ struct Bucket {
     int payload_R = 0;         // chained: row block of the extents kernel (NRA_CHAIN_R / NRA_CHAIN_R_TEST)
     size_t strip_off = 0;      // chained: this bucket's scratch strips in chain_sweep (int32 index)
     int n_strips = 0;
+    bool mt = false;           // chained LDS-ring sweeps with the row blocks of a read as concurrent waves (k_sweep_ringmt)
+    std::vector<std::pair<size_t, int>> mt_groups;   // launches: (first entry of chain_blocks, number of blocks)
     int n_pair = 0;            // pk16 tasks (1D score / 2D strand probe)
     size_t pair_off = 0;       // offset into pair_tasks
     int n_queue = 0;           // payload tasks prebuilt on the host (ALL_EXTENTS / 2D cells)
@@ -369,6 +372,16 @@ void fold_small_buckets(std::vector<std::vector<int32_t>>& by_bucket, size_t min
         by_bucket[up].insert(by_bucket[up].end(), by_bucket[bi].begin(), by_bucket[bi].end());
         by_bucket[bi].clear();
     }
+}
+
+// Every launch of the concurrent-block sweeps (k_sweep_ringmt) tags the granules it publishes with an epoch of its own:
+// process-wide, never 0 (a zeroed strip carries none).
+uint32_t next_epoch()
+{
+    static std::atomic<uint32_t> counter{0};
+    uint32_t e = ++counter;
+    if (e == 0) e = ++counter;
+    return e;
 }
 
 // Scratch strips of a chained launch: one per wave, `bytes_per_strip` each (a few values per template column).  As
@@ -443,6 +456,9 @@ struct nra_batch {
     bool all_strands_given = false;             // 2D: every read came with its strand, no probe needed
     int chain_cap = 0;
     int payload_strips = 0;                     // waves of a chained payload launch (strips in chain_payload)
+    DevBuf<NraChainBlock> chain_blocks;         // k_sweep_ringmt: (task, row block) lists, launch group after launch group
+    DevBuf<uint64_t> mt_strips;                 // ... the granule strips between consecutive blocks (zeroed at create)
+    DevBuf<int32_t> mt_words;                   // ... [0] ticket, [1] launch-wide give-up word
     DevBuf<NraTask> queue_tasks;
     DevBuf<int32_t> queue_count;   // per bucket: prebuilt queue length (constant)
     DevBuf<int32_t> tie_count;     // per bucket: tie queue length (device-written)
@@ -474,6 +490,9 @@ struct nra_batch {
     int n_score_ev = 0, n_ext_ev = 0;
     bool ran = false, accounted = false;
     bool have_cells = false;   // 2D: nra_batch2d_set_cells has run
+    bool mt_checked = true;         // 1D: the give-up word of the concurrent-block sweeps has been read after this run
+    bool flanks_enqueued = false;   // 2D: the strand-only kernels of this cell list are on their streams already
+    int ev_next = 2;                // 2D: next free timing-event pair (the run is enqueued in two parts)
     nra_stats_t stats{};
 
     ~nra_batch()
@@ -882,13 +901,18 @@ int nra_batch1d_create(int device, const nra_region_t* regions, int32_t n_region
     // more rows than one register block, scores beyond the doubled int16 range, or a template whose
     // extents do not fit the 16-bit payload of the int32 extents kernel.
     const bool test_chain = (flags & NRA_F_TEST_CHAIN) != 0;
+    // reads of more rows than this leave the one-block kernels for the chained ones (NRA_CHAIN_FROM: experiments)
+    int chain_from = NRA_MAX_QLEN_1BLOCK;
+    if (const char* e = getenv("NRA_CHAIN_FROM")) chain_from = std::max(64, std::min(atoi(e), NRA_MAX_QLEN_1BLOCK));
+    const bool ring_units = [&] { for (int32_t g = 0; g < n_regions; ++g) if (regions[g].unit_len > NRA_SWEEP_RING_MAX_M) return false; return true; }();
+    if (!ring_units || brute || (flags & (NRA_F_DPP_SWEEP | NRA_F_SERIAL_CHAIN))) chain_from = NRA_MAX_QLEN_1BLOCK;
     std::vector<uint8_t> chained((size_t)n_reads, 0);
     for (int32_t r = 0; r < n_reads; ++r) {
         if (kmin[r] > kmax[r]) continue;
         const nra_region_t& rg = regions[pr.reads[r].region];
         const int64_t ms = max_score(sc, pr.reads[r].qlen);
         const int64_t tl = (int64_t)rg.left_len + (int64_t)rg.unit_len * kmax[r] + rg.right_len;
-        chained[r] = test_chain || pr.reads[r].qlen > NRA_MAX_QLEN_1BLOCK || ms > kScoreCapBit || tl > NRA_MAX_TLEN;
+        chained[r] = test_chain || pr.reads[r].qlen > chain_from || ms > kScoreCapBit || tl > NRA_MAX_TLEN;
         if (brute && chained[r] && !test_chain) {
             // without the sweeps (flank-less region, unusual scoring, brute force on request) only what the
             // packed brute-force kernel holds can be scored
@@ -938,7 +962,8 @@ int nra_batch1d_create(int device, const nra_region_t* regions, int32_t n_region
         for (int i = 0; i < kNumR; ++i) { by_bucket[i] = std::move(full[i]); by_bucket[kNumR + 2 + i] = std::move(halfb[i]); }
     }
     clk.mark("  small buckets folded");
-    size_t strip_total = 0, chain_queue_cap = 0;
+    size_t strip_total = 0, chain_queue_cap = 0, mt_strip_total = 0;
+    std::vector<NraChainBlock> chain_blocks;
     std::vector<NraPairTask> pair_tasks;
     std::vector<NraTask> queue_tasks;       // ALL_EXTENTS only; otherwise just capacity
     std::vector<int32_t> queue_count;
@@ -961,7 +986,17 @@ int nra_batch1d_create(int device, const nra_region_t* regions, int32_t n_region
             for (int32_t r : by_bucket[bi])
                 if (regions[pr.reads[r].region].unit_len > NRA_SWEEP_RING_MAX_M) bk.ring = false;
             bk.payload_R = test_chain ? NRA_CHAIN_R_TEST : NRA_CHAIN_R;
-            bk.R = test_chain ? NRA_CHAIN_R_TEST : (bk.ring ? NRA_RING_CHAIN_R : NRA_CHAIN_R);
+            // the row blocks of a read as concurrent waves (k_sweep_ringmt), unless one read alone would need more
+            // strips than the scratch budget holds (then: one wave per read, block after block, two strips)
+            bk.mt = bk.ring && (flags & NRA_F_SERIAL_CHAIN) == 0;
+            if (bk.mt) {
+                const int rows = 64 * (test_chain ? NRA_CHAIN_R_TEST : NRA_RING_MT_R);
+                int qmax = 0;
+                for (int32_t r : by_bucket[bi]) qmax = std::max(qmax, pr.reads[r].qlen);
+                const size_t fit = (size_t)(NRA_CHAIN_SCRATCH_BUDGET / 2) / ((size_t)5 * 8 * (size_t)b->chain_cap);
+                if ((size_t)((qmax + rows - 1) / rows) > fit + 1) bk.mt = false;
+            }
+            bk.R = test_chain ? NRA_CHAIN_R_TEST : (bk.mt ? NRA_RING_MT_R : bk.ring ? NRA_RING_CHAIN_R : NRA_CHAIN_R);
         } else {
             bk.R = kRList[bk.half ? bi - kNumR - 2 : bi];
         }
@@ -1024,7 +1059,7 @@ int nra_batch1d_create(int device, const nra_region_t* regions, int32_t n_region
                     const NraDevRegion& d = dregs[g];
                     bk.cells_sweep += (int64_t)2 * 64 * bk.R * ((d.l1 + d.m1 * t.kmax + 31 * d.m1) + (d.l3 + 31));
                     t.snap_off = snap_total;
-                    snap_total += (uint64_t)3 * bk.R * 64;
+                    snap_total += (uint64_t)NRA_SNAP_LANE_STRIDE(bk.R) * 64;       // lane-major in the half-wave kernel
                     sweep_tasks.push_back(t);
                 }
             } else
@@ -1056,7 +1091,47 @@ int nra_batch1d_create(int device, const nra_region_t* regions, int32_t n_region
                 sweep_tasks.push_back(t);
             }
             bk.n_sweep = (int)(sweep_tasks.size() - bk.sweep_off);
-            if (bk.chain) {
+            if (bk.chain && bk.mt) {
+                // launch groups: as many tasks as the strip budget holds (one strip between consecutive blocks of a
+                // task), each group's (task, block) list block-major: all blocks 0, then all blocks 1, ...
+                const size_t fit = std::max<size_t>(1, (size_t)(NRA_CHAIN_SCRATCH_BUDGET / 2) / ((size_t)5 * 8 * (size_t)b->chain_cap));
+                const int rows = 64 * bk.R;
+                auto nblk_of = [&](const NraSweepTask& t) {
+                    int qmax = pr.reads[t.read_a].qlen;
+                    if (t.read_b >= 0) qmax = std::max(qmax, pr.reads[t.read_b].qlen);
+                    return std::max(1, (qmax + rows - 1) / rows);
+                };
+                size_t most_strips = 0;
+                for (int t0 = 0; t0 < bk.n_sweep;) {
+                    size_t used = 0;
+                    int t1 = t0, max_blk = 0;
+                    std::vector<size_t> base;
+                    while (t1 < bk.n_sweep) {
+                        const int nb2 = nblk_of(sweep_tasks[bk.sweep_off + (size_t)t1]);
+                        if (t1 > t0 && used + (size_t)(nb2 - 1) > fit) break;
+                        base.push_back(used);
+                        used += (size_t)(nb2 - 1);
+                        max_blk = std::max(max_blk, nb2);
+                        ++t1;
+                    }
+                    const size_t first_block = chain_blocks.size();
+                    for (int blk = 0; blk < max_blk; ++blk)
+                        for (int t = t0; t < t1; ++t) {
+                            const int nb2 = nblk_of(sweep_tasks[bk.sweep_off + (size_t)t]);
+                            if (blk >= nb2) continue;
+                            const int32_t sb = (int32_t)base[(size_t)(t - t0)];
+                            chain_blocks.push_back(NraChainBlock{t, blk, nb2, blk > 0 ? sb + blk - 1 : -1,
+                                                                 blk < nb2 - 1 ? sb + blk : -1});
+                        }
+                    bk.mt_groups.push_back({first_block, (int)(chain_blocks.size() - first_block)});
+                    most_strips = std::max(most_strips, used);
+                    t0 = t1;
+                }
+                bk.n_strips = (int)most_strips;
+                bk.strip_off = mt_strip_total;                     // (in strips of 5 * chain_cap granules)
+                mt_strip_total += most_strips;
+                chain_queue_cap = std::max(chain_queue_cap, bk.queue_cap);
+            } else if (bk.chain) {
                 // (two chained buckets at most -- packed and int32 -- share the budget)
                 bk.n_strips = chain_strips((size_t)bk.n_sweep, bk.ring ? NRA_RING_CHAIN_STRIPS : NRA_CHAIN_STRIPS,
                                            (size_t)10 * 4 * (size_t)b->chain_cap, NRA_CHAIN_SCRATCH_BUDGET / 2);
@@ -1094,8 +1169,16 @@ int nra_batch1d_create(int device, const nra_region_t* regions, int32_t n_region
         HIP_TRY(b->read_a1d.alloc((size_t)n_reads));
     }
     HIP_TRY(b->cand_flag.alloc((size_t)total));
-    if (strip_total) {
-        HIP_TRY(b->chain_sweep.alloc(strip_total));
+    if (!chain_blocks.empty()) {
+        HIP_TRY(b->chain_blocks.upload(chain_blocks));
+        const size_t granules = std::max<size_t>(mt_strip_total, 1) * 5 * (size_t)b->chain_cap;
+        HIP_TRY(b->mt_strips.alloc(granules));
+        HIP_TRY(hipMemset(b->mt_strips.p, 0, granules * 8));       // no granule carries an epoch yet (epochs are never 0)
+        HIP_TRY(b->mt_words.alloc(2 + b->buckets.size()));
+        HIP_TRY(hipMemset(b->mt_words.p, 0, (2 + b->buckets.size()) * 4));
+    }
+    if (strip_total || !chain_blocks.empty()) {
+        if (strip_total) HIP_TRY(b->chain_sweep.alloc(strip_total));
         // the chained buckets' extents launches run in turn and share these strips (int64 cells)
         b->payload_strips = chain_strips(chain_queue_cap, NRA_CHAIN_STRIPS, (size_t)6 * 8 * (size_t)b->chain_cap);
         HIP_TRY(b->chain_payload.alloc((size_t)b->payload_strips * 6 * (size_t)b->chain_cap));
@@ -1152,6 +1235,12 @@ static int run_1d(nra_batch* b)
     HIP_TRY(hipMemsetAsync(b->cand_tend.p, 0xff, std::max<size_t>(nc, 1) * 4, st));
     HIP_TRY(hipMemsetAsync(b->tie_count.p, 0, std::max<size_t>(nb, 1) * 4, st));
     HIP_TRY(hipMemsetAsync(b->cand_flag.p, 2, std::max<size_t>(nc, 1), st));   // 2 = "needs the extents DP"
+    if (b->chain_blocks.n > 0) {
+        // concurrent row blocks: every block adds its maximum to the read's A (atomicMax; A >= 0); the give-up word
+        HIP_TRY(hipMemsetAsync(b->read_a1d.p, 0, std::max<size_t>((size_t)b->n_reads, 1) * 4, st));
+        HIP_TRY(hipMemsetAsync(b->mt_words.p, 0, 4, st));
+        b->mt_checked = false;
+    }
     int ev = 2;
     b->n_score_ev = 0; b->n_ext_ev = 0;
     const int max_waves = 256 * 16;
@@ -1167,7 +1256,15 @@ static int run_1d(nra_batch* b)
             HIP_TRY(hipStreamWaitEvent(q, b->fork_ev, 0));
             HIP_TRY(hipEventRecord(b->ev[ev++], q));
             int32_t* strips = bk.chain ? b->chain_sweep.p + bk.strip_off : nullptr;
-            if (bk.ring && bk.chain)
+            if (bk.mt) {
+                for (const auto& g : bk.mt_groups)
+                    LAUNCH_TRY(nra_launch_sweep_ringmt_bwd(bk.R, b->has_n, bk.wide ? 1 : 0, q, g.second, b->chain_blocks.p + g.first,
+                                                           b->mt_words.p + 2 + i, b->sweep_tasks.p + bk.sweep_off, b->reads.p,
+                                                           b->regions.p, b->pool.p, b->q2bit.p, b->qnmask.p, b->sp, b->kmin.p,
+                                                           b->kmax.p, b->coff.p, b->snap.p, b->read_a1d.p,
+                                                           b->mt_strips.p + bk.strip_off * 5 * (size_t)b->chain_cap, b->chain_cap,
+                                                           next_epoch(), b->mt_words.p));
+            } else if (bk.ring && bk.chain)
                 LAUNCH_TRY(nra_launch_sweep_ringchain_bwd(bk.R, b->has_n, bk.wide ? 1 : 0, q, bk.n_sweep,
                                                           b->sweep_tasks.p + bk.sweep_off, b->reads.p, b->regions.p, b->pool.p,
                                                           b->q2bit.p, b->qnmask.p, b->sp, b->kmin.p, b->kmax.p, b->coff.p,
@@ -1187,7 +1284,16 @@ static int run_1d(nra_batch* b)
                                                 b->read_a1d.p, strips, b->chain_cap, bk.n_strips));
             HIP_TRY(hipEventRecord(b->ev[ev++], q));
             HIP_TRY(hipEventRecord(b->ev[ev++], q));
-            if (bk.ring && bk.chain)
+            if (bk.mt) {
+                for (const auto& g : bk.mt_groups)
+                    LAUNCH_TRY(nra_launch_sweep_ringmt_fwd(bk.R, b->has_n, bk.wide ? 1 : 0, q, g.second, b->chain_blocks.p + g.first,
+                                                           b->mt_words.p + 2 + i, b->sweep_tasks.p + bk.sweep_off, b->reads.p,
+                                                           b->regions.p, b->pool.p, b->q2bit.p, b->qnmask.p, b->sp, b->kmin.p,
+                                                           b->kmax.p, b->coff.p, b->snap.p, b->read_a1d.p, b->cand_score.p,
+                                                           b->cand_flag.p,
+                                                           b->mt_strips.p + bk.strip_off * 5 * (size_t)b->chain_cap, b->chain_cap,
+                                                           next_epoch(), b->mt_words.p));
+            } else if (bk.ring && bk.chain)
                 LAUNCH_TRY(nra_launch_sweep_ringchain_fwd(bk.R, b->has_n, bk.wide ? 1 : 0, q, bk.n_sweep,
                                                           b->sweep_tasks.p + bk.sweep_off, b->reads.p, b->regions.p, b->pool.p,
                                                           b->q2bit.p, b->qnmask.p, b->sp, b->kmin.p, b->kmax.p, b->coff.p,
@@ -1263,12 +1369,28 @@ static int run_1d(nra_batch* b)
     return NRA_OK;
 }
 
+// After a run with concurrent-block sweeps: did a wave give up waiting for the block above it?  (A hang guard that
+// should never fire; if it does the results of this run are not to be used.)
+static int check_mt(nra_batch* b)
+{
+    if (b->mt_checked || b->chain_blocks.n == 0) return NRA_OK;
+    int32_t failed = 0;
+    HIP_TRY(hipMemcpy(&failed, b->mt_words.p, 4, hipMemcpyDeviceToHost));
+    b->mt_checked = true;
+    if (failed) return fail(NRA_E_DEVICE, "chained sweep: a row block timed out waiting for the block above it");
+    return NRA_OK;
+}
+
 int nra_batch1d_fetch(nra_batch_t* b, int32_t* best_score, int64_t* sum_k, int32_t* n_ties,
                       uint8_t* status, int32_t* cand_score, int32_t* cand_tstart, int32_t* cand_tend)
 {
     if (!b || b->kind != 1) return fail(NRA_E_ARG, "not a 1D batch");
     HIP_TRY(hipSetDevice(b->device));
     HIP_TRY(hipStreamSynchronize(b->stream));
+    {
+        const int rcm = check_mt(b);
+        if (rcm) return rcm;
+    }
     const size_t n = (size_t)b->n_reads, nc = (size_t)b->n_cands;
     if (n) {
         int rc = fetch_results(b);
@@ -1449,6 +1571,7 @@ int route_grid(int32_t n_reads, int32_t start1, int32_t step1, int32_t count1, c
 
 int set_cells_common(nra_batch* b, const int8_t* read_strand, int64_t n_cells, const int32_t* cell_read,
                      const int32_t* cell_k1, const int32_t* cell_k2, const JointGrid* grid);
+int run_2d_flanks(nra_batch* b);
 
 }  // namespace
 
@@ -1521,6 +1644,11 @@ int set_cells_common(nra_batch* b, const int8_t* read_strand, int64_t n_cells, c
     if (n_cells > 0x7ff00000ll) return fail(NRA_E_RANGE, "too many cells");
     HIP_TRY(hipSetDevice(b->device));
     if (b->ran) HIP_TRY(hipStreamSynchronize(b->stream));      // the previous list's kernels own the buffers
+    if (b->flanks_enqueued) {                                  // ... also when only its first part was enqueued
+        for (hipStream_t q : b->bstreams) HIP_TRY(hipStreamSynchronize(q));
+        HIP_TRY(hipStreamSynchronize(b->stream));
+        b->flanks_enqueued = false;
+    }
     {
         int rc0 = account_run_fwd(b);
         if (rc0) return rc0;
@@ -1615,26 +1743,25 @@ int set_cells_common(nra_batch* b, const int8_t* read_strand, int64_t n_cells, c
         for (int32_t r = 0; r < n_reads; ++r) if (cnt[r] > 0 && read_strand[r] == 0) b->all_strands_given = false;
     int64_t alg_cells = 0;
     std::vector<int32_t> ks;
+    std::vector<int> bucket_ids;                     // by_bucket index of every entry of b->buckets
+
+    // ---- part 1: what depends on the reads and their strands only -- the reverse sweeps over R and the packed
+    // sweeps of the flanks outside the scoring window -- plus the strand probes.  With every strand given these
+    // kernels are enqueued right here, before the (longer) list of prefix and tail sweeps is built and uploaded:
+    // the host's share of a round then runs beside the device's first third of it.
     for (int bi = kNumR; bi >= 0; --bi) {
         if (by_bucket[bi].empty()) continue;
         Bucket bk;
         bk.chain = bi == kNumR;
         bk.R = bk.chain ? NRA_CHAIN_R : kRList[bi];
         bk.pair_off = pair_tasks.size();
-        bk.queue_off = queue_tasks.size();
         bk.jbwd_off = jbwd.size();
         bk.jlpk_off = jlpk.size(); bk.jrpk_off = jrpk.size();
         bk.probe_off = probe_tasks.size();
         const bool per_cell = b->brute || bk.chain;      // one DP per (read, cell) instead of the joint sweeps
-        const uint64_t slot = (uint64_t)NRA_JOINT_NSTATE(bk.R) * 64;
-        JointGroup g; g.R = bk.R; g.bucket = (int)b->buckets.size(); g.pre_off = jpre.size(); g.tail_off = jtail.size();
-        uint64_t used = 0, state_max = 0;
-        const size_t bucket_pre0 = jpre.size(), bucket_tail0 = jtail.size();
         for (int32_t r : by_bucket[bi]) {
             if (!per_cell) {
-                // one reverse sweep over R per read; one prefix sweep over L + u1^k1max per read that
-                // leaves the wave state at each of the read's k1 values; one tail sweep per run of cells
-                // with the same k1 and k2 in arithmetic progression (how the grid rounds list them)
+                // one reverse sweep over R per read and strand, kept for later cell lists of the batch
                 const int8_t given = read_strand ? read_strand[r] : 0;
                 const int32_t pi = b->jpair_of[r];
                 const NraJointPairTask& pair = b->jpairs[(size_t)pi];
@@ -1649,10 +1776,112 @@ int set_cells_common(nra_batch* b, const int8_t* read_strand, int64_t n_cells, c
                     b->rev_strand[r] = 0;
                     b->rev_pending.push_back({r, given});
                 }
+                // the L side up to the window: swept once per pair and strand, kept for later cell lists
+                if (b->jpack_l && (given == 0 || b->lst_strand[r] != given) && !pair_l[pi]) {
+                    pair_l[pi] = 1; jlpk.push_back(pair); bk.cells_sweep += (int64_t)2 * 64 * bk.R * colsL;
+                    for (int32_t q : {pair.read_a, pair.read_b}) {
+                        if (q < 0) continue;
+                        b->lst_strand[q] = 0;
+                        b->lst_pending.push_back({q, read_strand ? read_strand[q] : (int8_t)0});
+                    }
+                }
+            }
+            // strand probe against the read's first listed cell: half A = template, half B = its revcomp
+            if (!bk.chain) {
+                NraPairTask t{};
+                t.read = r; t.k1a = t.k1b = cell_k1[first[r]]; t.k2a = t.k2b = cell_k2[first[r]];
+                t.out_a = 2 * r; t.out_b = 2 * r + 1; t.flags = 3;     // B = reverse complement; raw scores
+                pair_tasks.push_back(t);
+                if (!b->all_strands_given)
+                    bk.cells_pair += 2 * sweep_cells(bk.R, d.l1 + d.m1 * t.k1a + d.l2 + d.m2 * t.k2a + d.l3);
+            } else {
+                // chained: the read and a reverse-complemented shadow of it against the same template
+                NraDevRead shadow = reads[r];
+                shadow.rc = 1;
+                const int32_t sh = (int32_t)reads.size();
+                reads.push_back(shadow);
+                probe_tasks.push_back(NraTask{r, cell_k1[first[r]], cell_k2[first[r]], 2 * r});
+                probe_tasks.push_back(NraTask{sh, cell_k1[first[r]], cell_k2[first[r]], 2 * r + 1});
+            }
+        }
+        bk.n_pair = (int)(pair_tasks.size() - bk.pair_off);
+        bk.n_jbwd = (int)(jbwd.size() - bk.jbwd_off);
+        bk.n_jlpk = (int)(jlpk.size() - bk.jlpk_off);
+        bk.n_jrpk = (int)(jrpk.size() - bk.jrpk_off);
+        bk.n_probe = (int)(probe_tasks.size() - bk.probe_off);
+        probe_count.push_back(bk.n_probe);
+        b->buckets.push_back(bk);
+        bucket_ids.push_back(bi);
+    }
+    const size_t nb = b->buckets.size();
+    // one chunk for everything but the wave states, which get their own (all of it reused by the next cell list)
+    b->cell_arena.expect(b->n_q2bit_words * 16 * 13 + (size_t)n_cells * 72 + pool.size() + (size_t)n_reads * 256 + (8u << 20));
+    HIP_TRY(b->pool.upload(pool));
+    HIP_TRY(b->regions.upload(dregs));
+    HIP_TRY(b->reads.upload(reads));
+    HIP_TRY(b->reads_init.upload(reads));
+    HIP_TRY(b->pair_tasks.upload(pair_tasks));
+    HIP_TRY(b->probe_tasks.upload(probe_tasks));
+    HIP_TRY(b->probe_count.upload(probe_count));
+    HIP_TRY(b->probe_dummy.alloc(2 * (size_t)n_reads));
+    HIP_TRY(b->probe_score.alloc(2 * (size_t)n_reads));
+    b->have_strand_in = read_strand != nullptr;
+    if (read_strand) {
+        std::vector<int8_t> v(read_strand, read_strand + n_reads);
+        HIP_TRY(b->strand_in.upload(v));
+    }
+    if (!chain_reads.empty()) {
+        size_t chain_cells = 0;
+        for (int32_t r : chain_reads) chain_cells += cnt[r];
+        b->chain_cap = (int)((tlmax + 127) / 64 * 64 + 64);
+        b->payload_strips = chain_strips(std::max(chain_cells, probe_tasks.size()), NRA_CHAIN_STRIPS,
+                                         (size_t)6 * 8 * (size_t)b->chain_cap);
+        HIP_TRY(b->chain_payload.alloc((size_t)b->payload_strips * 6 * (size_t)b->chain_cap));
+    }
+    if (!b->brute) {
+        HIP_TRY(b->jbwd_tasks.upload(jbwd));
+        HIP_TRY(b->jlpk_tasks.upload(jlpk));
+        HIP_TRY(b->jrpk_tasks.upload(jrpk));
+    }
+    // events and streams: kept from one cell list to the next, more taken from the pool when needed
+    auto ensure_handles = [&](size_t n_ev) -> int {
+        while (b->ev.size() < n_ev) { hipEvent_t e; HIP_TRY(g_handles.event(b->device, true, &e)); b->ev.push_back(e); }
+        // two streams per bucket: the buckets' chains overlap, and so do a bucket's reverse and prefix sweeps
+        while (b->bstreams.size() < 2 * nb) { hipStream_t q; HIP_TRY(g_handles.stream(b->device, &q)); b->bstreams.push_back(q); }
+        while (b->bdone.size() < 3 * nb) { hipEvent_t e; HIP_TRY(g_handles.event(b->device, false, &e)); b->bdone.push_back(e); }
+        return NRA_OK;
+    };
+    {
+        const int rc1 = ensure_handles(2 + 10 * nb + 2);
+        if (rc1) return rc1;
+    }
+    b->flanks_enqueued = false;
+    if (b->all_strands_given && !b->brute && n_cells > 0) {
+        const int rc1 = run_2d_flanks(b);
+        if (rc1) return rc1;
+    }
+    clk.mark("2D cells: strand-only sweeps built, uploaded, enqueued");
+
+    // ---- part 2: the sweeps that depend on the cell list
+    for (size_t bidx = 0; bidx < nb; ++bidx) {
+        const int bi = bucket_ids[bidx];
+        Bucket& bk = b->buckets[bidx];
+        bk.queue_off = queue_tasks.size();
+        const bool per_cell = b->brute || bk.chain;
+        const uint64_t slot = (uint64_t)NRA_JOINT_NSTATE(bk.R) * 64;
+        JointGroup g; g.R = bk.R; g.bucket = (int)bidx; g.pre_off = jpre.size(); g.tail_off = jtail.size();
+        uint64_t used = 0, state_max = 0;
+        const size_t bucket_pre0 = jpre.size(), bucket_tail0 = jtail.size();
+        for (int32_t r : by_bucket[bi]) {
+            if (!per_cell) {
+                // one prefix sweep over L + u1^k1max per read that leaves the wave state at each of the read's k1
+                // values; one tail sweep per run of cells with the same k1 and k2 in arithmetic progression (how
+                // the grid rounds list them)
+                const NraJointPairTask& pair = b->jpairs[(size_t)b->jpair_of[r]];
                 ks.clear();                                      // the read's distinct k1 values, ascending
                 if (grid) {
-                    const GridRow& g = grid->rows[(size_t)r];
-                    for (int32_t i = 0; i < g.n1; ++i) ks.push_back(g.k1lo + i * grid->step1);
+                    const GridRow& gr = grid->rows[(size_t)r];
+                    for (int32_t i = 0; i < gr.n1; ++i) ks.push_back(gr.k1lo + i * grid->step1);
                 } else {
                     ks.assign(cell_k1 + first[r], cell_k1 + first[r] + cnt[r]);
                     if (!std::is_sorted(ks.begin(), ks.end())) std::sort(ks.begin(), ks.end());
@@ -1666,26 +1895,15 @@ int set_cells_common(nra_batch* b, const int8_t* read_strand, int64_t n_cells, c
                 }
                 NraJointTask tp{}; tp.read = r; tp.k1_off = (int32_t)k1list.size(); tp.nk1 = (int32_t)ks.size();
                 tp.state = used; tp.k2step = 1;
-                if (b->jpack_l) {
-                    // the L side up to the window: swept once per pair and strand, kept for later cell lists
-                    tp.resume = 1; tp.pstate = pair.state; tp.phalf = pair.read_b == r ? 1 : 0;
-                    if ((given == 0 || b->lst_strand[r] != given) && !pair_l[pi]) {
-                        pair_l[pi] = 1; jlpk.push_back(pair); bk.cells_sweep += (int64_t)2 * 64 * bk.R * colsL;
-                        for (int32_t q : {pair.read_a, pair.read_b}) {
-                            if (q < 0) continue;
-                            b->lst_strand[q] = 0;
-                            b->lst_pending.push_back({q, read_strand ? read_strand[q] : (int8_t)0});
-                        }
-                    }
-                }
+                if (b->jpack_l) { tp.resume = 1; tp.pstate = pair.state; tp.phalf = pair.read_b == r ? 1 : 0; }
                 jpre.push_back(tp);
                 bk.cells_sweep += (int64_t)64 * bk.R * (d.l1 + d.m1 * ks.back() - 1 - (b->jpack_l ? colsL : 0));
                 if (grid) {
                     // one tail sweep per k1: the read's k2 values are one arithmetic progression
-                    const GridRow& g = grid->rows[(size_t)r];
-                    for (int32_t i = 0; i < g.n1; ++i) {
-                        NraJointTask t{}; t.read = r; t.k1 = ks[(size_t)i]; t.k2lo = g.k2lo; t.k2step = grid->step2; t.n2 = g.n2;
-                        t.out = (int32_t)(first[r] + (uint32_t)i * (uint32_t)g.n2);
+                    const GridRow& gr = grid->rows[(size_t)r];
+                    for (int32_t i = 0; i < gr.n1; ++i) {
+                        NraJointTask t{}; t.read = r; t.k1 = ks[(size_t)i]; t.k2lo = gr.k2lo; t.k2step = grid->step2; t.n2 = gr.n2;
+                        t.out = (int32_t)(first[r] + (uint32_t)i * (uint32_t)gr.n2);
                         t.state = used + slot * (uint64_t)i;
                         jtail.push_back(t);
                         bk.cells_sweep += joint_cells(bk.R, 1 + d.l2 + d.m2 * (t.k2lo + t.k2step * (t.n2 - 1)), reads[r].qlen);
@@ -1710,30 +1928,18 @@ int set_cells_common(nra_batch* b, const int8_t* read_strand, int64_t n_cells, c
                 used += slot * ks.size();
                 state_max = std::max(state_max, used);
             }
-            // strand probe against the read's first listed cell: half A = template, half B = its revcomp
-            if (!bk.chain) {
-                NraPairTask t{};
-                t.read = r; t.k1a = t.k1b = cell_k1[first[r]]; t.k2a = t.k2b = cell_k2[first[r]];
-                t.out_a = 2 * r; t.out_b = 2 * r + 1; t.flags = 3;     // B = reverse complement; raw scores
-                pair_tasks.push_back(t);
-                if (!b->all_strands_given)
-                    bk.cells_pair += 2 * sweep_cells(bk.R, d.l1 + d.m1 * t.k1a + d.l2 + d.m2 * t.k2a + d.l3);
-            } else {
-                // chained: the read and a reverse-complemented shadow of it against the same template
-                NraDevRead shadow = reads[r];
-                shadow.rc = 1;
-                const int32_t sh = (int32_t)reads.size();
-                reads.push_back(shadow);
-                probe_tasks.push_back(NraTask{r, cell_k1[first[r]], cell_k2[first[r]], 2 * r});
-                probe_tasks.push_back(NraTask{sh, cell_k1[first[r]], cell_k2[first[r]], 2 * r + 1});
-            }
-            for (uint32_t c = first[r]; c < first[r] + cnt[r]; ++c) {
-                const int tl = d.l1 + d.m1 * cell_k1[c] + d.l2 + d.m2 * cell_k2[c] + d.l3;
-                alg_cells += (int64_t)reads[r].qlen * tl;
-                if (per_cell) {
-                    queue_tasks.push_back(NraTask{r, cell_k1[c], cell_k2[c], (int32_t)c});
-                    bk.cells_queue += sweep_cells(bk.R, tl);
+            // algorithmic cells: the rectangle of every (read, cell) alignment
+            {
+                int64_t tl_sum = 0;
+                for (uint32_t c = first[r]; c < first[r] + cnt[r]; ++c) {
+                    const int tl = d.l1 + d.m1 * cell_k1[c] + d.l2 + d.m2 * cell_k2[c] + d.l3;
+                    tl_sum += tl;
+                    if (per_cell) {
+                        queue_tasks.push_back(NraTask{r, cell_k1[c], cell_k2[c], (int32_t)c});
+                        bk.cells_queue += sweep_cells(bk.R, tl);
+                    }
                 }
+                alg_cells += (int64_t)reads[r].qlen * tl_sum;
             }
         }
         if (!per_cell) {
@@ -1743,72 +1949,32 @@ int set_cells_common(nra_batch* b, const int8_t* read_strand, int64_t n_cells, c
             for (size_t i = bucket_tail0; i < jtail.size(); ++i) jtail[i].state += state_base;
             state_base += state_max;
         }
-        bk.n_pair = (int)(pair_tasks.size() - bk.pair_off);
         bk.n_queue = (int)(queue_tasks.size() - bk.queue_off);
-        bk.n_jbwd = (int)(jbwd.size() - bk.jbwd_off);
-        bk.n_jlpk = (int)(jlpk.size() - bk.jlpk_off);
-        bk.n_jrpk = (int)(jrpk.size() - bk.jrpk_off);
-        bk.n_probe = (int)(probe_tasks.size() - bk.probe_off);
         bk.queue_cap = (size_t)bk.n_queue;
         queue_count.push_back(bk.n_queue);
-        probe_count.push_back(bk.n_probe);
-        b->buckets.push_back(bk);
     }
-    const size_t nb = b->buckets.size();
 
-    clk.mark("2D cells: buckets, tasks");
-    // one chunk for everything but the wave states, which get their own (all of it reused by the next cell list)
-    b->cell_arena.expect(b->n_q2bit_words * 16 * 13 + (size_t)n_cells * 20 + pool.size() + (size_t)n_reads * 128 +
-                         (jbwd.size() + jpre.size() + jtail.size()) * sizeof(NraJointTask) + k1list.size() * 4 +
-                         (jlpk.size() + jrpk.size()) * sizeof(NraJointPairTask) +
-                         queue_tasks.size() * sizeof(NraTask) + (4u << 20));
-    HIP_TRY(b->pool.upload(pool));
-    HIP_TRY(b->regions.upload(dregs));
-    HIP_TRY(b->reads.upload(reads));
-    HIP_TRY(b->reads_init.upload(reads));
-    HIP_TRY(b->pair_tasks.upload(pair_tasks));
+    clk.mark("2D cells: prefix and tail sweeps built");
     HIP_TRY(b->queue_tasks.upload(queue_tasks));
     HIP_TRY(b->queue_count.upload(queue_count));
-    HIP_TRY(b->probe_tasks.upload(probe_tasks));
-    HIP_TRY(b->probe_count.upload(probe_count));
-    HIP_TRY(b->probe_dummy.alloc(2 * (size_t)n_reads));
-    if (!chain_reads.empty()) {
-        b->chain_cap = (int)((tlmax + 127) / 64 * 64 + 64);
-        b->payload_strips = chain_strips(std::max(queue_tasks.size(), probe_tasks.size()), NRA_CHAIN_STRIPS,
-                                         (size_t)6 * 8 * (size_t)b->chain_cap);
-        HIP_TRY(b->chain_payload.alloc((size_t)b->payload_strips * 6 * (size_t)b->chain_cap));
-    }
     if (!b->brute) {
-        HIP_TRY(b->jbwd_tasks.upload(jbwd));
         HIP_TRY(b->jpre_tasks.upload(jpre));
         HIP_TRY(b->jtail_tasks.upload(jtail));
-        HIP_TRY(b->jlpk_tasks.upload(jlpk));
-        HIP_TRY(b->jrpk_tasks.upload(jrpk));
         HIP_TRY(b->jk1list.upload(k1list));
         HIP_TRY(b->jstate.alloc((size_t)state_base));
     }
-    HIP_TRY(b->probe_score.alloc(2 * (size_t)n_reads));
     {
         std::vector<int32_t> v(cell_k1, cell_k1 + n_cells); HIP_TRY(b->cell_k1.upload(v));
         std::vector<int32_t> w(cell_k2, cell_k2 + n_cells); HIP_TRY(b->cell_k2.upload(w));
     }
     HIP_TRY(b->cell_first.upload(first));
     HIP_TRY(b->cell_cnt.upload(cnt));
-    b->have_strand_in = read_strand != nullptr;
-    if (read_strand) {
-        std::vector<int8_t> v(read_strand, read_strand + n_reads);
-        HIP_TRY(b->strand_in.upload(v));
-    }
     HIP_TRY(b->cand_score.alloc((size_t)n_cells));     // cell_score
     HIP_TRY(b->cand_tstart.alloc((size_t)n_cells));    // cell_wscore
     clk.mark("2D cells: device buffers, H2D");
-    // events and streams: kept from one cell list to the next, more taken from the pool when needed
     {
-        const size_t n_ev = 2 + 10 * nb + 4 * b->jgroups.size() + 2;
-        while (b->ev.size() < n_ev) { hipEvent_t e; HIP_TRY(g_handles.event(b->device, true, &e)); b->ev.push_back(e); }
-        // two streams per bucket: the buckets' chains overlap, and so do a bucket's reverse and prefix sweeps
-        while (b->bstreams.size() < 2 * nb) { hipStream_t q; HIP_TRY(g_handles.stream(b->device, &q)); b->bstreams.push_back(q); }
-        while (b->bdone.size() < 3 * nb) { hipEvent_t e; HIP_TRY(g_handles.event(b->device, false, &e)); b->bdone.push_back(e); }
+        const int rc1 = ensure_handles(2 + 10 * nb + 4 * b->jgroups.size() + 2);
+        if (rc1) return rc1;
     }
 
     b->stats.n_alignments = n_cells;
@@ -1855,19 +2021,25 @@ int nra_batch2d_create(int device, const nra_joint_region_t* reg, int32_t n_read
     return NRA_OK;
 }
 
-static int run_2d(nra_batch* b)
+}  // extern "C"
+
+namespace {
+
+// The kernels of a 2D run come in two parts.  Part 1 -- strand probes, strand choice, and per bucket the packed
+// sweeps of the flanks outside the scoring window and the reverse sweeps over R -- depends on the reads and their
+// strands only; nra_batch2d_set_cells / _set_grid enqueue it themselves when every strand is given, before they
+// build the rest of the cell list's tasks.  Part 2 -- prefix sweeps, tail sweeps, per-cell payload launches,
+// the selector -- is enqueued by nra_batch_run.
+int run_2d_flanks(nra_batch* b)
 {
     hipStream_t st = b->stream;
     const size_t nb = b->buckets.size();
-    const size_t nc = std::max<size_t>((size_t)b->n_cands, 1), nr = std::max<size_t>((size_t)b->n_reads, 1);
+    const size_t nr = std::max<size_t>((size_t)b->n_reads, 1);
     HIP_TRY(hipEventRecord(b->ev[0], st));
     HIP_TRY(hipMemcpyAsync(b->reads.p, b->reads_init.p, nr * sizeof(NraDevRead), hipMemcpyDeviceToDevice, st));
-    HIP_TRY(hipMemsetAsync(b->cand_score.p, 0xff, nc * 4, st));
-    HIP_TRY(hipMemsetAsync(b->cand_tstart.p, 0, nc * 4, st));
     HIP_TRY(hipMemsetAsync(b->probe_score.p, 0xff, 2 * nr * 4, st));
     int ev = 2;
     b->n_score_ev = 0; b->n_ext_ev = 0;
-    const int max_waves = 256 * 16;
     if (!b->all_strands_given) {
         HIP_TRY(hipEventRecord(b->fork_ev, st));
         for (size_t i = 0; i < nb; ++i) {
@@ -1896,24 +2068,8 @@ static int run_2d(nra_batch* b)
     LAUNCH_TRY(nra_launch_pick_strand(st, b->n_reads, b->probe_score.p,
                                       b->have_strand_in ? b->strand_in.p : nullptr, b->strand_out.p, b->reads.p));
     HIP_TRY(hipEventRecord(b->phase_ev[0], st));
-    // buckets scored cell by cell: all of them in brute-force mode, else the chained (long) reads only
-    for (size_t i = 0; i < nb; ++i) {
-        const Bucket& bk = b->buckets[i];
-        if (!b->brute && !bk.chain) continue;
-        HIP_TRY(hipEventRecord(b->ev[ev++], st));
-        LAUNCH_TRY(nra_launch_payload_window(bk.R, b->has_n, st, std::min(bk.n_queue, bk.chain ? b->payload_strips : max_waves),
-                                          b->queue_tasks.p + bk.queue_off, b->queue_count.p + i,
-                                          b->reads.p, b->regions.p, b->pool.p,
-                                          b->q2bit.p, b->qnmask.p, b->sp, b->cand_score.p,
-                                          b->cand_tstart.p, nullptr, bk.chain ? b->chain_payload.p : nullptr,
-                                          bk.chain ? b->chain_cap : 0, bk.chain ? 1 : 0));
-        HIP_TRY(hipEventRecord(b->ev[ev++], st));
-        b->n_score_ev++;
-    }
     if (!b->brute) {
-        // junction decomposition: reverse sweeps over R (one per read); then, group by group, the
-        // prefix sweeps (one per read) that leave the wave states and the tail sweeps (one per
-        // (read, k1) run of cells) that resume from them
+        // reverse sweeps over R (one per read) and the packed sweeps of both flanks (one per pair of reads)
         HIP_TRY(hipEventRecord(b->fork2_ev, st));
         for (size_t i = 0; i < nb; ++i) {
             const Bucket& bk = b->buckets[i];
@@ -1942,7 +2098,51 @@ static int run_2d(nra_batch* b)
             HIP_TRY(hipEventRecord(b->ev[ev++], qa));
             b->n_score_ev++;
             HIP_TRY(hipEventRecord(b->bdone[3 * i], qa));
+        }
+    }
+    b->ev_next = ev;
+    b->flanks_enqueued = true;
+    return NRA_OK;
+}
+
+int run_2d(nra_batch* b)
+{
+    if (!b->flanks_enqueued) {
+        const int rc = run_2d_flanks(b);
+        if (rc) return rc;
+    }
+    b->flanks_enqueued = false;          // (a second nra_batch_run of the same cell list starts over)
+    hipStream_t st = b->stream;
+    const size_t nb = b->buckets.size();
+    const size_t nc = std::max<size_t>((size_t)b->n_cands, 1);
+    int ev = b->ev_next;
+    const int max_waves = 256 * 16;
+    HIP_TRY(hipMemsetAsync(b->cand_score.p, 0xff, nc * 4, st));
+    HIP_TRY(hipMemsetAsync(b->cand_tstart.p, 0, nc * 4, st));
+    HIP_TRY(hipEventRecord(b->fork_ev, st));               // the cell arrays are cleared (the tails write them)
+    // buckets scored cell by cell: all of them in brute-force mode, else the chained (long) reads only
+    for (size_t i = 0; i < nb; ++i) {
+        const Bucket& bk = b->buckets[i];
+        if (!b->brute && !bk.chain) continue;
+        HIP_TRY(hipEventRecord(b->ev[ev++], st));
+        LAUNCH_TRY(nra_launch_payload_window(bk.R, b->has_n, st, std::min(bk.n_queue, bk.chain ? b->payload_strips : max_waves),
+                                          b->queue_tasks.p + bk.queue_off, b->queue_count.p + i,
+                                          b->reads.p, b->regions.p, b->pool.p,
+                                          b->q2bit.p, b->qnmask.p, b->sp, b->cand_score.p,
+                                          b->cand_tstart.p, nullptr, bk.chain ? b->chain_payload.p : nullptr,
+                                          bk.chain ? b->chain_cap : 0, bk.chain ? 1 : 0));
+        HIP_TRY(hipEventRecord(b->ev[ev++], st));
+        b->n_score_ev++;
+    }
+    if (!b->brute) {
+        // group by group, the prefix sweeps (one per read) that leave the wave states and the tail sweeps (one
+        // per (read, k1) run of cells) that resume from them
+        for (size_t i = 0; i < nb; ++i) {
+            const Bucket& bk = b->buckets[i];
+            if (bk.chain) continue;
+            hipStream_t qb = b->bstreams[2 * i + 1];
             HIP_TRY(hipStreamWaitEvent(st, b->bdone[3 * i], 0));
+            HIP_TRY(hipStreamWaitEvent(qb, b->fork_ev, 0));
             bool first = true;
             for (const JointGroup& g : b->jgroups) {
                 if (g.bucket != (int)i) continue;
@@ -1979,6 +2179,10 @@ static int run_2d(nra_batch* b)
     HIP_TRY(hipEventRecord(b->ev[1], st));
     return NRA_OK;
 }
+
+}  // namespace
+
+extern "C" {
 
 int nra_batch2d_fetch(nra_batch_t* b, int8_t* read_strand, int32_t* cell_score, int32_t* cell_wscore,
                       int32_t* best_wscore, int64_t* sum_k1, int64_t* sum_k2, int32_t* n_ties, uint8_t* status)
@@ -2337,7 +2541,9 @@ int nra_batch_sync(nra_batch_t* b)
     if (!b) return fail(NRA_E_ARG, "batch is NULL");
     HIP_TRY(hipSetDevice(b->device));
     HIP_TRY(hipStreamSynchronize(b->stream));
-    return account_run(b);
+    const int rc = account_run(b);
+    if (rc || b->kind != 1) return rc;
+    return check_mt(b);
 }
 
 int nra_batch_stats(nra_batch_t* b, nra_stats_t* st)

@@ -50,6 +50,21 @@ struct NraSweepTask {
     int32_t read_c, read_d;   // k_sweep_ring32: the second pair of the wave (lanes 32..63); < 0: none
 };
 
+// R side of the junction as the half-wave kernel (k_sweep_ring32) keeps it: lane-major, [lane][H - o1 | E_in | E2_in][row],
+// NRA_SNAP_LANE_STRIDE(R) dwords per lane (a multiple of 4: a lane stores its rows as 16-byte pieces, all in the one
+// step it spends on the snapshot column, so every 64-byte sector it touches is complete when it leaves the wave; with
+// the [row][lane] planes of the full-wave kernels two lanes per step add 4 bytes each to 128-byte lines that take 32
+// steps to fill, and the half-wave kernel's WRITE_SIZE came to 2.6 x the bytes stored)
+#define NRA_SNAP_LANE_STRIDE(R) ((3 * (R) + 3) / 4 * 4)
+
+// One (task, row block) of the chained sweeps with concurrent blocks (k_sweep_ringmt): waves take these by ticket,
+// in list order -- a producer (block b) precedes its consumer (block b + 1).
+struct NraChainBlock {
+    int32_t task;                  // index into the launch's sweep tasks
+    int32_t blk, nblk;
+    int32_t strip_in, strip_out;   // strips (5 planes of chain_cap 8-byte granules each) above / below the block; -1: none
+};
+
 // Tasks of the joint sweeps (nra_joint.hip).
 //   tail sweep: one (read, k1) row of the 2D grid -- the read's cells with this k1 are
 //     k2 = k2lo + n*k2step, n < n2, and sit at out + n in the cell arrays; `state` = where the
@@ -215,6 +230,11 @@ int nra_launch_sweep_ring32_fwd(int R, int has_n, hipStream_t st, int n_tasks, c
 #define NRA_RING_CHAIN_R 20
 #define NRA_RING_CHAIN_MIN_ROWS NRA_MAX_QLEN_1BLOCK   // shorter reads stay unchained: a block costs a pipeline fill and half a block of padding
 #define NRA_RING_CHAIN_STRIPS 4096
+// rows per lane of the chained sweeps whose row blocks run as concurrent waves (k_sweep_ringmt): 15 keeps the forward
+// sweep within the 168 registers of three waves per SIMD (20: two)
+#ifndef NRA_RING_MT_R
+#define NRA_RING_MT_R 15
+#endif
 int nra_launch_sweep_ringchain_bwd(int R, int has_n, int wide, hipStream_t st, int n_tasks,
                                    const NraSweepTask* tasks, const NraDevRead* reads,
                                    const NraDevRegion* regions, const uint8_t* pool,
@@ -228,6 +248,24 @@ int nra_launch_sweep_ringchain_fwd(int R, int has_n, int wide, hipStream_t st, i
                                    const int32_t* kmin, const int32_t* kmax, const uint32_t* coff,
                                    int32_t* snap, int32_t* read_a, int32_t* cand_score, uint8_t* cand_flag,
                                    int32_t* chain_buf, int chain_cap, int n_strips);
+
+// chained LDS-ring sweeps with the row blocks of a read as concurrent waves (k_sweep_ringmt).  `ticket`: one int32
+// (zeroed by the launcher); `strips`: n strips x 5 x chain_cap granules, zeroed once; `epoch`: unique per launch,
+// never 0; `error`: launch-wide give-up word (zeroed by the host before the run, read back after it)
+int nra_launch_sweep_ringmt_bwd(int R, int has_n, int wide, hipStream_t st, int n_blocks,
+                                const NraChainBlock* blocks, int32_t* ticket, const NraSweepTask* tasks,
+                                const NraDevRead* reads, const NraDevRegion* regions, const uint8_t* pool,
+                                const uint32_t* q2bit, const uint32_t* qnmask, NraScoreParams sp,
+                                const int32_t* kmin, const int32_t* kmax, const uint32_t* coff,
+                                int32_t* snap, int32_t* read_a, uint64_t* strips, int chain_cap,
+                                uint32_t epoch, int32_t* error);
+int nra_launch_sweep_ringmt_fwd(int R, int has_n, int wide, hipStream_t st, int n_blocks,
+                                const NraChainBlock* blocks, int32_t* ticket, const NraSweepTask* tasks,
+                                const NraDevRead* reads, const NraDevRegion* regions, const uint8_t* pool,
+                                const uint32_t* q2bit, const uint32_t* qnmask, NraScoreParams sp,
+                                const int32_t* kmin, const int32_t* kmax, const uint32_t* coff,
+                                int32_t* snap, int32_t* read_a, int32_t* cand_score, uint8_t* cand_flag,
+                                uint64_t* strips, int chain_cap, uint32_t epoch, int32_t* error);
 
 // 2D junction decomposition (nra_joint.hip)
 int nra_launch_joint_bwd(int R, int has_n, hipStream_t st, int n_tasks, const NraJointTask* tasks,

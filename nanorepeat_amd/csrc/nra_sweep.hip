@@ -111,6 +111,20 @@ __device__ __forceinline__ void sweep_snapshot(const int (&Hq)[R], const int (&E
     }
 }
 
+// The same for the half-wave kernel: lane-major (NRA_SNAP_LANE_STRIDE), p = the lane's own piece, 16-byte aligned.
+template <int R>
+__device__ __forceinline__ void sweep_snapshot_lane(const int (&Hq)[R], const int (&E)[R], const int (&E2)[R],
+                                                    int32_t* __restrict__ p)
+{
+    constexpr int N4 = NRA_SNAP_LANE_STRIDE(R) / 4;
+    int v[4 * N4];
+#pragma unroll
+    for (int i = 0; i < 4 * N4; ++i) v[i] = i < R ? Hq[i] : i < 2 * R ? E[i - R] : i < 3 * R ? E2[i - 2 * R] : 0;
+    int4* __restrict__ p4 = reinterpret_cast<int4*>(p);
+#pragma unroll
+    for (int i = 0; i < N4; ++i) p4[i] = make_int4(v[4 * i], v[4 * i + 1], v[4 * i + 2], v[4 * i + 3]);
+}
+
 // CHAIN = the WIDE sweeps: reads longer than one register block (3072 bases) are swept as consecutive row
 // blocks of 64*R rows by one wave, ONE read per wave in plain int32 cells (2*score + origin bit: no range
 // limit worth naming), the last cell of a block leaving its per-column hand-off in a scratch strip that
@@ -741,8 +755,8 @@ __global__ __launch_bounds__(WAVE) void k_sweep_ring32(int n_tasks, const NraSwe
                 const int a = (s ? rdb.qlen : rda.qlen) - 2 - r;
                 if (a >= 0) {
                     const int al = a / R, ai = a - al * R;      // reverse-sweep row a sits in lane al of this half
-                    const int32_t* __restrict__ p = snap_task + (size_t)ai * 64 + hoff + al;
-                    const int vh = p[0], ve = p[R * 64], ve2 = p[2 * R * 64];
+                    const int32_t* __restrict__ p = snap_task + (size_t)(hoff + al) * NRA_SNAP_LANE_STRIDE(R) + ai;
+                    const int vh = p[0], ve = p[R], ve2 = p[2 * R];
                     h[s] = (s ? half_hi(vh) : half_lo(vh)) + 2 * o1;
                     e[s] = (s ? half_hi(ve) : half_lo(ve)) + q1;
                     e2[s] = (s ? half_hi(ve2) : half_lo(ve2)) + q2;
@@ -790,7 +804,7 @@ __global__ __launch_bounds__(WAVE) void k_sweep_ring32(int n_tasks, const NraSwe
         if (++slot == skew) slot = 0;
 
         if constexpr (DIR == 0) {
-            if (tt & FLAG_SNAPSHOT) sweep_snapshot<0, R, R>(Hq, E, E2, snap_task, lane);
+            if (tt & FLAG_SNAPSHOT) sweep_snapshot_lane<R>(Hq, E, E2, snap_task + (size_t)lane * NRA_SNAP_LANE_STRIDE(R));
         } else {
             if (pcnt == phase && step >= jfirst) {          // every lane is on a unit boundary: wave-uniform
                 const int tS = sweep_combine<0, R, R>(Hq, E, E2, Hbo, Ebo, E2bo, NEG2);
@@ -1078,6 +1092,302 @@ __global__ __launch_bounds__(WAVE) void k_sweep_ringchain(int n_tasks, const Nra
 }
 
 // ------------------------------------------------------------------------------------
+// k_sweep_ringmt: the chained LDS-ring sweep with the row blocks of a read as CONCURRENT waves.
+//
+// k_sweep_ringchain runs the blocks of a task one after the other in one wave: a batch of few long reads (2000
+// cores of 3.7 kb = 1000 tasks of three blocks) then has one wave per SIMD.  Here a wave is one (task, row block):
+// block b+1 starts as soon as block b has published the columns it needs and follows 64 * (skew + 1) steps behind,
+// so the blocks of a read overlap and the launch has (blocks per read) times the waves.
+//
+// Hand-off (cdna_hip_programming.md Guideline 16, R2: the data is the flag): what lane 63 of block b leaves per
+// column -- H of the block's last row, the two vertical-gap states and, on boundary columns, the S and B
+// accumulators -- is stored as 8-byte granules {epoch, value}, ONE agent-scope (sc1, write-through) store each, into
+// the strip between the two blocks; block b+1 loads the granules of the 64 columns it is about to hand to its
+// lane 0 with agent-scope (sc1) loads and polls until every tag carries this launch's epoch.  No fence, no flag;
+// the strips are zeroed once when the batch is created and every launch has an epoch of its own (never 0), so a
+// granule of an earlier launch or run never passes.
+//
+// No deadlock, whatever the dispatch order: a wave takes its (task, block) by TICKET -- one atomic add when it
+// starts -- and the block list is ordered so that a producer precedes its consumer (all blocks 0, then all blocks 1,
+// ...).  Whoever holds a ticket runs; every smaller ticket was taken by a wave that has started, so the producer a
+// wave waits for is running or done and never waits for a larger ticket.  Spins sleep (s_sleep), are bounded, and
+// watch a launch-wide error word: a wave that gives up sets it, the others leave, the host reports NRA_E_DEVICE.
+typedef unsigned long long nra_u64;
+typedef __attribute__((address_space(1))) nra_u64 nra_gu64;
+typedef __attribute__((address_space(1))) int nra_gi32;
+#define NRA_MT_SPIN_LIMIT (1u << 24)        // polls of ~1 us each before a wave gives up (a hang guard, not a path)
+
+template <int R, bool HAS_N, int DIR, bool W>
+__global__ __launch_bounds__(WAVE, 3) void k_sweep_ringmt(int n_blocks, const NraChainBlock* __restrict__ blocks,
+                                                       int32_t* ticket, const NraSweepTask* __restrict__ tasks,
+                                                       const NraDevRead* __restrict__ reads,
+                                                       const NraDevRegion* __restrict__ regions,
+                                                       const uint8_t* __restrict__ pool,
+                                                       const uint32_t* __restrict__ q2bit,
+                                                       const uint32_t* __restrict__ qnmask,
+                                                       NraScoreParams sp,
+                                                       const int32_t* __restrict__ kmin_arr,
+                                                       const int32_t* __restrict__ kmax_arr,
+                                                       const uint32_t* __restrict__ coff,
+                                                       int32_t* __restrict__ snap,
+                                                       int32_t* read_a,
+                                                       int32_t* __restrict__ cand_score,
+                                                       uint8_t* __restrict__ cand_flag,
+                                                       nra_u64* strips, int chain_cap, uint32_t epoch, int32_t* error)
+{
+    constexpr int SC = 2;
+    constexpr int BIASW = W ? 0 : BIAS;
+    __shared__ int4 ring[SWEEP_RING_D * 64];
+    __shared__ int2 racc[64];
+    const int lane = threadIdx.x;
+    const int wr = (lane + 1) & 63;
+    int my = 0;
+    if (lane == 0) my = atomicAdd(ticket, 1);
+    my = __builtin_amdgcn_readfirstlane(my);
+    if (my >= n_blocks) return;
+    const NraChainBlock cb = blocks[my];
+    const NraSweepTask tk = tasks[cb.task];
+    const int blk = cb.blk;
+    const bool first_blk = blk == 0, last_blk = blk == cb.nblk - 1;
+    nra_gu64* cin = (nra_gu64*)(strips + (size_t)(first_blk ? 0 : cb.strip_in) * 5 * (size_t)chain_cap);
+    nra_gu64* cout = (nra_gu64*)(strips + (size_t)(last_blk ? 0 : cb.strip_out) * 5 * (size_t)chain_cap);
+    nra_gi32* err = (nra_gi32*)error;
+    const nra_u64 tag = (nra_u64)epoch << 32;
+
+    const bool has_b = !W && tk.read_b >= 0;
+    const int ra = tk.read_a, rb = has_b ? tk.read_b : tk.read_a;
+    const NraDevRead rda = reads[ra], rdb = reads[rb];
+    const NraDevRegion rg = regions[rda.region];
+    const int m = rg.m1;
+    const int flank = DIR ? rg.l1 : rg.l3;
+    const uint8_t* __restrict__ piece = pool + (DIR ? rg.p1_off : rg.pr_off);
+    const int ncols = DIR ? flank + m * tk.kmax : flank;
+    const int jfirst = DIR ? flank + m * tk.kmin - 1 : flank - 1;
+    const int skew = DIR ? m : 1;
+    const int kmin_a = kmin_arr[ra], kmax_a = kmax_arr[ra];
+    const int kmin_b = kmin_arr[rb], kmax_b = kmax_arr[rb];
+    const uint32_t coff_a = coff[ra], coff_b = coff[rb];
+    int32_t* __restrict__ snap_task = snap + tk.snap_off;
+
+    const int o1 = SC * sp.open1, o2 = SC * sp.open2;
+    const int P1 = W ? 1 : 0x00010001;
+    const int v_floor = (BIASW - o1) * P1;
+    const int v_o1 = o1 * P1, v_e1 = SC * sp.ext1 * P1, v_o2 = o2 * P1, v_e2 = SC * sp.ext2 * P1;
+    const int NEG1 = W ? -(1 << 28) : NEGB * P1;
+    const int NEG2 = W ? -(1 << 28) : 2 * NEGB * P1;
+    const int s_match = SC * sp.match + o1, s_mis = o1 - SC * sp.mismatch, s_ambi = o1 - SC * sp.ambi;
+    const int tbl_hi = s_mis | (s_ambi << 8);
+    const int tbl_mis4 = s_mis * 0x01010101, tbl_ambi4 = s_ambi * 0x01010101;
+
+    auto column_table = [&](int col) {
+        int t = tbl_mis4;
+        if (col >= 0 && col < ncols) {
+            const int code = piece[col];
+            t = code < 4 ? tbl_mis4 + ((s_match - s_mis) << (8 * code)) : tbl_ambi4;
+            if (DIR == 0 && col == flank - 1) t |= FLAG_SNAPSHOT;
+            if (DIR == 1 && col + 1 >= flank) t |= FLAG_INREP;     // origin bit of an alignment starting at the NEXT column
+        }
+        return t;
+    };
+
+    // What enters row 0 of this block at template column `col` (each lane its own column): constants for the
+    // first block and outside the template, else the granules the block above has published -- polled until they
+    // carry this launch's epoch.  Wave-uniform control flow; returns false when the launch has failed.
+    auto fetch = [&](int col, int& h, int& f, int& f2, int& s2, int& b2) -> bool {
+        h = v_floor; f = NEG1; f2 = NEG1; s2 = NEG2; b2 = NEG1;
+        const bool mine = !first_blk && col >= 0 && col < ncols;
+        const bool at_boundary = DIR == 1 && mine && col >= jfirst && (col - jfirst) % m == 0;
+        if (first_blk) return true;
+        const nra_gu64* g = cin + (mine ? col : 0);
+        for (unsigned spins = 0;; ++spins) {
+            bool ok = true;
+            if (mine) {
+                const nra_u64 x0 = __hip_atomic_load(g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                const nra_u64 x1 = __hip_atomic_load(g + chain_cap, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                const nra_u64 x2 = __hip_atomic_load(g + 2 * (size_t)chain_cap, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                ok = (x0 >> 32) == epoch && (x1 >> 32) == epoch && (x2 >> 32) == epoch;
+                h = (int)(unsigned)x0; f = (int)(unsigned)x1; f2 = (int)(unsigned)x2;
+                if (at_boundary) {
+                    const nra_u64 x3 = __hip_atomic_load(g + 3 * (size_t)chain_cap, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    const nra_u64 x4 = __hip_atomic_load(g + 4 * (size_t)chain_cap, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    ok = ok && (x3 >> 32) == epoch && (x4 >> 32) == epoch;
+                    s2 = (int)(unsigned)x3; b2 = (int)(unsigned)x4;
+                }
+            }
+            if (__builtin_amdgcn_ballot_w64(!ok) == 0) return true;
+            __builtin_amdgcn_s_sleep(32);
+            if ((spins & 15) == 15) {
+                int failed = 0;
+                if (lane == 0) failed = __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (__builtin_amdgcn_readfirstlane(failed) != 0) return false;
+                if (spins >= NRA_MT_SPIN_LIMIT) {
+                    if (lane == 0) __hip_atomic_store(err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    return false;
+                }
+            }
+        }
+    };
+    auto publish = [&](int plane, int col, int v) {
+        __hip_atomic_store(cout + (size_t)plane * chain_cap + col, tag | (nra_u64)(unsigned)v, __ATOMIC_RELAXED,
+                           __HIP_MEMORY_SCOPE_AGENT);
+    };
+
+    int out_a = 0, out_b = 0;
+    int n_out = 0, kcur = tk.kmin;                          // wave-uniform
+    auto flush = [&](int n_valid) {
+        const int k = kcur - 64 + lane;
+        if (lane < 64 - n_valid) return;
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2) {
+            if (s2 == 1 && !has_b) break;
+            const int lo_k = s2 ? kmin_b : kmin_a, hi_k = s2 ? kmax_b : kmax_a;
+            if (k < lo_k || k > hi_k) continue;
+            const uint32_t idx = (s2 ? coff_b : coff_a) + (uint32_t)(k - lo_k);
+            const int v = s2 ? out_b : out_a;
+            cand_score[idx] = v >> 2;
+            cand_flag[idx] = (uint8_t)(v & 3);
+        }
+    };
+    const int a_of_a = DIR ? read_a[ra] : 0, a_of_b = DIR ? read_a[rb] : 0;
+
+    const int nsteps = ncols + 63 * skew;
+    const int row_base = blk * 64 * R;
+
+    int qc[R];
+#pragma unroll
+    for (int i = 0; i < R; ++i) {
+        const int gi = row_base + lane * R + i;
+        const int ca = sweep_query_sel<HAS_N>(rda, q2bit, qnmask, gi, DIR == 0);
+        const int cb2 = W ? 0x0c : sweep_query_sel<HAS_N>(rdb, q2bit, qnmask, gi, DIR == 0);
+        qc[i] = ca | (0x0c << 8) | (cb2 << 16) | (0x0c << 24);
+    }
+    int Hbo[DIR ? R : 1], Ebo[DIR ? R : 1], E2bo[DIR ? R : 1];
+    if (DIR) {
+        const int q1 = SC * (sp.open1 - sp.ext1), q2 = SC * (sp.open2 - sp.ext2);
+#pragma unroll
+        for (int i = 0; i < R; ++i) {
+            const int r = row_base + lane * R + i;
+            int h[2], e[2], e2[2];
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+                const int a = (s ? rdb.qlen : rda.qlen) - 2 - r;
+                if (a >= 0) {
+                    const int ablk = a / (64 * R);
+                    const int w = a - ablk * 64 * R;
+                    const int al = w / R, ai = w - al * R;
+                    const int32_t* __restrict__ p = snap_task + ((size_t)ablk * 3 * R + ai) * 64 + al;
+                    const int vh = p[0], ve = p[R * 64], ve2 = p[2 * R * 64];
+                    h[s] = (W ? vh : (s ? half_hi(vh) : half_lo(vh))) + 2 * o1;
+                    e[s] = (W ? ve : (s ? half_hi(ve) : half_lo(ve))) + q1;
+                    e2[s] = (W ? ve2 : (s ? half_hi(ve2) : half_lo(ve2))) + q2;
+                } else { h[s] = BIASW + o1 - SC; e[s] = BIASW - SC; e2[s] = BIASW - SC; }
+            }
+            Hbo[i] = W ? h[0] : pack2(h[0], h[1]);
+            Ebo[i] = W ? e[0] : pack2(e[0], e[1]);
+            E2bo[i] = W ? e2[0] : pack2(e2[0], e2[1]);
+        }
+    }
+    int Hq[R], Hq2[R], E[R], E2[R];
+#pragma unroll
+    for (int i = 0; i < R; ++i) { Hq[i] = v_floor; Hq2[i] = NEG1; E[i] = NEG1; E2[i] = NEG1; }
+
+    // ring: padding columns everywhere, then lane 0's first `skew` columns (and, when the first boundary is one
+    // of them, its accumulators; a later first boundary gets them from lane 63 one boundary phase ahead, below)
+#pragma unroll
+    for (int s = 0; s < SWEEP_RING_D; ++s) ring[s * 64 + lane] = make_int4(v_floor, NEG1, NEG1, tbl_mis4);
+    racc[lane] = make_int2(NEG2, NEG1);
+    int feed = tbl_mis4, sH, sF, sF2, sS, sB;   // what lane 63 hands to lane 0
+    if (!fetch(lane < skew ? lane : -1, sH, sF, sF2, sS, sB)) return;
+    if (lane < skew) ring[lane * 64] = make_int4(sH, sF, sF2, column_table(lane));
+    if (DIR == 1 && lane == jfirst && jfirst < skew) racc[0] = make_int2(sS, sB);
+    ring_order();
+
+    int Hup_prev = v_floor, M = BIASW * P1;
+    int slot = 0;
+    int phase = jfirst % m, pcnt = 0, bidx = 0;
+#pragma unroll 1
+    for (int step = 0; step < nsteps; ++step) {
+        if ((step & 63) == 0) {                                            // columns step + skew + (0..63)
+            const int col = step + skew + wr;
+            feed = column_table(col);
+            if (!fetch(col, sH, sF, sF2, sS, sB)) return;
+        }
+        const int4 in = ring[slot * 64 + lane];
+        const int tt = in.w;
+        const int fl = DIR == 1 ? (int)((((unsigned)tt >> 15) & (unsigned)P1) | (unsigned)(BIASW * P1)) : BIASW * P1;   // as in k_sweep_ring
+        int F = mx2<W>(in.y, fl), F2 = in.z;
+        sweep_cell<0, R, R, W, true>(Hq, Hq2, E, E2, qc, Hup_prev, F, F2, M, tt & 0x7f7f7f7f, tbl_hi, fl, v_e1, v_e2, v_o1, v_o2);
+        Hup_prev = mx2<W>(in.x, fl - v_o1);
+        ring[slot * 64 + wr] = make_int4(Hq[R - 1], F, F2, tt);
+        if (lane == 63) ring[slot * 64] = make_int4(sH, sF, sF2, feed);
+        ring_order();                                       // the next steps' loads stay behind these stores
+        const int c63 = step - 63 * skew;                                  // the column lane 63 has just finished
+        if (lane == 63 && !last_blk && c63 >= 0) { publish(0, c63, Hq[R - 1]); publish(1, c63, F); publish(2, c63, F2); }
+        feed = dpp_rol1(feed); sH = dpp_rol1(sH); sF = dpp_rol1(sF); sF2 = dpp_rol1(sF2);
+        if (++slot == skew) slot = 0;
+
+        if constexpr (DIR == 0) {
+            if (tt & FLAG_SNAPSHOT) sweep_snapshot<0, R, R>(Hq, E, E2, snap_task + (size_t)blk * 3 * R * 64, lane);
+        } else {
+            if (pcnt == phase) {                                           // wave-uniform
+                if (step >= jfirst) {                                      // every lane on a unit boundary
+                    const int tS = sweep_combine<0, R, R, W>(Hq, E, E2, Hbo, Ebo, E2bo, NEG2);
+                    const int2 acc = racc[lane];
+                    const int accS = mx2<W>(acc.x, tS), accB = mx2<W>(acc.y, M);
+                    racc[wr] = make_int2(accS, accB);
+                    if (lane == 63) {
+                        racc[0] = make_int2(sS, sB);                       // of column step + skew: lane 0's next boundary
+                        if (!last_blk && c63 >= 0) { publish(3, c63, accS); publish(4, c63, accB); }
+                    }
+                    ring_order();
+                    if (last_blk && bidx >= 63 && kcur <= tk.kmax) {       // lane 63 is on the boundary of k = kcur
+                        int va = 0, vb = 0;
+                        if (lane == 63) {
+#pragma unroll
+                            for (int s2 = 0; s2 < (W ? 1 : 2); ++s2) {
+                                const int B = (W ? accB : (s2 ? half_hi(accB) : half_lo(accB))) - BIASW;
+                                const int S = (W ? accS : (s2 ? half_hi(accS) : half_lo(accS))) - 2 * BIASW;
+                                const int lo = sp.min_score > 1 ? sp.min_score : 1;
+                                const int V = imax(imax(S, B), (s2 ? a_of_b : a_of_a) + 1);
+                                const int best = V >> 1;
+                                int flag = 1;
+                                if (V & 1) flag = 0;
+                                else if ((B >> 1) >= best) flag = ((S >> 1) >= best) ? 2 : 0;
+                                const int v = ((best >= lo ? best : -1) << 2) | flag;
+                                if (s2) vb = v; else va = v;
+                            }
+                        }
+                        out_a = dpp_rol1(out_a); out_b = dpp_rol1(out_b);
+                        if (lane == 63) { out_a = va; out_b = vb; }
+                        ++kcur; ++n_out;
+                        if (n_out == 64) { flush(64); n_out = 0; }
+                    }
+                    ++bidx;
+                } else if (step + m >= jfirst) {                           // one boundary phase before lane 0's first boundary
+                    if (lane == 63) racc[0] = make_int2(sS, sB);           // of column step + skew = jfirst
+                    ring_order();
+                }
+            }
+            sS = dpp_rol1(sS); sB = dpp_rol1(sB);
+            if (++pcnt == m) pcnt = 0;
+        }
+    }
+    if (DIR == 0) {
+        // A = best alignment inside R (doubled) = the maximum over every cell of every block: the blocks are waves
+        // of their own, so each adds its maximum to the read's word (zeroed before the launch; A >= 0)
+        int a_all = M;
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) a_all = mx2<W>(a_all, __shfl_xor(a_all, off, 64));
+        if (lane == 0) {
+            atomicMax(&read_a[ra], (W ? a_all : half_lo(a_all)) - BIASW);
+            if (has_b) atomicMax(&read_a[rb], half_hi(a_all) - BIASW);
+        }
+    } else if (last_blk && n_out > 0) {
+        flush(n_out);
+    }
+}
+
+// ------------------------------------------------------------------------------------
 // launchers
 // ------------------------------------------------------------------------------------
 template <int DIR>
@@ -1259,6 +1569,61 @@ extern "C" int nra_launch_sweep_ringchain_fwd(int R, int has_n, int wide, hipStr
 {
     return launch_sweep_ringchain<1>(R, has_n, wide, st, n_tasks, tasks, reads, regions, pool, q2bit, qnmask, sp, kmin,
                                      kmax, coff, snap, read_a, cand_score, cand_flag, chain_buf, chain_cap, n_strips);
+}
+#endif
+
+template <int DIR>
+static int launch_sweep_ringmt(int R, int has_n, int wide, hipStream_t st, int n_blocks, const NraChainBlock* blocks,
+                               int32_t* ticket, const NraSweepTask* tasks, const NraDevRead* reads,
+                               const NraDevRegion* regions, const uint8_t* pool, const uint32_t* q2bit,
+                               const uint32_t* qnmask, NraScoreParams sp, const int32_t* kmin, const int32_t* kmax,
+                               const uint32_t* coff, int32_t* snap, int32_t* read_a, int32_t* cand_score,
+                               uint8_t* cand_flag, uint64_t* strips, int chain_cap, uint32_t epoch, int32_t* error)
+{
+    if (n_blocks <= 0) return 0;
+    if (epoch == 0) return (int)hipErrorInvalidValue;
+    hipError_t e = hipMemsetAsync(ticket, 0, sizeof(int32_t), st);
+    if (e != hipSuccess) return (int)e;
+#define ARGS n_blocks, blocks, ticket, tasks, reads, regions, pool, q2bit, qnmask, sp, kmin, kmax, coff, snap, read_a, cand_score, cand_flag, (nra_u64*)strips, chain_cap, epoch, error
+#define LAUNCH(r)                                                                                        \
+    do {                                                                                                 \
+        if (wide) { if (has_n) k_sweep_ringmt<r, true, DIR, true><<<n_blocks, WAVE, 0, st>>>(ARGS);      \
+                    else k_sweep_ringmt<r, false, DIR, true><<<n_blocks, WAVE, 0, st>>>(ARGS); }         \
+        else { if (has_n) k_sweep_ringmt<r, true, DIR, false><<<n_blocks, WAVE, 0, st>>>(ARGS);          \
+               else k_sweep_ringmt<r, false, DIR, false><<<n_blocks, WAVE, 0, st>>>(ARGS); }             \
+    } while (0)
+    if (R == NRA_RING_MT_R) LAUNCH(NRA_RING_MT_R);
+    else if (R == NRA_CHAIN_R_TEST) LAUNCH(NRA_CHAIN_R_TEST);
+    else return (int)hipErrorInvalidValue;
+#undef LAUNCH
+#undef ARGS
+    return (int)hipGetLastError();
+}
+
+#if NRA_HAS_PART(18)
+extern "C" int nra_launch_sweep_ringmt_bwd(int R, int has_n, int wide, hipStream_t st, int n_blocks,
+                                           const NraChainBlock* blocks, int32_t* ticket, const NraSweepTask* tasks,
+                                           const NraDevRead* reads, const NraDevRegion* regions, const uint8_t* pool,
+                                           const uint32_t* q2bit, const uint32_t* qnmask, NraScoreParams sp,
+                                           const int32_t* kmin, const int32_t* kmax, const uint32_t* coff,
+                                           int32_t* snap, int32_t* read_a, uint64_t* strips, int chain_cap,
+                                           uint32_t epoch, int32_t* error)
+{
+    return launch_sweep_ringmt<0>(R, has_n, wide, st, n_blocks, blocks, ticket, tasks, reads, regions, pool, q2bit, qnmask,
+                                  sp, kmin, kmax, coff, snap, read_a, nullptr, nullptr, strips, chain_cap, epoch, error);
+}
+#endif
+#if NRA_HAS_PART(19)
+extern "C" int nra_launch_sweep_ringmt_fwd(int R, int has_n, int wide, hipStream_t st, int n_blocks,
+                                           const NraChainBlock* blocks, int32_t* ticket, const NraSweepTask* tasks,
+                                           const NraDevRead* reads, const NraDevRegion* regions, const uint8_t* pool,
+                                           const uint32_t* q2bit, const uint32_t* qnmask, NraScoreParams sp,
+                                           const int32_t* kmin, const int32_t* kmax, const uint32_t* coff,
+                                           int32_t* snap, int32_t* read_a, int32_t* cand_score, uint8_t* cand_flag,
+                                           uint64_t* strips, int chain_cap, uint32_t epoch, int32_t* error)
+{
+    return launch_sweep_ringmt<1>(R, has_n, wide, st, n_blocks, blocks, ticket, tasks, reads, regions, pool, q2bit, qnmask,
+                                  sp, kmin, kmax, coff, snap, read_a, cand_score, cand_flag, strips, chain_cap, epoch, error);
 }
 #endif
 

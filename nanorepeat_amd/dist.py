@@ -14,32 +14,71 @@ import numpy as np
 
 from . import _capi
 
-# rows-per-lane instantiations of the sweep kernels (csrc/nra_internal.h NRA_R_LIST); longer reads
-# run as chained blocks of 64 * 20 rows
+# rows-per-lane instantiations of the sweep kernels (csrc/nra_internal.h NRA_R_LIST)
 _R_LIST = np.array([1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16, 18, 20, 22, 24, 28, 32, 40, 48], np.int64)
-_CHAIN_ROWS = 64 * 20      # NRA_RING_CHAIN_R
+_CHAIN_ROWS = 64 * 15      # NRA_RING_MT_R: reads beyond one register block run as chained blocks of 960 rows
+_HALF_WAVE_MAX_QLEN = 32 * 24     # NRA_RING32_MAX_R: up to here a read pair takes half a wave (k_sweep_ring32)
+_RING_MAX_UNIT = 8         # NRA_SWEEP_RING_MAX_M: longer units keep the DPP sweeps (128 columns in flight)
 
 
-def padded_rows(qlen):
-    """Rows a wave sweeps for a read of qlen bases (64 x the bucket's rows per lane)."""
+def _rows_per_lane(need, min_reads=0, span=2):
+    """Rows per lane of every read: the smallest instantiation that holds `need`, then -- like the host side of the
+    library, fold_small_buckets -- a bucket of fewer than min_reads reads joins the next non-empty one within `span`
+    more rows per lane (an under-filled launch costs more than the padding)."""
+    idx = np.minimum(np.searchsorted(_R_LIST, need), len(_R_LIST) - 1)
+    if min_reads > 0 and len(idx):
+        count = np.bincount(idx, minlength=len(_R_LIST))
+        target = np.arange(len(_R_LIST))
+        for bi in range(len(_R_LIST) - 1):
+            if count[bi] == 0 or count[bi] >= min_reads:
+                continue
+            for bj in range(bi + 1, len(_R_LIST)):
+                if _R_LIST[bj] > _R_LIST[bi] + span:
+                    break
+                if count[bj] > 0:
+                    count[bj] += count[bi]; count[bi] = 0
+                    target[target == bi] = bj
+                    break
+        idx = target[idx]
+    return _R_LIST[idx]
+
+
+def padded_rows(qlen, unit_len=None, fold=False):
+    """Rows the sweeps execute for a read of qlen bases: 32 x rows-per-lane in the half-wave kernel (reads of up to
+    768 bases, units of up to 8), 64 x rows-per-lane up to 3072 bases, chained 960-row blocks beyond.  fold: the
+    reads are one batch, whose small rows-per-lane buckets are folded as the library folds them."""
     q = np.asarray(qlen, np.int64)
-    need = (q + 63) // 64
-    one = _R_LIST[np.minimum(np.searchsorted(_R_LIST, need), len(_R_LIST) - 1)] * 64
-    chained = (q + _CHAIN_ROWS - 1) // _CHAIN_ROWS * _CHAIN_ROWS
-    return np.where(need <= _R_LIST[-1], one, chained)
+    m = np.full(q.shape, 1, np.int64) if unit_len is None else np.asarray(unit_len, np.int64)
+    is_chain = q > 64 * _R_LIST[-1]
+    is_half = ~is_chain & (q <= _HALF_WAVE_MAX_QLEN) & (m <= _RING_MAX_UNIT)
+    is_full = ~is_chain & ~is_half
+    rows = (q + _CHAIN_ROWS - 1) // _CHAIN_ROWS * _CHAIN_ROWS
+    if is_half.any():
+        rows = np.where(is_half, 0, rows)
+        rows[is_half] = 32 * _rows_per_lane((q[is_half] + 31) // 32, 2048 if fold else 0)
+    if is_full.any():
+        rows = np.where(is_full, 0, rows)
+        rows[is_full] = 64 * _rows_per_lane((q[is_full] + 63) // 64, 1024 if fold else 0)
+    return rows
 
 
-def executed_cells(regions, qlen, kmax, read_region=None):
-    """DP cells the junction-decomposition kernels execute for every read: padded rows x
-    (|L| + m*kmax forward columns + |R| reverse columns + the two pipelines' 127 fill/drain
-    columns).  This -- not the K-fold algorithmic count -- is what a shard costs."""
+def executed_cells(regions, qlen, kmax, read_region=None, fold=True):
+    """DP cells the junction-decomposition kernels execute for every read (csrc/nra_host.cpp, Bucket::cells_sweep):
+    padded rows x (|L| + m*kmax forward columns + |R| reverse columns + the two pipelines' fill: one column per
+    lane below the first, times the skew -- m in the forward LDS-ring sweep, 1 in the reverse one; 127 + 127 in the
+    DPP sweeps of long units).  This -- not the K-fold algorithmic count -- is what a shard costs.  (The kernels
+    sweep the union of the windows of the two or four reads that share a wave: second-order;
+    tests/test_gpu_parity.py holds the sum to 2 % of nra_stats_t's.)  fold: treat the reads as ONE batch and fold
+    its small rows-per-lane buckets as the library does (a shard is folded on its own: close enough to balance by)."""
     q = np.asarray(qlen, np.int64)
     n = len(q)
     rr = np.zeros(n, np.int64) if read_region is None else np.asarray(read_region, np.int64)
     fl = np.array([len(l) + len(r) for l, _, r in regions], np.int64)[rr]
     m = np.array([len(u) for _, u, _ in regions], np.int64)[rr]
     km = np.maximum(np.asarray(kmax, np.int64), 0)
-    return padded_rows(q) * (fl + m * km + 254)
+    lanes_below = np.where((q <= _HALF_WAVE_MAX_QLEN) & (m <= _RING_MAX_UNIT), 31, 63)
+    fill = np.where(m <= _RING_MAX_UNIT, lanes_below * (m + 1), 254)
+    return padded_rows(q, m, fold) * (fl + m * km + fill)
 
 
 def estimate_cells(regions, reads, kmin, kmax, read_region=None):

@@ -165,7 +165,7 @@ def config4_region_cost(desc, reads_per_region, flank=100, anchor=1000):
     cost = 0
     for a in desc["alleles"]:
         q = 2 * flank + desc["m"] * a
-        cost += int(padded_rows(q)) * (2 * anchor + desc["m"] * reference_window(float(a))[1] + 254)
+        cost += int(padded_rows(q, desc["m"])) * (2 * anchor + desc["m"] * reference_window(float(a))[1] + 31 * (desc["m"] + 1))
     return cost * reads_per_region // len(desc["alleles"])
 
 

@@ -177,9 +177,16 @@ def test_region_block_sharder_properties():
     # one region, many ranks (config 2 strong scaling): still balanced
     owner = D.shard_region_blocks(np.full(1000, 7), None, 8)
     assert np.bincount(owner, minlength=8).min() >= 100
-    # executed-cell cost: padded rows x executed columns
-    cells = D.executed_cells([("A" * 10, "CAG", "T" * 7)], [5, 65, 3073], [4, 4, 4])
-    assert cells.tolist() == [64 * (17 + 12 + 254), 128 * (17 + 12 + 254), 3 * 1280 * (17 + 12 + 254)]
+    # executed-cell cost: padded rows x executed columns (csrc/nra_host.cpp: half-wave sweeps up to 768 bases with a
+    # pipeline 31 lanes deep, full-wave ones up to 3072 with 63, chained 960-row blocks beyond; the forward
+    # pipeline is skewed by the unit length)
+    cells = D.executed_cells([("A" * 10, "CAG", "T" * 7)], [5, 65, 769, 3073], [4, 4, 4, 4], fold=False)
+    assert cells.tolist() == [32 * (17 + 12 + 31 * 4), 96 * (17 + 12 + 31 * 4), 64 * 13 * (17 + 12 + 63 * 4),
+                              4 * 960 * (17 + 12 + 63 * 4)]
+    # as one batch: the lone 5-base read joins the 3-rows-per-lane bucket of the 65-base one (fold_small_buckets)
+    assert D.executed_cells([("A" * 10, "CAG", "T" * 7)], [5, 65], [4, 4]).tolist() == [96 * (17 + 12 + 31 * 4)] * 2
+    # a unit beyond the LDS-ring kernels keeps the DPP sweeps: full waves, 127 + 127 columns of fill
+    assert D.executed_cells([("A" * 10, "ACGTACGTAC", "T" * 7)], [65], [2]).tolist() == [128 * (17 + 20 + 254)]
 
 
 def test_shard_reads_is_a_balanced_partition():

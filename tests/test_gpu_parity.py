@@ -299,11 +299,11 @@ def test_long_cores_chained_int32_sweeps_equal_oracle(capi, oracle):
         kmin.append(win[0]); kmax.append(win[1])
     assert (kmin[1], kmax[1]) == (2850, 3150) and len(reads[2]) > 19000
     o = oracle.round3_1d([(L, "TATTG", R)], reads, kmin, kmax)
-    for flags in (0, capi.F_TIE_EXTENTS):
+    for flags in (0, capi.F_TIE_EXTENTS, capi.F_SERIAL_CHAIN):
         g = capi.round3_1d([(L, "TATTG", R)], reads, kmin, kmax, flags=flags)
         for k in ("best_score", "sum_k", "n_ties", "status", "cand_score"):
             assert np.array_equal(g[k], o[k]), (flags, k, g[k][:8], o[k][:8])
-        if flags:
+        if flags & capi.F_TIE_EXTENTS:
             ties = o["cand_tstart"] >= 0
             assert np.array_equal(g["cand_tstart"][ties], o["cand_tstart"][ties])
             assert np.array_equal(g["cand_tend"][ties], o["cand_tend"][ties])
@@ -439,7 +439,7 @@ def test_more_chained_tasks_than_scratch_strips(capi, oracle):
     DPP sweeps, 9000 int32 tasks (> 512 strips).  Same results as the unchained sweeps; a sample equals the oracle."""
     d = synth.make_1d(9000, "CAG", (6, 11), "ont_q20", kwin=(2, 16), anchor=40, flank=25, seed=88)
     base = capi.round3_1d(d["regions"], d["reads"], d["kmin"], d["kmax"])
-    for flags in (capi.F_TEST_CHAIN, capi.F_TEST_CHAIN | capi.F_DPP_SWEEP):
+    for flags in (capi.F_TEST_CHAIN, capi.F_TEST_CHAIN | capi.F_SERIAL_CHAIN, capi.F_TEST_CHAIN | capi.F_DPP_SWEEP):
         g = capi.round3_1d(d["regions"], d["reads"], d["kmin"], d["kmax"], flags=flags)
         for k in ("best_score", "sum_k", "n_ties", "status", "cand_score"):
             assert np.array_equal(g[k], base[k]), (flags, k)
@@ -447,6 +447,31 @@ def test_more_chained_tasks_than_scratch_strips(capi, oracle):
     o = oracle.round3_1d(d["regions"], [d["reads"][i] for i in pick], d["kmin"][pick], d["kmax"][pick])
     for k in ("best_score", "sum_k", "n_ties", "status"):
         assert np.array_equal(base[k][pick], o[k]), k
+
+
+def test_row_blocks_as_concurrent_waves(capi, oracle):
+    """k_sweep_ringmt: the row blocks of a long read are waves of their own that hand the columns down through granule
+    strips.  Packed (two reads per wave, 3.2 - 6.5 kb: 4 - 7 blocks of 960 rows) and int32 cells (> 6750 bases) in one
+    batch, reads of different block counts paired, a lone read, tight and wide windows (first boundary early and
+    late in the sweep), the same batch run twice (fresh epochs), and against the one-wave-per-read chain."""
+    rng = np.random.default_rng(31)
+    L, R = synth.rand_seq(rng, 600), synth.rand_seq(rng, 500)
+    reads, kmin, kmax = [], [], []
+    for k_true, lo, hi in ((600, 590, 612), (640, 500, 660), (900, 880, 915), (1250, 1247, 1253), (700, 699, 701),
+                           (1500, 1490, 1512), (610, 0, 30)):
+        reads.append(synth.apply_errors(rng, L[-100:] + "TATTG" * k_true + R[:100], "ont_q20"))
+        kmin.append(lo); kmax.append(hi)
+    assert min(len(r) for r in reads) > 3072 and max(len(r) for r in reads) > 6750
+    o = oracle.round3_1d([(L, "TATTG", R)], reads, kmin, kmax)
+    with capi.Batch.create_1d([(L, "TATTG", R)], reads, kmin, kmax) as b:
+        for _ in range(2):
+            b.run(); b.sync()
+            g = b.fetch()
+            for k in ("best_score", "sum_k", "n_ties", "status", "cand_score"):
+                assert np.array_equal(g[k], o[k]), (k, g[k][:8], o[k][:8])
+    s = capi.round3_1d([(L, "TATTG", R)], reads, kmin, kmax, flags=capi.F_SERIAL_CHAIN)
+    for k in ("best_score", "sum_k", "n_ties", "status", "cand_score"):
+        assert np.array_equal(s[k], o[k]), k
 
 
 def test_one_read_against_a_megabase_template(capi, oracle):
@@ -616,6 +641,27 @@ def test_config4_many_regions_sample(capi, oracle):
         assert np.array_equal(gp[k], g[k][perm]), k
 
 
+def test_shard_cost_model_follows_the_kernels(capi):
+    """dist.executed_cells -- what the sharding balances -- against the cells the batch says its kernels execute
+    (nra_stats_t.executed_cells), on a batch mixing half-wave, full-wave and chained reads, short and long units."""
+    from nanorepeat_amd import dist as D
+    rng = np.random.default_rng(21)
+    regions, reads, rr, kmin, kmax = [], [], [], [], []
+    for g, (unit, anchor, alleles, n) in enumerate((("TATTG", 1000, (40, 150), 300), ("CAG", 400, (20, 300), 300),
+                                                    ("AT", 200, (30, 700), 200), ("ACGTTGCATTAC", 300, (8, 20), 60),
+                                                    ("TATTG", 600, (800,), 6))):
+        d = synth.make_1d(n, unit, alleles, "ont_q20", kwin=None, anchor=anchor, rng=rng)
+        regions += d["regions"]; reads += d["reads"]; rr += [g] * n
+        kmin += d["kmin"].tolist(); kmax += d["kmax"].tolist()
+    qlen = [len(r) for r in reads]
+    assert min(qlen) < 300 and max(qlen) > 3072
+    with capi.Batch.create_1d(regions, reads, kmin, kmax, read_region=rr) as b:
+        b.run(); b.sync()
+        st = b.stats()
+    model = int(D.executed_cells(regions, qlen, kmax, rr).sum())
+    assert abs(model - st["executed_cells"]) <= 0.02 * st["executed_cells"], (model, st["executed_cells"])
+
+
 def test_config3_joint_sample(capi, oracle):
     """Config 3 shape: HTT-like CAG+CCG joint grid through the host mirror (both rounds)."""
     j = synth.make_joint(6, seed=33)                  # alleles (17,10) / (55,7), 1.2 kb amplicon reads
@@ -659,7 +705,7 @@ def test_1d_row_block_chaining_small_blocks(capi, oracle):
     for unit, seed, fl in (("TATTG", 201, 100), ("CAG", 202, 60), ("AT", 203, 30)):
         d = synth.make_1d(14, unit, (6, 31), "ont", kwin=None, anchor=220, flank=fl, seed=seed)
         o = oracle.round3_1d(d["regions"], d["reads"], d["kmin"], d["kmax"])
-        for flags in (capi.F_TEST_CHAIN, capi.F_TEST_CHAIN | capi.F_TIE_EXTENTS):
+        for flags in (capi.F_TEST_CHAIN, capi.F_TEST_CHAIN | capi.F_TIE_EXTENTS, capi.F_TEST_CHAIN | capi.F_SERIAL_CHAIN):
             with capi.Batch.create_1d(d["regions"], d["reads"], d["kmin"], d["kmax"], flags=flags) as b:
                 b.run(); b.sync(); g = b.fetch()
             keys = KEYS_1D if flags & capi.F_TIE_EXTENTS else ("best_score", "sum_k", "n_ties", "status", "cand_score")

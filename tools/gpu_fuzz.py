@@ -52,14 +52,14 @@ def fuzz_1d(rng):
         kmin.append(lo); kmax.append(hi)
     sc = rand_scoring(rng)
     o = O.round3_1d([(L, unit, R)], reads, kmin, kmax, sc=O.default_scoring(**sc))
-    for flags in (0, A.F_TIE_EXTENTS, A.F_BRUTE_FORCE, A.F_TEST_CHAIN, A.F_DPP_SWEEP, A.F_NO_HALF_WAVE):
-        if flags == A.F_TEST_CHAIN and (len(L) < 1 or len(R) < 1):
+    for flags in (0, A.F_TIE_EXTENTS, A.F_BRUTE_FORCE, A.F_TEST_CHAIN, A.F_TEST_CHAIN | A.F_SERIAL_CHAIN, A.F_DPP_SWEEP, A.F_NO_HALF_WAVE):
+        if flags & A.F_TEST_CHAIN and (len(L) < 1 or len(R) < 1):
             continue
         try:
             with A.Batch.create_1d([(L, unit, R)], reads, kmin, kmax, sc=A.default_scoring(**sc), flags=flags) as b:
                 b.run(); b.sync(); g = b.fetch()
         except A.NraError:
-            if flags == A.F_TEST_CHAIN:      # scoring that needs the brute-force path cannot chain 128-base blocks
+            if flags & A.F_TEST_CHAIN:      # scoring that needs the brute-force path cannot chain 128-base blocks
                 continue
             raise
         keys = K1 + (("cand_tstart", "cand_tend") if flags in (A.F_TIE_EXTENTS, A.F_BRUTE_FORCE) else ())
@@ -92,7 +92,7 @@ def fuzz_1d_multi(rng):
     order = rng.permutation(len(reads))
     reads = [reads[i] for i in order]; kmin = [kmin[i] for i in order]; kmax = [kmax[i] for i in order]; rr = [rr[i] for i in order]
     o = O.round3_1d(regions, reads, kmin, kmax, read_region=rr)
-    for flags in (0, A.F_TIE_EXTENTS, A.F_ALL_EXTENTS, A.F_TEST_CHAIN, A.F_TEST_CHAIN | A.F_DPP_SWEEP, A.F_NO_HALF_WAVE):
+    for flags in (0, A.F_TIE_EXTENTS, A.F_ALL_EXTENTS, A.F_TEST_CHAIN, A.F_TEST_CHAIN | A.F_SERIAL_CHAIN, A.F_TEST_CHAIN | A.F_DPP_SWEEP, A.F_NO_HALF_WAVE):
         if flags & A.F_TEST_CHAIN and any(len(L) < 1 or len(R) < 1 for L, _, R in regions):
             continue
         g = A.round3_1d(regions, reads, kmin, kmax, read_region=rr, flags=flags)

@@ -1,5 +1,6 @@
 """Times the 1D path on long cores (large expansions): 3.7 and 5.7 kb cores (packed chained blocks) and 7.7 kb cores
-(int32 chained blocks), LDS-ring chain vs the DPP chain (NRA_F_DPP_SWEEP).  Usage: python tools/gpu_long_cores.py [n_reads]"""
+(int32 chained blocks): row blocks as concurrent waves (k_sweep_ringmt, the default) vs one wave per read pair
+(NRA_F_SERIAL_CHAIN, k_sweep_ringchain) vs the DPP chain (NRA_F_DPP_SWEEP).  Usage: python tools/gpu_long_cores.py [n_reads] [modes]"""
 import json, sys, time
 import numpy as np
 sys.path.insert(0, '.')
@@ -13,7 +14,10 @@ for name, alleles in (("cores_3.7kb", (700, 705)), ("cores_5.7kb", (1100, 1105))
     n_align = int((d["kmax"].astype(np.int64) - d["kmin"] + 1).sum())
     row = {"reads": n, "alignments": n_align}
     ref = None
-    for mode, flags in (("ring", 0), ("dpp", A.F_DPP_SWEEP)):
+    modes = (sys.argv[2].split(",") if len(sys.argv) > 2 else ["concurrent_blocks", "serial_blocks"])
+    for mode, flags in (("concurrent_blocks", 0), ("serial_blocks", A.F_SERIAL_CHAIN), ("dpp", A.F_DPP_SWEEP)):
+        if mode not in modes:
+            continue
         with A.Batch.create_1d(d["regions"], d["reads"], d["kmin"], d["kmax"], flags=flags) as b:
             b.run(); b.sync()
             t0 = time.perf_counter()
@@ -25,6 +29,6 @@ for name, alleles in (("cores_3.7kb", (700, 705)), ("cores_5.7kb", (1100, 1105))
         if ref is None:
             ref = g
         row[mode] = {"ms_per_pass": dt * 1e3, "Malign_per_s": n_align / dt / 1e6, "executed_Tcell_per_s": st["executed_cells"] / dt / 1e12,
-                     "same_as_ring": all(np.array_equal(g[k], ref[k]) for k in g)}
+                     "executed_cells": st["executed_cells"], "same_as_first": all(np.array_equal(g[k], ref[k]) for k in g)}
     out[name] = row
 print(json.dumps(out, indent=1))
