@@ -1410,6 +1410,62 @@ int nra_batch1d_fetch(nra_batch_t* b, int32_t* best_score, int64_t* sum_k, int32
     return NRA_OK;
 }
 
+// A large many-region call in region blocks: block i + 1 is packed, bucketed and uploaded (host work + H2D) while
+// the kernels of block i run, so that the host's share of the call (config 4: ~110 of ~380 ms) hides behind the
+// device's.  Reads of a region stay in one block (the sweeps pair two or four reads of a region per wave); needs
+// the reads grouped by region (read_region non-decreasing), which is how the host mirror lists them.
+#define NRA_STREAM_MIN_READS 131072
+static int round3_1d_streamed(int device, const nra_region_t* regions, int32_t n_regions, int32_t n_reads,
+                              const char* seqs, const int64_t* seq_off, const int32_t* read_region,
+                              const int32_t* kmin, const int32_t* kmax, const nra_scoring_t* sc, int32_t flags,
+                              int32_t* best_score, int64_t* sum_k, int32_t* n_ties, uint8_t* status,
+                              int32_t* cand_score, int32_t* cand_tstart, int32_t* cand_tend)
+{
+    const int n_blocks = (int)std::min<int64_t>(16, std::max<int64_t>(2, n_reads / 65536));
+    struct Block { int32_t r0, r1, g0, g1; int64_t c0; };
+    std::vector<Block> blocks;
+    {
+        int64_t cands = 0;
+        int32_t r = 0;
+        for (int i = 0; i < n_blocks && r < n_reads; ++i) {
+            Block bl{r, r, read_region[r], 0, cands};
+            const int32_t want = (int32_t)((int64_t)n_reads * (i + 1) / n_blocks);
+            while (r < n_reads && (r < want || read_region[r] == read_region[r - 1])) {      // whole regions only
+                cands += std::max<int64_t>(0, (int64_t)kmax[r] - kmin[r] + 1);
+                ++r;
+            }
+            if (i == n_blocks - 1) for (; r < n_reads; ++r) cands += std::max<int64_t>(0, (int64_t)kmax[r] - kmin[r] + 1);
+            bl.r1 = r; bl.g1 = read_region[r - 1] + 1;
+            if (bl.r1 > bl.r0) blocks.push_back(bl);
+        }
+    }
+    std::vector<nra_batch_t*> live(blocks.size(), nullptr);
+    std::vector<std::vector<int32_t>> local_region(blocks.size());
+    int rc = NRA_OK;
+    auto finish = [&](size_t i) {
+        if (!live[i]) return;
+        const Block& bl = blocks[i];
+        if (!rc) rc = nra_batch_sync(live[i]);
+        if (!rc) rc = nra_batch1d_fetch(live[i], best_score + bl.r0, sum_k + bl.r0, n_ties + bl.r0, status + bl.r0,
+                                        cand_score ? cand_score + bl.c0 : nullptr, cand_tstart ? cand_tstart + bl.c0 : nullptr,
+                                        cand_tend ? cand_tend + bl.c0 : nullptr);
+        nra_batch_destroy(live[i]);
+        live[i] = nullptr;
+    };
+    for (size_t i = 0; i < blocks.size() && !rc; ++i) {
+        const Block& bl = blocks[i];
+        std::vector<int32_t>& lr = local_region[i];
+        lr.resize((size_t)(bl.r1 - bl.r0));
+        for (int32_t r = bl.r0; r < bl.r1; ++r) lr[(size_t)(r - bl.r0)] = read_region[r] - bl.g0;
+        rc = nra_batch1d_create(device, regions + bl.g0, bl.g1 - bl.g0, bl.r1 - bl.r0, seqs, seq_off + bl.r0, lr.data(),
+                                kmin + bl.r0, kmax + bl.r0, sc, flags, &live[i]);
+        if (!rc) rc = nra_batch_run(live[i]);
+        if (i >= 2) finish(i - 2);              // at most three blocks alive: running, queued, being built
+    }
+    for (size_t i = 0; i < blocks.size(); ++i) finish(i);
+    return rc;
+}
+
 int nra_round3_1d(int device, const nra_region_t* regions, int32_t n_regions, int32_t n_reads,
                   const char* seqs, const int64_t* seq_off, const int32_t* read_region,
                   const int32_t* kmin, const int32_t* kmax, const nra_scoring_t* sc, int32_t flags,
@@ -1419,6 +1475,14 @@ int nra_round3_1d(int device, const nra_region_t* regions, int32_t n_regions, in
     if (n_reads > 0 && (!best_score || !sum_k || !n_ties || !status)) return fail(NRA_E_ARG, "NULL output array");
     nra_batch_t* b = nullptr;
     if (cand_tstart || cand_tend) flags |= NRA_F_TIE_EXTENTS;
+    if (n_reads >= NRA_STREAM_MIN_READS && n_regions > 1 && read_region && regions && seqs && seq_off && kmin && kmax) {
+        bool grouped = true;
+        for (int32_t r = 0; r < n_reads && grouped; ++r)
+            grouped = read_region[r] >= 0 && read_region[r] < n_regions && (r == 0 || read_region[r] >= read_region[r - 1]);
+        if (grouped)
+            return round3_1d_streamed(device, regions, n_regions, n_reads, seqs, seq_off, read_region, kmin, kmax, sc,
+                                      flags, best_score, sum_k, n_ties, status, cand_score, cand_tstart, cand_tend);
+    }
     int rc = nra_batch1d_create(device, regions, n_regions, n_reads, seqs, seq_off, read_region, kmin,
                                 kmax, sc, flags, &b);
     if (rc) return rc;

@@ -449,6 +449,33 @@ def test_more_chained_tasks_than_scratch_strips(capi, oracle):
         assert np.array_equal(base[k][pick], o[k]), k
 
 
+def test_large_call_streams_region_blocks(capi, oracle):
+    """nra_round3_1d cuts a call of >= 131072 reads grouped by region into region blocks and packs / uploads block
+    i + 1 while block i's kernels run: same results as the one resident batch, per read and per candidate, also
+    when a region straddles the nominal block boundary; a sample equals the oracle."""
+    rng = np.random.default_rng(5)
+    regions, reads, rr, kmin, kmax = [], [], [], [], []
+    sizes = [20000, 300, 65000, 7, 48000, 1, 10000]            # 143 308 reads in 7 regions of very different size
+    for g, n in enumerate(sizes):
+        unit = ("CAG", "TATTG", "AT", "GGC", "CAG", "AC", "TTTA")[g]
+        d = synth.make_1d(400, unit, (5, 9), "ont_q20", kwin=(2, 12), anchor=30, flank=20, rng=rng)
+        regions += d["regions"]
+        pick = rng.integers(0, 400, size=n)
+        reads += [d["reads"][i] for i in pick]; rr += [g] * n
+        kmin += [2] * n; kmax += [12] * n
+    with capi.Batch.create_1d(regions, reads, kmin, kmax, read_region=rr) as b:
+        b.run(); b.sync()
+        want = b.fetch()
+    got = capi.round3_1d(regions, reads, kmin, kmax, read_region=rr)
+    for k in ("best_score", "sum_k", "n_ties", "status", "cand_score"):
+        assert np.array_equal(got[k], want[k]), k
+    pick = np.arange(0, len(reads), 4999)
+    o = oracle.round3_1d(regions, [reads[i] for i in pick], [kmin[i] for i in pick], [kmax[i] for i in pick],
+                         read_region=[rr[i] for i in pick])
+    for k in ("best_score", "sum_k", "n_ties", "status"):
+        assert np.array_equal(got[k][pick], o[k]), k
+
+
 def test_row_blocks_as_concurrent_waves(capi, oracle):
     """k_sweep_ringmt: the row blocks of a long read are waves of their own that hand the columns down through granule
     strips.  Packed (two reads per wave, 3.2 - 6.5 kb: 4 - 7 blocks of 960 rows) and int32 cells (> 6750 bases) in one
