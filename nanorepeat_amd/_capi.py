@@ -169,10 +169,18 @@ def _ptr(a, ty):
 
 
 def pack_reads(reads):
+    """Concatenated sequence bytes + offsets.  All-str input (the usual case) is joined once and encoded once."""
+    n = len(reads)
+    off = np.zeros(n + 1, dtype=np.int64)
+    if n == 0:
+        return b"", off
+    if all(type(r) is str for r in reads):
+        blob = "".join(reads)
+        if blob.isascii():                      # one byte per character: lengths carry over
+            np.cumsum(np.fromiter(map(len, reads), np.int64, n), out=off[1:])
+            return blob.encode("ascii"), off
     bs = [r.encode() if isinstance(r, str) else bytes(r) for r in reads]
-    off = np.zeros(len(bs) + 1, dtype=np.int64)
-    if bs:
-        off[1:] = np.cumsum([len(b) for b in bs])
+    off[1:] = np.cumsum([len(b) for b in bs])
     return b"".join(bs), off
 
 

@@ -260,7 +260,10 @@ def initial_estimate_repeat_size(repeat_chrom_seq, fastq_dict, data_type, num_th
 
 
 def _read_seq(fastq_record):
-    return fastq_record.split("\n")[1].strip()
+    """The sequence line of a 4-line FASTQ record (two index() calls instead of splitting all four lines)."""
+    a = fastq_record.index("\n") + 1
+    b = fastq_record.find("\n", a)
+    return fastq_record[a:b if b >= 0 else None].strip()
 
 
 MAX_READ_2D = 3072          # rows one wave holds (NRA_MAX_QLEN_1BLOCK): the limit of nra_align_pairs_cigar queries.

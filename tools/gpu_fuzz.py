@@ -172,13 +172,55 @@ def fuzz_2d(rng):
     return None
 
 
+def fuzz_2d_grid(rng):
+    """Two routed grid rounds on one resident batch (nra_batch2d_set_grid, strands given: the strand-only kernels go
+    out before the cell tasks are built) against the oracle on the cell list nra_joint_grid_cells gives."""
+    u1 = synth.rand_unit(rng, int(rng.integers(1, 6))); u2 = synth.rand_unit(rng, int(rng.integers(1, 6)))
+    L = synth.rand_seq(rng, int(rng.choice([1, 9, 11, 60, 74, 75, 140, 300]))); R = synth.rand_seq(rng, int(rng.choice([2, 3, 10, 60, 74, 140, 300])))
+    mid = synth.rand_seq(rng, int(rng.choice([0, 1, 5, 13, 40])))
+    n = int(rng.integers(1, 9)); reads, truth, strand = [], [], []
+    for r in range(n):
+        a, b = int(rng.integers(0, 25)), int(rng.integers(0, 15))
+        fl, fr = int(rng.integers(0, len(L) + 1)), int(rng.integers(0, len(R) + 1))
+        s = synth.apply_errors(rng, L[len(L) - fl:] + u1 * a + mid + u2 * b + R[:fr], ["hifi", "ont"][int(rng.integers(0, 2))])
+        st = 1
+        if rng.random() < 0.4: s = synth.revcomp(s); st = -1
+        reads.append(mangle(rng, s)); truth.append((a, b)); strand.append(st)
+    t1 = np.array([t[0] for t in truth], np.float64); t2 = np.array([t[1] for t in truth], np.float64)
+    strand = np.array(strand, np.int8)
+    region = (L, u1, mid, u2, R)
+    with A.Batch.create_2d_reads(region, reads) as b:
+        for rnd in range(2):
+            a1 = (int(rng.integers(0, 6)), int(rng.integers(1, 5)), int(rng.integers(1, 12)))
+            a2 = (int(rng.integers(0, 4)), int(rng.integers(1, 4)), int(rng.integers(1, 10)))
+            w1, w2 = rng.integers(1, 9, size=n) + rng.choice([0.0, 0.5, 1 / 3], size=n), rng.integers(1, 6, size=n) + rng.choice([0.0, 0.5], size=n)
+            lo1, hi1, lo2, hi2 = t1 - w1, t1 + w1, t2 - w2, t2 + w2
+            if rng.random() < 0.3: hi2[int(rng.integers(0, n))] = -1.0          # a read without cells
+            st = strand if rng.random() < 0.8 else None
+            grid = A.Grid(a1, lo1, hi1, a2, lo2, hi2)
+            cr, k1, k2 = A.joint_grid_cells(grid)
+            if b.set_grid(grid, st) != len(cr):
+                return dict(kind="2d-grid", key="n_cells", got=[b.n_cand], want=[len(cr)])
+            if len(cr) == 0:
+                continue
+            b.run(); b.sync(); g = b.fetch()
+            o = O.joint_2d(region, reads, cr, k1, k2, read_strand=st)
+            has = np.zeros(n, bool); has[cr] = True
+            for k in K2:
+                sel = has if len(o[k]) == n else slice(None)
+                if not np.array_equal(np.asarray(g[k])[sel], np.asarray(o[k])[sel]):
+                    return dict(kind="2d-grid", round=rnd, key=k, region=region, reads=reads, grid=(a1, a2), bounds=[x.tolist() for x in (lo1, hi1, lo2, hi2)],
+                                strands=None if st is None else st.tolist(), got=np.asarray(g[k]).tolist(), want=np.asarray(o[k]).tolist())
+    return None
+
+
 if __name__ == "__main__":
     rounds = int(sys.argv[1]) if len(sys.argv) > 1 else 100
     seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
     rng = np.random.default_rng(seed)
     t0 = time.time(); bad = 0
     for i in range(rounds):
-        for f in (fuzz_1d, fuzz_1d_multi, fuzz_2d, fuzz_pairs):
+        for f in (fuzz_1d, fuzz_1d_multi, fuzz_2d, fuzz_2d_grid, fuzz_pairs):
             r = f(rng)
             if r is not None:
                 bad += 1
