@@ -93,6 +93,9 @@ def parse():
     ap.add_argument("--cpu-sample", type=int, default=-1,
                     help="reads in the CPU-baseline sample (-1: sized for ~15 s, ~6 s in a sub-record; 0: skip)")
     ap.add_argument("--one-shot-calls", type=int, default=5, help="host-buffers-in/out scorer calls timed at N = 1 (0: skip)")
+    ap.add_argument("--live-pmc", default="auto", choices=("auto", "on", "off"),
+                    help="count the VALU instructions of this very build with a short rocprofv3 --pmc child run (auto: the "
+                         "default N = 1 run only; falls back to the tracked summary when rocprofv3 is not there)")
     ap.add_argument("--sub-configs", default="3,4,5",
                     help="default run (N = 1, config 2) only: the other configs measured into `configs` (none: skip)")
     return ap.parse_args()
@@ -162,19 +165,77 @@ def cpu_baseline_1d(data, n_sample, seconds):
                       f"OpenMP over reads), not minimap2"}, out
 
 
+def live_pmc(config, kernel_substr, steps=2, timeout_s=150):
+    """SQ_INSTS_VALU / SQ_ACTIVE_INST_VALU / GRBM_GUI_ACTIVE of the sweep kernels of THIS build, counted by a child
+    `rocprofv3 --pmc ... -- python3 bench.py --steps N` (counters only: no trace domain beside --kernel-trace).
+    Returns the same keys pmc_counters() reads from the tracked summary, or None when anything goes wrong."""
+    import csv
+    import glob
+    import shutil
+    import tempfile
+    exe = shutil.which("rocprofv3")
+    if exe is None:
+        return None
+    out = tempfile.mkdtemp(prefix="nra_pmc_", dir=os.environ.get("TMPDIR", "/tmp"))
+    cmd = [exe, "--pmc", "SQ_INSTS_VALU", "SQ_ACTIVE_INST_VALU", "GRBM_GUI_ACTIVE", "--kernel-trace",
+           "--output-format", "csv", "-d", out, "--", sys.executable, os.path.abspath(__file__),
+           "--config", str(config), "--steps", str(steps), "--warmup", "0", "--cpu-sample", "0", "--one-shot-calls", "0",
+           "--sub-configs", "none", "--live-pmc", "off"]
+    try:
+        env = dict(os.environ, TMPDIR=os.environ.get("TMPDIR", "/tmp"))
+        for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+            env.pop(k, None)
+        r = subprocess.run(cmd, cwd=os.environ.get("TMPDIR", "/tmp"), env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE,
+                           timeout=timeout_s, start_new_session=True)
+        if r.returncode != 0:
+            return None
+        total, ns = {}, 0.0
+        for f in glob.glob(os.path.join(out, "**", "*counter_collection.csv"), recursive=True):
+            for row in csv.DictReader(open(f)):
+                if kernel_substr not in row["Kernel_Name"]:
+                    continue
+                total[row["Counter_Name"]] = total.get(row["Counter_Name"], 0.0) + float(row["Counter_Value"])
+                if row["Counter_Name"] == "GRBM_GUI_ACTIVE":
+                    ns += float(row["End_Timestamp"]) - float(row["Start_Timestamp"])
+        if not total.get("SQ_INSTS_VALU") or ns <= 0:
+            return None
+        return {"source_sha16": kernel_source_sha16(), "live": True,
+                "sweep_kernels": {"valu_wave_instructions_per_step": total["SQ_INSTS_VALU"] / steps},
+                "simd_cycles_per_valu_instruction_active": 4.0 * total.get("SQ_ACTIVE_INST_VALU", 0.0) / total["SQ_INSTS_VALU"],
+                "clock_GHz": total["GRBM_GUI_ACTIVE"] / 8.0 / ns}
+    except Exception:
+        return None
+    finally:
+        shutil.rmtree(out, ignore_errors=True)
+
+
+LIVE_PMC = {}        # config -> counters of a live child run (filled by main() before the timed run)
+
+
 def pmc_counters(config, kernel_s, brute):
     """Counter-derived figures from the tracked rocprofv3 --pmc summary of this command -- quoted only when the
     summary was taken from the very kernel sources this run was built from (else: stale, nulls)."""
     rel = pmc_profile_path(config)
     prof = os.path.join(ROOT, rel)
     none = {"traffic": None, "counters": None, "frac_issued": None, "issue_ceiling": None}
-    if brute or not os.path.exists(prof):
+    if brute:
         return dict(none, counters={"source": rel, "status": "no PMC summary for this command"})
     try:
-        pmc = json.load(open(prof))
+        pmc = json.load(open(prof)) if os.path.exists(prof) else {}
     except Exception as e:
-        return dict(none, counters={"source": rel, "status": f"unreadable: {e}"})
+        pmc = {}
+    if not pmc and LIVE_PMC.get(config) is None:
+        return dict(none, counters={"source": rel, "status": "no PMC summary for this command"})
     sha = kernel_source_sha16()
+    live = LIVE_PMC.get(config)
+    if live is not None:
+        # instruction counts of this very build, counted in this run; HBM bytes stay with the tracked passes (FETCH_SIZE and
+        # WRITE_SIZE need TCC passes of their own) and are quoted only when those were taken from the same sources
+        tracked = pmc if pmc.get("source_sha16") == sha else {"sweep_kernels": {}}
+        pmc = dict(tracked, **{k: v for k, v in live.items() if k != "sweep_kernels"})
+        pmc["sweep_kernels"] = dict(tracked.get("sweep_kernels", {}), **live["sweep_kernels"])
+        rel = "live rocprofv3 --pmc child run of this command (SQ_INSTS_VALU, SQ_ACTIVE_INST_VALU, GRBM_GUI_ACTIVE)" + \
+              ("; HBM bytes from " + rel if tracked.get("hbm_bytes_per_step_sweep_kernels") else "")
     if pmc.get("source_sha16") != sha:
         return dict(none, counters={"source": rel, "status": "stale: taken from other kernel sources "
                                                              f"({pmc.get('source_sha16')} != {sha}); not quoted"})
@@ -193,7 +254,7 @@ def pmc_counters(config, kernel_s, brute):
                            "tools/ubench) at the shader clock held under this load (GRBM_GUI_ACTIVE)"}
     return {"traffic": pmc.get("hbm_bytes_per_step_sweep_kernels"),
             "counters": {"source": rel + " (rocprofv3 --pmc passes of this command, same kernel sources: " + sha + ")",
-                         "status": "current",
+                         "status": "counted in this run" if live is not None else "current",
                          "valu_wave_instructions_per_step": valu,
                          "simd_cycles_per_valu_instruction": pmc.get("simd_cycles_per_valu_instruction"),
                          "fetch_bytes_per_step": pmc["sweep_kernels"].get("fetch_bytes"),
@@ -570,6 +631,13 @@ def main():
     args = parse()
     spawn_ranks_if_needed(args)
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    default_run = world == 1 and args.config == 2 and not args.brute and args.sub_configs not in ("none", "")
+    if args.live_pmc == "on" or (args.live_pmc == "auto" and default_run):
+        wanted = [args.config] + ([3] if default_run and "3" in args.sub_configs.split(",") else [])
+        for c in wanted:
+            got = live_pmc(c, "k_joint" if c == 3 else "k_sweep_")
+            if got is not None:
+                LIVE_PMC[c] = got
     line = bench_joint(args) if args.config == 3 else bench_1d(args)
     if line is not None and world == 1 and args.config == 2 and not args.brute and args.sub_configs not in ("none", ""):
         line["configs"] = {}

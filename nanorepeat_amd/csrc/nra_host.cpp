@@ -363,6 +363,24 @@ inline int64_t max_score(const nra_scoring_t* sc, int64_t qlen) { return (int64_
 // next non-empty instantiation within `span` more rows per lane (the extra rows are padding).
 void fold_small_buckets(std::vector<std::vector<int32_t>>& by_bucket, size_t min_reads, int span)
 {
+    if (const char* e = getenv("NRA_FOLD")) {         // experiments: "min_reads,span[,top]"
+        int a = 0, b2 = 0, mode = 0;
+        if (sscanf(e, "%d,%d,%d", &a, &b2, &mode) >= 2) { min_reads = (size_t)a; span = b2; }
+        if (mode == 1) {
+            // top-down groups: consecutive small buckets within `span` rows per lane of the group's top join it; a
+            // bucket of min_reads or more stands alone
+            for (int top = kNumR - 1; top >= 0; --top) {
+                if (by_bucket[top].empty() || by_bucket[top].size() >= min_reads) continue;
+                for (int bj = top - 1; bj >= 0 && kRList[top] - kRList[bj] <= span; --bj) {
+                    if (by_bucket[bj].empty()) continue;
+                    if (by_bucket[bj].size() >= min_reads) break;
+                    by_bucket[top].insert(by_bucket[top].end(), by_bucket[bj].begin(), by_bucket[bj].end());
+                    by_bucket[bj].clear();
+                }
+            }
+            return;
+        }
+    }
     for (int bi = 0; bi + 1 < kNumR; ++bi) {
         if (by_bucket[bi].empty() || by_bucket[bi].size() >= min_reads) continue;
         int up = -1;
