@@ -87,6 +87,8 @@ def parse():
     ap.add_argument("--reads-per-region", type=int, default=1000, help="config 4")
     ap.add_argument("--brute", action="store_true",
                     help="score K independent alignments per read (k_score_pk16) instead of the decomposition")
+    ap.add_argument("--joint-tails", action="store_true",
+                    help="config 3, comparison: tail sweeps with the junction at R[0] (NRA_F_JOINT_TAILS) instead of the junction at the end of mid")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL)")
     ap.add_argument("--same-device", action="store_true",
                     help="rehearsal only: every rank uses GPU 0 (with --backend gloo on a one-GPU box)")
@@ -165,10 +167,11 @@ def cpu_baseline_1d(data, n_sample, seconds):
                       f"OpenMP over reads), not minimap2"}, out
 
 
-def live_pmc(config, kernel_substr, steps=2, timeout_s=150):
-    """SQ_INSTS_VALU / SQ_ACTIVE_INST_VALU / GRBM_GUI_ACTIVE of the sweep kernels of THIS build, counted by a child
-    `rocprofv3 --pmc ... -- python3 bench.py --steps N` (counters only: no trace domain beside --kernel-trace).
-    Returns the same keys pmc_counters() reads from the tracked summary, or None when anything goes wrong."""
+def live_pmc(config, kernel_substr, with_traffic, steps=2, timeout_s=120):
+    """Counters of the sweep kernels of THIS build, counted by short child runs `rocprofv3 --pmc <group> --kernel-trace --
+    python3 bench.py --steps N` (counters only, one group per pass): SQ_INSTS_VALU / SQ_ACTIVE_INST_VALU / GRBM_GUI_ACTIVE
+    and, with_traffic, FETCH_SIZE and WRITE_SIZE (a TCC pass each).  Returns the keys pmc_counters() reads from a
+    tracked summary, or None when the first pass fails (no rocprofv3, a refusal, a timeout)."""
     import csv
     import glob
     import shutil
@@ -176,37 +179,50 @@ def live_pmc(config, kernel_substr, steps=2, timeout_s=150):
     exe = shutil.which("rocprofv3")
     if exe is None:
         return None
-    out = tempfile.mkdtemp(prefix="nra_pmc_", dir=os.environ.get("TMPDIR", "/tmp"))
-    cmd = [exe, "--pmc", "SQ_INSTS_VALU", "SQ_ACTIVE_INST_VALU", "GRBM_GUI_ACTIVE", "--kernel-trace",
-           "--output-format", "csv", "-d", out, "--", sys.executable, os.path.abspath(__file__),
-           "--config", str(config), "--steps", str(steps), "--warmup", "0", "--cpu-sample", "0", "--one-shot-calls", "0",
-           "--sub-configs", "none", "--live-pmc", "off"]
-    try:
-        env = dict(os.environ, TMPDIR=os.environ.get("TMPDIR", "/tmp"))
-        for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
-            env.pop(k, None)
-        r = subprocess.run(cmd, cwd=os.environ.get("TMPDIR", "/tmp"), env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE,
-                           timeout=timeout_s, start_new_session=True)
-        if r.returncode != 0:
+    tmp = os.environ.get("TMPDIR", "/tmp")
+
+    def one_pass(counters):
+        out = tempfile.mkdtemp(prefix="nra_pmc_", dir=tmp)
+        cmd = [exe, "--pmc"] + counters + ["--kernel-trace", "--output-format", "csv", "-d", out, "--", sys.executable,
+               os.path.abspath(__file__), "--config", str(config), "--steps", str(steps), "--warmup", "0", "--cpu-sample", "0",
+               "--one-shot-calls", "0", "--sub-configs", "none", "--live-pmc", "off"]
+        try:
+            env = dict(os.environ, TMPDIR=tmp)
+            for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+                env.pop(k, None)
+            r = subprocess.run(cmd, cwd=tmp, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=timeout_s,
+                               start_new_session=True)
+            if r.returncode != 0:
+                return None
+            total, ns = {}, 0.0
+            for f in glob.glob(os.path.join(out, "**", "*counter_collection.csv"), recursive=True):
+                for row in csv.DictReader(open(f)):
+                    if kernel_substr not in row["Kernel_Name"]:
+                        continue
+                    total[row["Counter_Name"]] = total.get(row["Counter_Name"], 0.0) + float(row["Counter_Value"])
+                    if row["Counter_Name"] == counters[-1]:
+                        ns += float(row["End_Timestamp"]) - float(row["Start_Timestamp"])
+            total["_ns"] = ns
+            return total
+        except Exception:
             return None
-        total, ns = {}, 0.0
-        for f in glob.glob(os.path.join(out, "**", "*counter_collection.csv"), recursive=True):
-            for row in csv.DictReader(open(f)):
-                if kernel_substr not in row["Kernel_Name"]:
-                    continue
-                total[row["Counter_Name"]] = total.get(row["Counter_Name"], 0.0) + float(row["Counter_Value"])
-                if row["Counter_Name"] == "GRBM_GUI_ACTIVE":
-                    ns += float(row["End_Timestamp"]) - float(row["Start_Timestamp"])
-        if not total.get("SQ_INSTS_VALU") or ns <= 0:
-            return None
-        return {"source_sha16": kernel_source_sha16(), "live": True,
-                "sweep_kernels": {"valu_wave_instructions_per_step": total["SQ_INSTS_VALU"] / steps},
-                "simd_cycles_per_valu_instruction_active": 4.0 * total.get("SQ_ACTIVE_INST_VALU", 0.0) / total["SQ_INSTS_VALU"],
-                "clock_GHz": total["GRBM_GUI_ACTIVE"] / 8.0 / ns}
-    except Exception:
+        finally:
+            shutil.rmtree(out, ignore_errors=True)
+
+    sq = one_pass(["SQ_INSTS_VALU", "SQ_ACTIVE_INST_VALU", "GRBM_GUI_ACTIVE"])
+    if not sq or not sq.get("SQ_INSTS_VALU") or sq["_ns"] <= 0:
         return None
-    finally:
-        shutil.rmtree(out, ignore_errors=True)
+    res = {"source_sha16": kernel_source_sha16(), "live": True,
+           "sweep_kernels": {"valu_wave_instructions_per_step": sq["SQ_INSTS_VALU"] / steps},
+           "simd_cycles_per_valu_instruction_active": 4.0 * sq.get("SQ_ACTIVE_INST_VALU", 0.0) / sq["SQ_INSTS_VALU"],
+           "clock_GHz": sq["GRBM_GUI_ACTIVE"] / 8.0 / sq["_ns"]}
+    if with_traffic:
+        fe, wr = one_pass(["FETCH_SIZE"]), one_pass(["WRITE_SIZE"])
+        if fe and wr and "FETCH_SIZE" in fe and "WRITE_SIZE" in wr:        # KB units (MI355X_MICROARCH.md, HBM)
+            res["sweep_kernels"]["fetch_bytes"] = fe["FETCH_SIZE"] * 1024 / steps
+            res["sweep_kernels"]["write_bytes"] = wr["WRITE_SIZE"] * 1024 / steps
+            res["hbm_bytes_per_step_sweep_kernels"] = (fe["FETCH_SIZE"] + wr["WRITE_SIZE"]) * 1024 / steps
+    return res
 
 
 LIVE_PMC = {}        # config -> counters of a live child run (filled by main() before the timed run)
@@ -234,8 +250,9 @@ def pmc_counters(config, kernel_s, brute):
         tracked = pmc if pmc.get("source_sha16") == sha else {"sweep_kernels": {}}
         pmc = dict(tracked, **{k: v for k, v in live.items() if k != "sweep_kernels"})
         pmc["sweep_kernels"] = dict(tracked.get("sweep_kernels", {}), **live["sweep_kernels"])
-        rel = "live rocprofv3 --pmc child run of this command (SQ_INSTS_VALU, SQ_ACTIVE_INST_VALU, GRBM_GUI_ACTIVE)" + \
-              ("; HBM bytes from " + rel if tracked.get("hbm_bytes_per_step_sweep_kernels") else "")
+        rel = "rocprofv3 --pmc child runs of this command, in this run (SQ_INSTS_VALU, SQ_ACTIVE_INST_VALU, GRBM_GUI_ACTIVE" + \
+              (", FETCH_SIZE, WRITE_SIZE)" if live.get("hbm_bytes_per_step_sweep_kernels") else
+               "); HBM bytes from " + rel if tracked.get("hbm_bytes_per_step_sweep_kernels") else ")")
     if pmc.get("source_sha16") != sha:
         return dict(none, counters={"source": rel, "status": "stale: taken from other kernel sources "
                                                              f"({pmc.get('source_sha16')} != {sha}); not quoted"})
@@ -253,7 +270,8 @@ def pmc_counters(config, kernel_s, brute):
                            "every 4 cycles on gfx950: SQ_ACTIVE_INST_VALU / SQ_INSTS_VALU = 1 quad-cycle; "
                            "tools/ubench) at the shader clock held under this load (GRBM_GUI_ACTIVE)"}
     return {"traffic": pmc.get("hbm_bytes_per_step_sweep_kernels"),
-            "counters": {"source": rel + " (rocprofv3 --pmc passes of this command, same kernel sources: " + sha + ")",
+            "counters": {"source": rel + (" (rocprofv3 --pmc passes of this command)" if live is None else "") +
+                                   "; kernel sources " + sha,
                          "status": "counted in this run" if live is not None else "current",
                          "valu_wave_instructions_per_step": valu,
                          "simd_cycles_per_valu_instruction": pmc.get("simd_cycles_per_valu_instruction"),
@@ -506,7 +524,8 @@ def bench_joint(args):
     a = J.Repeat.parse(f"chr4:{len(left)}:{len(left) + 57}:{u1}:200")
     b = J.Repeat.parse(f"chr4:{len(left) + 57 + len(mid)}:{len(left) + 57 + len(mid) + 21}:{u2}:20")
     a.max_size += 10; b.max_size += 10                               # nanoRepeat_joint.py:202-203
-    session = J.GridSession(J._joint_region(chrom, a, b), fq, device=local_rank)
+    from nanorepeat_amd import _capi as A
+    session = J.GridSession(J._joint_region(chrom, a, b), fq, device=local_rank, flags=A.F_JOINT_TAILS if args.joint_tails else 0)
     last = {}
 
     def step(sess=session):
@@ -635,7 +654,7 @@ def main():
     if args.live_pmc == "on" or (args.live_pmc == "auto" and default_run):
         wanted = [args.config] + ([3] if default_run and "3" in args.sub_configs.split(",") else [])
         for c in wanted:
-            got = live_pmc(c, "k_joint" if c == 3 else "k_sweep_")
+            got = live_pmc(c, "k_joint" if c == 3 else "k_sweep_", with_traffic=(c == args.config))
             if got is not None:
                 LIVE_PMC[c] = got
     line = bench_joint(args) if args.config == 3 else bench_1d(args)

@@ -61,6 +61,9 @@ extern "C" {
                                  cells too, instead of packed int16 cells with two reads per wave (k_joint_pk16) */
 #define NRA_F_SERIAL_CHAIN 128 /* testing / comparison, 1D: sweep the row blocks of a long read one after the other in one wave
                                  (k_sweep_ringchain) instead of as concurrent waves (k_sweep_ringmt) */
+#define NRA_F_JOINT_TAILS 256  /* testing / comparison, 2D routed grids: junction at R[0] and one tail sweep over mid + unit2^k2 per
+                                 (read, k1) -- what explicit cell lists use -- instead of the junction at the end of mid (extended
+                                 reverse sweeps, MID sweeps, k_joint_combine) */
 #define NRA_F_BRUTE_FORCE  4  /* score the K candidates of a read as K independent alignments
                                  (k_score_pk16) instead of the junction decomposition (k_sweep_pk16) */
 

@@ -325,6 +325,8 @@ struct Bucket {
     size_t jbwd_off = 0;
     int n_jlpk = 0, n_jrpk = 0;    // ... packed sweeps of the payload-free columns of L / rev(R) (one per pair of reads)
     size_t jlpk_off = 0, jrpk_off = 0;
+    int n_comb = 0;            // 2D, junction at the end of mid: combine tasks (one per read)
+    size_t comb_off = 0;
     int n_probe = 0;           // 2D, chained reads: strand-probe payload tasks (two per read)
     size_t probe_off = 0;
     int64_t cells_pair = 0;    // executed cells per run, pk16
@@ -363,24 +365,6 @@ inline int64_t max_score(const nra_scoring_t* sc, int64_t qlen) { return (int64_
 // next non-empty instantiation within `span` more rows per lane (the extra rows are padding).
 void fold_small_buckets(std::vector<std::vector<int32_t>>& by_bucket, size_t min_reads, int span)
 {
-    if (const char* e = getenv("NRA_FOLD")) {         // experiments: "min_reads,span[,top]"
-        int a = 0, b2 = 0, mode = 0;
-        if (sscanf(e, "%d,%d,%d", &a, &b2, &mode) >= 2) { min_reads = (size_t)a; span = b2; }
-        if (mode == 1) {
-            // top-down groups: consecutive small buckets within `span` rows per lane of the group's top join it; a
-            // bucket of min_reads or more stands alone
-            for (int top = kNumR - 1; top >= 0; --top) {
-                if (by_bucket[top].empty() || by_bucket[top].size() >= min_reads) continue;
-                for (int bj = top - 1; bj >= 0 && kRList[top] - kRList[bj] <= span; --bj) {
-                    if (by_bucket[bj].empty()) continue;
-                    if (by_bucket[bj].size() >= min_reads) break;
-                    by_bucket[top].insert(by_bucket[top].end(), by_bucket[bj].begin(), by_bucket[bj].end());
-                    by_bucket[bj].clear();
-                }
-            }
-            return;
-        }
-    }
     for (int bi = 0; bi + 1 < kNumR; ++bi) {
         if (by_bucket[bi].empty() || by_bucket[bi].size() >= min_reads) continue;
         int up = -1;
@@ -470,6 +454,11 @@ struct nra_batch {
     DevBuf<NraJointTask> jbwd_tasks, jpre_tasks, jtail_tasks; // 2D decomposition: per read / per read / per (read, k1) run
     DevBuf<int32_t> jsnap, jread_a;             // R side of the junction (3 x int32 per base), A per read
     DevBuf<int32_t> jk1list, jstate;            // k1 values per read; wave states of the prefix sweeps
+    // routed grids, junction at the end of mid: column states of the MID sweeps / the extended reverse sweeps,
+    // B(k1) / A(k2), one combine task per read
+    DevBuf<int32_t> jfs, jrs, jfb, jra;
+    DevBuf<NraJointCombineTask> jcomb_tasks;
+    bool joint_v2 = false, joint_v2_prev = false;
     std::vector<JointGroup> jgroups;
     bool all_strands_given = false;             // 2D: every read came with its strand, no probe needed
     int chain_cap = 0;
@@ -1787,10 +1776,11 @@ int set_cells_common(nra_batch* b, const int8_t* read_strand, int64_t n_cells, c
     d.p1_off = pool_append(pool, b->jr_left.data(), left_len, b->jr_unit1.data(), unit1_len, k1max, has_n);
     d.p2_off = pool_append(pool, b->jr_mid.data(), mid_len, b->jr_unit2.data(), unit2_len, k2max, has_n);
     d.p3_off = pool_append(pool, b->jr_right.data(), right_len, nullptr, 0, 0, has_n);
-    {
-        std::string rr(b->jr_right);
+    {   // rev(R) + rev(u2)^k2max: the reverse sweeps (the extended ones run on into the second repeat)
+        std::string rr(b->jr_right), ru(b->jr_unit2);
         std::reverse(rr.begin(), rr.end());
-        d.pr_off = pool_append(pool, rr.data(), right_len, nullptr, 0, 0, has_n);
+        std::reverse(ru.begin(), ru.end());
+        d.pr_off = pool_append(pool, rr.data(), right_len, ru.data(), unit2_len, k2max, has_n);
     }
     d.l1 = left_len; d.m1 = unit1_len; d.l2 = mid_len; d.m2 = unit2_len; d.l3 = right_len;
     pool.push_back(0);
@@ -1814,6 +1804,18 @@ int set_cells_common(nra_batch* b, const int8_t* read_strand, int64_t n_cells, c
     std::vector<int32_t> k1list;
     // junction decomposition needs a base left of the window and two bases of R
     b->brute = (flags & NRA_F_BRUTE_FORCE) != 0 || left_len < 1 || right_len < 2;
+    // a routed grid: every read's cells are a full product (k1 values) x (one k2 progression) -> junction at the end
+    // of mid.  The state kept from earlier cell lists differs between the two forms: switching drops it.
+    b->joint_v2 = grid != nullptr && !b->brute && (flags & NRA_F_JOINT_TAILS) == 0;
+    if (b->joint_v2 != b->joint_v2_prev) {
+        std::fill(b->rev_strand.begin(), b->rev_strand.end(), (int8_t)0);
+        b->joint_v2_prev = b->joint_v2;
+    }
+    std::vector<NraJointCombineTask> jcomb;
+    std::vector<uint64_t> rs_off((size_t)n_reads, 0);
+    std::vector<int32_t> ra_off((size_t)n_reads, 0);
+    uint64_t rs_total = 0, fs_total = 0;
+    int64_t ra_total = 0, fb_total = 0;
     // wave states of one group of reads (NRA_F_TEST_CHAIN: one read per group, to exercise the reuse)
     // The buckets run concurrently, each in its own part of the state buffer.
     size_t n_nonempty = 0;
@@ -1847,7 +1849,23 @@ int set_cells_common(nra_batch* b, const int8_t* read_strand, int64_t n_cells, c
                 const int8_t given = read_strand ? read_strand[r] : 0;
                 const int32_t pi = b->jpair_of[r];
                 const NraJointPairTask& pair = b->jpairs[(size_t)pi];
-                if (given == 0 || b->rev_strand[r] != given) {      // not made yet (or for the other strand)
+                const bool stale = given == 0 || b->rev_strand[r] != given;     // nothing kept for this read and strand
+                if (b->joint_v2) {
+                    // the reverse sweep runs on over rev(u2)^k2hi and leaves a column state per k2 of the read: it
+                    // belongs to this cell list; only the packed sweep of rev(R) up to the window is kept
+                    const GridRow& gr = grid->rows[(size_t)r];
+                    NraJointTask tb{}; tb.read = r; tb.k2lo = gr.k2lo; tb.k2step = grid->step2; tb.n2 = gr.n2;
+                    tb.state = rs_total; tb.out = (int32_t)ra_total;
+                    rs_off[(size_t)r] = rs_total; ra_off[(size_t)r] = (int32_t)ra_total;
+                    rs_total += (uint64_t)gr.n2 * 3 * (uint64_t)reads[r].qlen; ra_total += gr.n2;
+                    if (b->jpack_r) {
+                        tb.resume = 1; tb.pstate = pair.state; tb.phalf = pair.read_b == r ? 1 : 0;
+                        if (stale && !pair_r[pi]) { pair_r[pi] = 1; jrpk.push_back(pair); bk.cells_sweep += (int64_t)2 * 64 * bk.R * colsR; }
+                    }
+                    jbwd.push_back(tb);
+                    bk.cells_sweep += joint_cells(bk.R, d.l3 - (b->jpack_r ? colsR : 0) + d.m2 * (gr.k2lo + grid->step2 * (gr.n2 - 1)), reads[r].qlen);
+                    if (stale) { b->rev_strand[r] = 0; b->rev_pending.push_back({r, given}); }
+                } else if (stale) {
                     NraJointTask tb{}; tb.read = r; tb.k2step = 1; tb.n2 = 1;
                     if (b->jpack_r) {
                         tb.resume = 1; tb.pstate = pair.state; tb.phalf = pair.read_b == r ? 1 : 0;
@@ -1924,6 +1942,10 @@ int set_cells_common(nra_batch* b, const int8_t* read_strand, int64_t n_cells, c
         HIP_TRY(b->jbwd_tasks.upload(jbwd));
         HIP_TRY(b->jlpk_tasks.upload(jlpk));
         HIP_TRY(b->jrpk_tasks.upload(jrpk));
+        if (b->joint_v2) {
+            HIP_TRY(b->jrs.alloc((size_t)rs_total));
+            HIP_TRY(b->jra.alloc((size_t)ra_total));
+        }
     }
     // events and streams: kept from one cell list to the next, more taken from the pool when needed
     auto ensure_handles = [&](size_t n_ev) -> int {
@@ -1934,7 +1956,7 @@ int set_cells_common(nra_batch* b, const int8_t* read_strand, int64_t n_cells, c
         return NRA_OK;
     };
     {
-        const int rc1 = ensure_handles(2 + 10 * nb + 2);
+        const int rc1 = ensure_handles(2 + 12 * nb + 2);
         if (rc1) return rc1;
     }
     b->flanks_enqueued = false;
@@ -1949,6 +1971,7 @@ int set_cells_common(nra_batch* b, const int8_t* read_strand, int64_t n_cells, c
         const int bi = bucket_ids[bidx];
         Bucket& bk = b->buckets[bidx];
         bk.queue_off = queue_tasks.size();
+        bk.comb_off = jcomb.size();
         const bool per_cell = b->brute || bk.chain;
         const uint64_t slot = (uint64_t)NRA_JOINT_NSTATE(bk.R) * 64;
         JointGroup g; g.R = bk.R; g.bucket = (int)bidx; g.pre_off = jpre.size(); g.tail_off = jtail.size();
@@ -1980,7 +2003,25 @@ int set_cells_common(nra_batch* b, const int8_t* read_strand, int64_t n_cells, c
                 if (b->jpack_l) { tp.resume = 1; tp.pstate = pair.state; tp.phalf = pair.read_b == r ? 1 : 0; }
                 jpre.push_back(tp);
                 bk.cells_sweep += (int64_t)64 * bk.R * (d.l1 + d.m1 * ks.back() - 1 - (b->jpack_l ? colsL : 0));
-                if (grid) {
+                if (b->joint_v2) {
+                    // one MID sweep per k1 (the last prefix column + mid; leaves its column state and B(k1)), and the
+                    // read's combine task: n1 x n2 cells from the column states on either side of the junction
+                    const GridRow& gr = grid->rows[(size_t)r];
+                    const uint64_t q3 = (uint64_t)3 * (uint64_t)reads[r].qlen;
+                    for (int32_t i = 0; i < gr.n1; ++i) {
+                        NraJointTask t{}; t.read = r; t.k1 = ks[(size_t)i]; t.k2step = 1;
+                        t.out = (int32_t)(fb_total + i);
+                        t.state = used + slot * (uint64_t)i;
+                        t.pstate = fs_total + (uint64_t)i * q3;
+                        jtail.push_back(t);
+                        bk.cells_sweep += joint_cells(bk.R, 1 + d.l2, reads[r].qlen);
+                    }
+                    NraJointCombineTask ct{};
+                    ct.read = r; ct.n1 = gr.n1; ct.n2 = gr.n2; ct.out = (int32_t)first[r];
+                    ct.fb = (int32_t)fb_total; ct.ra = ra_off[(size_t)r]; ct.fs = fs_total; ct.rs = rs_off[(size_t)r];
+                    jcomb.push_back(ct);
+                    fs_total += (uint64_t)gr.n1 * q3; fb_total += gr.n1;
+                } else if (grid) {
                     // one tail sweep per k1: the read's k2 values are one arithmetic progression
                     const GridRow& gr = grid->rows[(size_t)r];
                     for (int32_t i = 0; i < gr.n1; ++i) {
@@ -2033,6 +2074,7 @@ int set_cells_common(nra_batch* b, const int8_t* read_strand, int64_t n_cells, c
         }
         bk.n_queue = (int)(queue_tasks.size() - bk.queue_off);
         bk.queue_cap = (size_t)bk.n_queue;
+        bk.n_comb = (int)(jcomb.size() - bk.comb_off);
         queue_count.push_back(bk.n_queue);
     }
 
@@ -2044,6 +2086,11 @@ int set_cells_common(nra_batch* b, const int8_t* read_strand, int64_t n_cells, c
         HIP_TRY(b->jtail_tasks.upload(jtail));
         HIP_TRY(b->jk1list.upload(k1list));
         HIP_TRY(b->jstate.alloc((size_t)state_base));
+        if (b->joint_v2) {
+            HIP_TRY(b->jfs.alloc((size_t)fs_total));
+            HIP_TRY(b->jfb.alloc((size_t)fb_total));
+            HIP_TRY(b->jcomb_tasks.upload(jcomb));
+        }
     }
     {
         std::vector<int32_t> v(cell_k1, cell_k1 + n_cells); HIP_TRY(b->cell_k1.upload(v));
@@ -2055,7 +2102,7 @@ int set_cells_common(nra_batch* b, const int8_t* read_strand, int64_t n_cells, c
     HIP_TRY(b->cand_tstart.alloc((size_t)n_cells));    // cell_wscore
     clk.mark("2D cells: device buffers, H2D");
     {
-        const int rc1 = ensure_handles(2 + 10 * nb + 4 * b->jgroups.size() + 2);
+        const int rc1 = ensure_handles(2 + 12 * nb + 4 * b->jgroups.size() + 2);
         if (rc1) return rc1;
     }
 
@@ -2067,7 +2114,8 @@ int set_cells_common(nra_batch* b, const int8_t* read_strand, int64_t n_cells, c
     b->stats.algorithmic_bytes = (int64_t)b->n_q2bit_words * 4 + (int64_t)pool.size() + n_cells * 8 + (int64_t)n_reads * 25;
     int64_t packed_ints = 0;
     for (const Bucket& bk : b->buckets) packed_ints += (int64_t)(bk.n_jlpk + bk.n_jrpk) * NRA_JOINT_NPSTATE(bk.R) * 64;
-    b->stats.intermediate_bytes = b->brute ? 0 : 2 * ((int64_t)state_base * 4 + (int64_t)b->n_q2bit_words * 16 * 3 * 4 + packed_ints * 4);
+    b->stats.intermediate_bytes = b->brute ? 0 : 2 * ((int64_t)state_base * 4 + packed_ints * 4 +
+                                                      (b->joint_v2 ? (int64_t)(rs_total + fs_total) * 4 : (int64_t)b->n_q2bit_words * 16 * 3 * 4));
     b->have_cells = true;
     return NRA_OK;
 }
@@ -2174,6 +2222,11 @@ int run_2d_flanks(nra_batch* b)
                 b->n_score_ev++;
             }
             HIP_TRY(hipEventRecord(b->ev[ev++], qa));
+            if (b->joint_v2)
+                LAUNCH_TRY(nra_launch_joint_bwd_ext(bk.R, b->has_n, qa, bk.n_jbwd, b->jbwd_tasks.p + bk.jbwd_off,
+                                                    b->reads.p, b->regions.p, b->pool.p, b->q2bit.p, b->qnmask.p,
+                                                    b->sp, b->jrs.p, b->jra.p, b->jrstate.p));
+            else
             LAUNCH_TRY(nra_launch_joint_bwd(bk.R, b->has_n, qa, bk.n_jbwd, b->jbwd_tasks.p + bk.jbwd_off,
                                             b->reads.p, b->regions.p, b->pool.p, b->q2bit.p, b->qnmask.p,
                                             b->sp, b->jsnap.p, b->jread_a.p, b->jrstate.p));
@@ -2234,13 +2287,27 @@ int run_2d(nra_batch* b)
                                                    b->sp, b->jk1list.p, b->jstate.p, b->jlstate.p));
                 HIP_TRY(hipEventRecord(b->ev[ev++], qb));
                 b->n_score_ev++;
-                if (first) HIP_TRY(hipStreamWaitEvent(qb, b->bdone[3 * i], 0));     // the tails read the R side
+                if (first && !b->joint_v2) HIP_TRY(hipStreamWaitEvent(qb, b->bdone[3 * i], 0));     // the tails read the R side
                 first = false;
                 HIP_TRY(hipEventRecord(b->ev[ev++], qb));
+                if (b->joint_v2)
+                    LAUNCH_TRY(nra_launch_joint_mid(g.R, b->has_n, qb, g.n_tail, b->jtail_tasks.p + g.tail_off,
+                                                    b->reads.p, b->regions.p, b->pool.p, b->q2bit.p, b->qnmask.p,
+                                                    b->sp, b->jstate.p, b->jfs.p, b->jfb.p));
+                else
                 LAUNCH_TRY(nra_launch_joint_tail(g.R, b->has_n, qb, g.n_tail, b->jtail_tasks.p + g.tail_off,
                                                  b->reads.p, b->regions.p, b->pool.p, b->q2bit.p, b->qnmask.p,
                                                  b->sp, b->jstate.p, b->jsnap.p, b->jread_a.p, b->cand_score.p,
                                                  b->cand_tstart.p));
+                HIP_TRY(hipEventRecord(b->ev[ev++], qb));
+                b->n_score_ev++;
+            }
+            if (b->joint_v2 && bk.n_comb > 0) {
+                // every cell of the bucket's reads from the column states on either side of the junction
+                HIP_TRY(hipStreamWaitEvent(qb, b->bdone[3 * i], 0));                // ... the extended reverse sweeps'
+                HIP_TRY(hipEventRecord(b->ev[ev++], qb));
+                LAUNCH_TRY(nra_launch_joint_combine(qb, bk.n_comb, b->jcomb_tasks.p + bk.comb_off, b->reads.p, b->sp,
+                                                    b->jfs.p, b->jrs.p, b->jfb.p, b->jra.p, b->cand_score.p, b->cand_tstart.p));
                 HIP_TRY(hipEventRecord(b->ev[ev++], qb));
                 b->n_score_ev++;
             }

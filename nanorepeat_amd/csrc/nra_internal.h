@@ -74,6 +74,10 @@ struct NraChainBlock {
 //   reverse sweep over R: one per read, only `read` is used.
 //   resume != 0 (reverse and prefix sweeps): the first NRA_JOINT_PACKED_COLS columns were swept by k_joint_pk16;
 //     the wave state it left is at pstate (index into the packed-state buffer), this read in half `phalf`.
+//   Junction at the end of `mid` (routed grids, round 3 of the build): the reverse sweep runs on over rev(u2)^k2hi
+//     and leaves, at the column of every k2 = k2lo + n*k2step, n < n2, its rows' column state in slot n of `state`
+//     (3 planes of qlen int32) and A(k2) at out + n; a MID sweep (one per (read, k1)) resumes like a tail, sweeps
+//     the last prefix column + mid, and leaves its rows' column state at `pstate` and B(k1) at `out`.
 struct NraJointTask {
     int32_t read;
     int32_t k1;
@@ -83,6 +87,14 @@ struct NraJointTask {
     uint64_t state;
     uint64_t pstate;
     int32_t phalf, resume;
+};
+
+// One read of a routed grid for k_joint_combine: its n1 x n2 cells (k1-major at `out`) from the column states the
+// MID sweeps (fs: n1 slots of 3 x qlen) and the extended reverse sweep (rs: n2 slots) left, B(k1) at fb, A(k2) at ra.
+struct NraJointCombineTask {
+    int32_t read, n1, n2, out;
+    int32_t fb, ra, pad0, pad1;
+    uint64_t fs, rs;
 };
 
 // Two reads of one rows-per-lane bucket whose payload-free columns -- L up to the scoring window, or rev(R) up to
@@ -281,6 +293,18 @@ int nra_launch_joint_pk16(int R, int has_n, hipStream_t st, int n_tasks, const N
                           const NraDevRead* reads, const NraDevRegion* regions, const uint8_t* pool,
                           const uint32_t* q2bit, const uint32_t* qnmask, NraScoreParams sp, int dir,
                           int32_t* pstate);
+// junction at the end of mid: extended reverse sweeps, MID sweeps, the per-cell combine
+int nra_launch_joint_bwd_ext(int R, int has_n, hipStream_t st, int n_tasks, const NraJointTask* tasks,
+                             const NraDevRead* reads, const NraDevRegion* regions, const uint8_t* pool,
+                             const uint32_t* q2bit, const uint32_t* qnmask, NraScoreParams sp,
+                             int32_t* rsnap, int32_t* ra, const int32_t* pstate);
+int nra_launch_joint_mid(int R, int has_n, hipStream_t st, int n_tasks, const NraJointTask* tasks,
+                         const NraDevRead* reads, const NraDevRegion* regions, const uint8_t* pool,
+                         const uint32_t* q2bit, const uint32_t* qnmask, NraScoreParams sp,
+                         int32_t* state, int32_t* fsnap, int32_t* fb);
+int nra_launch_joint_combine(hipStream_t st, int n_tasks, const NraJointCombineTask* tasks, const NraDevRead* reads,
+                             NraScoreParams sp, const int32_t* fsnap, const int32_t* rsnap, const int32_t* fb,
+                             const int32_t* ra, int32_t* cell_score, int32_t* cell_wscore);
 int nra_launch_joint_tail(int R, int has_n, hipStream_t st, int n_tasks, const NraJointTask* tasks,
                           const NraDevRead* reads, const NraDevRegion* regions, const uint8_t* pool,
                           const uint32_t* q2bit, const uint32_t* qnmask, NraScoreParams sp,

@@ -74,6 +74,9 @@ __device__ __forceinline__ int oriented_code(const NraDevRead& rd, const uint32_
 // Waves per SIMD to aim for (512 VGPRs per lane and SIMD): a sweep keeps 4 registers per row (H,
 // E_in, E2_in, the read base) -- 7 in the tail sweep, which also holds the R side -- and ~45 more.
 // Without the hint the compiler spends every register its occupancy bracket has (R = 18: 239).
+// DIR: 0 reverse sweep over rev(R); 1 prefix sweep; 2 tail sweep; 3 reverse sweep extended over rev(u2)^k2hi with a
+// column state per k2 (junction at the end of mid); 4 MID sweep (a tail that stops at the end of mid and leaves its
+// column state).
 constexpr int joint_waves(int R, int DIR)
 {
     const int need = (DIR == 2 ? 7 : 4) * R + 70;
@@ -97,6 +100,9 @@ __global__ __launch_bounds__(WAVE, joint_waves(R, DIR)) void k_joint_sweep(int n
                                                       int32_t* __restrict__ cell_wscore,
                                                       const int32_t* __restrict__ pstate)   // DIR 0 / 1: packed states
 {
+    constexpr bool FWD = DIR == 1 || DIR == 2 || DIR == 4;      // read vs the template left to right
+    constexpr bool TAIL = DIR == 2 || DIR == 4;                 // resumes from a prefix sweep's wave state
+    constexpr bool EXT = DIR == 3, MID = DIR == 4;
     const int task = blockIdx.x;
     if (task >= n_tasks) return;
     const int lane = threadIdx.x;
@@ -110,15 +116,15 @@ __global__ __launch_bounds__(WAVE, joint_waves(R, DIR)) void k_joint_sweep(int n
     // template of this sweep, in the sweep's own column numbers v = 0, 1, ...:
     //   DIR 0: rev(R);  DIR 1: L + u1^k1max up to the last state dump;
     //   DIR 2: v = 0 is column t0 = |L| + m1*k1 - 1 of piece 1, then mid + u2^k2hi.
-    const uint8_t* __restrict__ p1 = pool + (DIR ? rg.p1_off : rg.pr_off);
+    const uint8_t* __restrict__ p1 = pool + (FWD ? rg.p1_off : rg.pr_off);
     const uint8_t* __restrict__ p2 = pool + rg.p2_off;
-    const int t0 = DIR == 2 ? rg.l1 + rg.m1 * tk.k1 - 1 : 0;                   // real column of v = 0
+    const int t0 = TAIL ? rg.l1 + rg.m1 * tk.k1 - 1 : 0;                       // real column of v = 0
     int si = 0;                                                                // DIR 1: next dump
     int next_t = DIR == 1 ? rg.l1 + rg.m1 * k1list[tk.k1_off] - 1 : -1;
     const int t_last = DIR == 1 ? rg.l1 + rg.m1 * k1list[tk.k1_off + tk.nk1 - 1] - 1 : 0;
-    const int ncols = DIR == 0 ? lenR : DIR == 1 ? t_last
-                                                 : 1 + rg.l2 + rg.m2 * (tk.k2lo + tk.k2step * (tk.n2 - 1));
-    const int vfirst = rg.l2 + rg.m2 * tk.k2lo;                                // DIR 2: first boundary
+    const int ncols = DIR == 0 ? lenR : DIR == 1 ? t_last : MID ? 1 + rg.l2
+                      : (EXT ? lenR - 1 : rg.l2) + 1 + rg.m2 * (tk.k2lo + tk.k2step * (tk.n2 - 1));
+    const int vfirst = (EXT ? lenR - 1 : rg.l2) + rg.m2 * tk.k2lo;             // DIR 2 / 3: first boundary
     const int vstep = rg.m2 * tk.k2step;
     const int wa = imax(0, rg.l1 - 10);                                        // window start (forward)
     constexpr int NSTATE = NRA_JOINT_NSTATE(R);
@@ -130,7 +136,7 @@ __global__ __launch_bounds__(WAVE, joint_waves(R, DIR)) void k_joint_sweep(int n
 #pragma unroll
     for (int i = 0; i < R; ++i) {
         const int r = lane * R + i;
-        qcp[i >> 2] |= (uint32_t)oriented_code<HAS_N>(rd, q2bit, qnmask, DIR ? r : (r < Q ? Q - 1 - r : -1)) << (8 * (i & 3));
+        qcp[i >> 2] |= (uint32_t)oriented_code<HAS_N>(rd, q2bit, qnmask, FWD ? r : (r < Q ? Q - 1 - r : -1)) << (8 * (i & 3));
     }
 
     const int sA = sp.match << 16, sB = -(sp.mismatch << 16), sN = -(sp.ambi << 16);
@@ -183,8 +189,9 @@ __global__ __launch_bounds__(WAVE, joint_waves(R, DIR)) void k_joint_sweep(int n
     int tt = NRA_PAD_T;
     int j = t0 - lane;                  // real template column of this lane's next cell
     int ncur = 0;                       // boundary counter, meaningful in the output lane only
+    int nsnap = 0;                      // EXT: boundary columns this lane has passed
 
-    if (DIR == 2) {
+    if (TAIL) {
         // resume: the registers of every lane as the prefix sweep left them before step t0
         const int32_t* __restrict__ sv = state + tk.state + lane;
 #pragma unroll
@@ -201,9 +208,9 @@ __global__ __launch_bounds__(WAVE, joint_waves(R, DIR)) void k_joint_sweep(int n
     // H is stored minus the gap open there too (nra_pk16.h; no payload before the window), the accumulator
     // chains start empty (no boundary before step0)
     int step0 = 0;
-    if (DIR != 2) {
+    if (!TAIL) {
         if (tk.resume) {
-            step0 = NRA_JOINT_PACKED_COLS(DIR ? rg.l1 : lenR);
+            step0 = NRA_JOINT_PACKED_COLS(FWD ? rg.l1 : lenR);
             const int32_t* __restrict__ pv = pstate + tk.pstate + lane;
             const int hi = tk.phalf;
             auto cell_of = [&](int v) { return (((hi ? half_hi(v) : half_lo(v)) - BIAS) << 16) + JBIAS; };
@@ -240,12 +247,14 @@ __global__ __launch_bounds__(WAVE, joint_waves(R, DIR)) void k_joint_sweep(int n
                 const int col = step + lane;
                 feed = NRA_PAD_T;
                 if (col < ncols) {
-                    if (DIR == 2) {
+                    if (TAIL) {
                         feed = col == 0 ? p1[t0] : p2[col - 1];
-                        if (col >= vfirst && (col - vfirst) % vstep == 0 && (col - vfirst) / vstep < tk.n2) feed |= JFLAG_BOUNDARY;
+                        if (MID) { if (col == ncols - 1) feed |= JFLAG_SNAPSHOT | JFLAG_BOUNDARY; }
+                        else if (col >= vfirst && (col - vfirst) % vstep == 0 && (col - vfirst) / vstep < tk.n2) feed |= JFLAG_BOUNDARY;
                     } else {
-                        feed = p1[col];
+                        feed = p1[col];          // (EXT: rev(R) is followed by rev(u2)^k2max in the pool)
                         if (DIR == 0 && col == lenR - 1) feed |= JFLAG_SNAPSHOT | JFLAG_BOUNDARY;
+                        if (EXT && col >= vfirst && (col - vfirst) % vstep == 0) feed |= JFLAG_SNAPSHOT | JFLAG_BOUNDARY;
                     }
                 }
             }
@@ -274,7 +283,7 @@ __global__ __launch_bounds__(WAVE, joint_waves(R, DIR)) void k_joint_sweep(int n
             // window payload increments of THIS column (tk.py:464-485; mirrored for the reverse sweep), and the
             // vertical-gap open of the PREVIOUS column, which the stored Hq carry (fo_prev)
             int pe, pn, eo, ex, fo, fx, fo_prev;
-            if (DIR) {
+            if (FWD) {
                 const bool inw = j >= wa;                                    // every column from wa on
                 pe = inw ? 2 : 0; pn = inw ? -4 : 0;
                 eo = inw ? -4 : 0; ex = inw ? (j == wa ? -4 : -2) : 0;        // deletion onto base j
@@ -288,19 +297,20 @@ __global__ __launch_bounds__(WAVE, joint_waves(R, DIR)) void k_joint_sweep(int n
                     Hup_prev -= 4;
                 }
             } else {
-                const int p = lenR - 1 - j;                                  // forward position inside R
-                const bool inw = p < wr && p >= 0;
+                const int p = lenR - 1 - j;                                  // forward position inside R (EXT: < 0 inside u2^k2)
+                const bool real = EXT ? j < ncols : p >= 0;                  // a template column, not pipeline padding
+                const bool inw = p < wr && real;
                 pe = inw ? 2 : 0; pn = inw ? -4 : 0;
                 eo = inw ? -4 : 0; ex = inw ? (p == wr - 1 ? -4 : -2) : 0;   // read backwards: first base met
-                const bool fin = p < wr - 1 && p >= 0;                       // insertion before R[p]
+                const bool fin = p < wr - 1 && real;                         // insertion before R[p] (or inside u2^k2)
                 fo = fin ? -4 : 0; fx = fin ? -2 : 0;
-                fo_prev = (p + 1 < wr - 1 && p + 1 >= 0) ? -4 : 0;
+                fo_prev = (p + 1 < wr - 1 && (EXT ? j - 1 < ncols : p + 1 >= 0)) ? -4 : 0;
             }
             const int fo1p = o1 + fo_prev;
             const int s_eq = sA + pe - fo1p, s_ne = sB + pn - fo1p, n_eq = sN + pe - fo1p, n_ne = sN + pn - fo1p;
             const int ex1 = x1 + ex, ex2 = x2 + ex;
             const int fo1 = o1 + fo, fx1 = x1 + fx, fx2 = x2 + fx;
-            const int dq = DIR == 0 ? eo - fo_prev : 0;                      // reverse: two columns at the window's edge
+            const int dq = !FWD ? eo - fo_prev : 0;                          // reverse: two columns at the window's edge
 #define NRA_SUBST(i, out)                                                                          \
             {                                                                                      \
                 const int qc_ = (int)((qcp[(i) >> 2] >> (8 * ((i) & 3))) & 0xffu);                 \
@@ -324,9 +334,9 @@ __global__ __launch_bounds__(WAVE, joint_waves(R, DIR)) void k_joint_sweep(int n
                     d_next = Hq[i] + sc;
                 }
                 // E(i,j) from column j-1, lazily: E_in stays in the register for the combine
-                const int ein = DIR == 0 ? imax(E[i] + ex1, Hq[i] + dq) : imax(E[i] + ex1, Hq[i]);
+                const int ein = !FWD ? imax(E[i] + ex1, Hq[i] + dq) : imax(E[i] + ex1, Hq[i]);
                 const int hq2_prev = KEEP_HQ2 ? Hq2[i] : Hq[i] + o21;
-                const int e2in = DIR == 0 ? imax(E2[i] + ex2, hq2_prev + dq) : imax(E2[i] + ex2, hq2_prev);
+                const int e2in = !FWD ? imax(E2[i] + ex2, hq2_prev + dq) : imax(E2[i] + ex2, hq2_prev);
                 h = imax(imax(d, ein), F);
                 h = imax(imax(h, e2in), F2);
                 if (i & 1) M = imax(imax(M, h_prev), h);                     // two rows per 3-input max
@@ -363,6 +373,17 @@ __global__ __launch_bounds__(WAVE, joint_waves(R, DIR)) void k_joint_sweep(int n
                         s3[0] = Hq[i] - fo1; s3[1] = E[i]; s3[2] = E2[i];
                     }
                 }
+            } else if ((EXT || MID) && (tt & JFLAG_SNAPSHOT)) {
+                // the lane's rows as they stand on a junction column: planes [H | E_in | E2_in] of Q rows.  EXT: slot
+                // nsnap (the lane's own count of boundaries passed) of the read's k2 list, H without the vertical open;
+                // MID: the one slot of this (read, k1), values as the junction combine takes them
+                int32_t* dst = EXT ? snap + tk.state + (size_t)nsnap * 3 * Q : snap + tk.pstate;
+#pragma unroll
+                for (int i = 0; i < R; ++i) {
+                    const int a = lane * R + i;
+                    if (a < Q) { dst[a] = EXT ? Hq[i] - fo1 : Hq[i]; dst[Q + a] = E[i]; dst[2 * Q + a] = E2[i]; }
+                }
+                ++nsnap;
             }
             Hbot = Hq[R - 1]; Fout = F; F2out = F2;
             accS = imax(accS_in, tS);
@@ -371,6 +392,10 @@ __global__ __launch_bounds__(WAVE, joint_waves(R, DIR)) void k_joint_sweep(int n
             if (DIR != 1 && lane == last_lane && at_boundary) {
                 if (DIR == 0) {
                     read_a[tk.read] = accB;                  // best alignment inside R (packed)
+                } else if (EXT) {
+                    read_a[tk.out + ncur++] = accB;          // A(k2): best alignment inside u2^k2 + R
+                } else if (MID) {
+                    read_a[tk.out] = accB;                   // B(k1): best alignment inside L + u1^k1 + mid
                 } else {
                     const int n = ncur++;
                     const int A = read_a[tk.read];
@@ -521,6 +546,105 @@ extern "C" int nra_launch_joint_tail(int R, int has_n, hipStream_t st, int n_tas
 {
     return launch_joint<2>(R, has_n, st, n_tasks, tasks, reads, regions, pool, q2bit, qnmask, sp, nullptr, state,
                            snap, read_a, cell_score, cell_wscore, nullptr);
+}
+#endif
+#if NRA_HAS_PART(20)
+extern "C" int nra_launch_joint_bwd_ext(int R, int has_n, hipStream_t st, int n_tasks, const NraJointTask* tasks,
+                                        const NraDevRead* reads, const NraDevRegion* regions, const uint8_t* pool,
+                                        const uint32_t* q2bit, const uint32_t* qnmask, NraScoreParams sp,
+                                        int32_t* rsnap, int32_t* ra, const int32_t* pstate)
+{
+    return launch_joint<3>(R, has_n, st, n_tasks, tasks, reads, regions, pool, q2bit, qnmask, sp, nullptr, nullptr,
+                           rsnap, ra, nullptr, nullptr, pstate);
+}
+#endif
+#if NRA_HAS_PART(21)
+extern "C" int nra_launch_joint_mid(int R, int has_n, hipStream_t st, int n_tasks, const NraJointTask* tasks,
+                                    const NraDevRead* reads, const NraDevRegion* regions, const uint8_t* pool,
+                                    const uint32_t* q2bit, const uint32_t* qnmask, NraScoreParams sp,
+                                    int32_t* state, int32_t* fsnap, int32_t* fb)
+{
+    return launch_joint<4>(R, has_n, st, n_tasks, tasks, reads, regions, pool, q2bit, qnmask, sp, nullptr, state,
+                           fsnap, fb, nullptr, nullptr, nullptr);
+}
+
+// ------------------------------------------------------------------------------------
+// k_joint_combine: the cells of a routed grid from the column states on either side of the junction at the end of mid.
+// One wave per read; rows across the lanes (row = 64*t + lane: coalesced plane loads).  Cell (k1_i, k2_n):
+//   S = max over rows r of  Hq_f(r) + H_b(a) - fo1_win,  E_f(r) + E_b(a) + (q, +2),  E2_f(r) + E2_b(a) + (q2, +2),   a = Q-2-r
+//   V = max(S, B(k1_i), A(k2_n))  ->  score, window score        (the arithmetic of k_joint_sweep's tail combine)
+__global__ __launch_bounds__(WAVE) void k_joint_combine(int n_tasks, const NraJointCombineTask* __restrict__ tasks,
+                                                        const NraDevRead* __restrict__ reads, NraScoreParams sp,
+                                                        const int32_t* __restrict__ fsnap,
+                                                        const int32_t* __restrict__ rsnap,
+                                                        const int32_t* __restrict__ fb, const int32_t* __restrict__ ra,
+                                                        int32_t* __restrict__ cell_score,
+                                                        int32_t* __restrict__ cell_wscore)
+{
+    const int task = blockIdx.x;
+    if (task >= n_tasks) return;
+    const int lane = threadIdx.x;
+    const NraJointCombineTask tk = tasks[task];
+    const int Q = reads[tk.read].qlen;
+    const int o1 = -(sp.open1 << 16);
+    const int fo1_win = o1 - 4;
+    const int q1 = (sp.open1 - sp.ext1) << 16, q2 = (sp.open2 - sp.ext2) << 16;
+    const int cH = -JBIAS - fo1_win, cE = -JBIAS + q1 + 2, cE2 = -JBIAS + q2 + 2;      // as the tail sweep's prologue
+    const int lo = sp.min_score > 1 ? sp.min_score : 1;
+    // rows in chunks of 4 per lane (256 rows): the R side of a chunk stays in registers for all k1 of a k2, the twelve
+    // loads of a cell's chunk are independent (the loop is latency-bound otherwise: 19 dependent trips per cell)
+    constexpr int CH = 4;
+    __shared__ int part[64];                                  // running S of the cells (k1) of the current k2, per k1 < 64
+    for (int n = 0; n < tk.n2; ++n) {
+        const int32_t* __restrict__ rs = rsnap + tk.rs + (size_t)n * 3 * Q;
+        const int A = ra[tk.ra + n];
+        for (int i0 = 0; i0 < tk.n1; i0 += 64) {              // (grids with more than 64 k1 values per read: in rounds)
+            const int ni = imin(64, tk.n1 - i0);
+            if (lane < ni) part[lane] = JNEG;
+            for (int r0 = 0; r0 < Q - 1; r0 += 64 * CH) {
+                int hb[CH], eb[CH], e2b[CH];
+#pragma unroll
+                for (int c = 0; c < CH; ++c) {
+                    const int r = r0 + 64 * c + lane;
+                    const bool ok = r < Q - 1;                // row Q-1 has no partner on the R side
+                    const int a = ok ? Q - 2 - r : 0;
+                    hb[c] = ok ? rs[a] + cH : JNEG; eb[c] = ok ? rs[Q + a] + cE : JNEG; e2b[c] = ok ? rs[2 * Q + a] + cE2 : JNEG;
+                }
+                for (int i = 0; i < ni; ++i) {
+                    const int32_t* __restrict__ fs = fsnap + tk.fs + (size_t)(i0 + i) * 3 * Q;
+                    int tS = JNEG;
+#pragma unroll
+                    for (int c = 0; c < CH; ++c) {
+                        const int r = r0 + 64 * c + lane;
+                        const int rr = r < Q ? r : 0;
+                        tS = imax(imax(tS, fs[rr] + hb[c]), imax(fs[Q + rr] + eb[c], fs[2 * Q + rr] + e2b[c]));
+                    }
+#pragma unroll
+                    for (int off = 32; off > 0; off >>= 1) tS = imax(tS, __shfl_xor(tS, off, 64));
+                    if (lane == 0) part[i] = imax(part[i], tS);
+                }
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            if (lane < ni) {
+                const int V = imax(imax(part[lane], fb[tk.fb + i0 + lane]), A);
+                const int scv = V >> 16;
+                const int idx = tk.out + (i0 + lane) * tk.n2 + n;
+                if (scv >= lo) { cell_score[idx] = scv; cell_wscore[idx] = (V & 0xffff) - JBIAS; }
+                else { cell_score[idx] = -1; cell_wscore[idx] = 0; }
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        }
+    }
+}
+
+extern "C" int nra_launch_joint_combine(hipStream_t st, int n_tasks, const NraJointCombineTask* tasks,
+                                        const NraDevRead* reads, NraScoreParams sp, const int32_t* fsnap,
+                                        const int32_t* rsnap, const int32_t* fb, const int32_t* ra,
+                                        int32_t* cell_score, int32_t* cell_wscore)
+{
+    if (n_tasks <= 0) return 0;
+    k_joint_combine<<<n_tasks, WAVE, 0, st>>>(n_tasks, tasks, reads, sp, fsnap, rsnap, fb, ra, cell_score, cell_wscore);
+    return (int)hipGetLastError();
 }
 #endif
 #if NRA_HAS_PART(17)

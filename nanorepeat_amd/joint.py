@@ -321,7 +321,7 @@ class GridSession:
     waits for the device.  That hid the host's share of a round when the cell lists were built in numpy (round 2
     of the build: 12 of 22 ms); with the routing in the library (`nra_batch2d_set_grid`) one group is faster."""
 
-    def __init__(self, region, fastq_dict, device=0, scoring=None, scorer=None, parts=None):
+    def __init__(self, region, fastq_dict, device=0, scoring=None, scorer=None, parts=None, flags=0):
         self.region = region
         self.names = list(fastq_dict)
         self.device, self.scoring, self.scorer = device, scoring, scorer
@@ -333,7 +333,7 @@ class GridSession:
         if parts > 1:
             from concurrent.futures import ThreadPoolExecutor
             cuts = [len(self.names) * p // parts for p in range(parts + 1)]
-            self.subs = [GridSession(region, {n: fastq_dict[n] for n in self.names[a:b]}, device, scoring, scorer, parts=1)
+            self.subs = [GridSession(region, {n: fastq_dict[n] for n in self.names[a:b]}, device, scoring, scorer, parts=1, flags=flags)
                          for a, b in zip(cuts[:-1], cuts[1:])]
             self.pool = ThreadPoolExecutor(max_workers=parts, thread_name_prefix="nra-grid")
             import threading
@@ -344,7 +344,7 @@ class GridSession:
         self.index = {n: i for i, n in enumerate(self.names)}
         self.reads = [_read_seq(fastq_dict[n]) for n in self.names]
         if scorer is None:
-            self.batch = _capi.Batch.create_2d_reads(region, self.reads, sc=scoring, device=device)
+            self.batch = _capi.Batch.create_2d_reads(region, self.reads, sc=scoring, flags=flags, device=device)
 
     @property
     def rounds(self):
