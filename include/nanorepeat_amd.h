@@ -64,6 +64,9 @@ extern "C" {
 #define NRA_F_JOINT_TAILS 256  /* testing / comparison, 2D routed grids: junction at R[0] and one tail sweep over mid + unit2^k2 per
                                  (read, k1) -- what explicit cell lists use -- instead of the junction at the end of mid (extended
                                  reverse sweeps, MID sweeps, k_joint_combine) */
+#define NRA_F_JOINT_NO_CHAIN 512 /* testing / comparison, 2D routed grids: the MID part (last prefix column + mid) as one systolic sweep per
+                                 (read, k1) resuming from the prefix sweep's wave state, instead of column-parallel scans
+                                 (k_joint_midscan) on the column states the prefix sweep leaves */
 #define NRA_F_BRUTE_FORCE  4  /* score the K candidates of a read as K independent alignments
                                  (k_score_pk16) instead of the junction decomposition (k_sweep_pk16) */
 

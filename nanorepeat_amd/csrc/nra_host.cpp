@@ -459,6 +459,7 @@ struct nra_batch {
     DevBuf<int32_t> jfs, jrs, jfb, jra;
     DevBuf<NraJointCombineTask> jcomb_tasks;
     bool joint_v2 = false, joint_v2_prev = false;
+    bool joint_chain = false;                   // ... with the MID part as column-parallel scans on column states (k_joint_midscan)
     std::vector<JointGroup> jgroups;
     bool all_strands_given = false;             // 2D: every read came with its strand, no probe needed
     int chain_cap = 0;
@@ -1807,6 +1808,7 @@ int set_cells_common(nra_batch* b, const int8_t* read_strand, int64_t n_cells, c
     // a routed grid: every read's cells are a full product (k1 values) x (one k2 progression) -> junction at the end
     // of mid.  The state kept from earlier cell lists differs between the two forms: switching drops it.
     b->joint_v2 = grid != nullptr && !b->brute && (flags & NRA_F_JOINT_TAILS) == 0;
+    b->joint_chain = b->joint_v2 && (flags & NRA_F_JOINT_NO_CHAIN) == 0;
     if (b->joint_v2 != b->joint_v2_prev) {
         std::fill(b->rev_strand.begin(), b->rev_strand.end(), (int8_t)0);
         b->joint_v2_prev = b->joint_v2;
@@ -2008,6 +2010,14 @@ int set_cells_common(nra_batch* b, const int8_t* read_strand, int64_t n_cells, c
                     // read's combine task: n1 x n2 cells from the column states on either side of the junction
                     const GridRow& gr = grid->rows[(size_t)r];
                     const uint64_t q3 = (uint64_t)3 * (uint64_t)reads[r].qlen;
+                    if (b->joint_chain) {
+                        // the MID part of all the read's k1 in one wave, column by column (k_joint_midscan)
+                        NraJointTask t{}; t.read = r; t.k1_off = tp.k1_off; t.nk1 = tp.nk1; t.k2step = 1;
+                        t.out = (int32_t)fb_total; t.state = used; t.pstate = fs_total;
+                        jtail.push_back(t);
+                        bk.cells_sweep += (int64_t)64 * bk.R * gr.n1 * (1 + d.l2);
+                        bk.cells_sweep += (int64_t)64 * bk.R * (1 + std::min(63, std::max(reads[r].qlen - 1, 0) / bk.R));   // the prefix sweep's own drain
+                    } else
                     for (int32_t i = 0; i < gr.n1; ++i) {
                         NraJointTask t{}; t.read = r; t.k1 = ks[(size_t)i]; t.k2step = 1;
                         t.out = (int32_t)(fb_total + i);
@@ -2282,6 +2292,11 @@ int run_2d(nra_batch* b)
             for (const JointGroup& g : b->jgroups) {
                 if (g.bucket != (int)i) continue;
                 HIP_TRY(hipEventRecord(b->ev[ev++], qb));
+                if (b->joint_chain)
+                    LAUNCH_TRY(nra_launch_joint_prefix_cols(g.R, b->has_n, qb, g.n_pre, b->jpre_tasks.p + g.pre_off,
+                                                            b->reads.p, b->regions.p, b->pool.p, b->q2bit.p, b->qnmask.p,
+                                                            b->sp, b->jk1list.p, b->jstate.p, b->jlstate.p));
+                else
                 LAUNCH_TRY(nra_launch_joint_prefix(g.R, b->has_n, qb, g.n_pre, b->jpre_tasks.p + g.pre_off,
                                                    b->reads.p, b->regions.p, b->pool.p, b->q2bit.p, b->qnmask.p,
                                                    b->sp, b->jk1list.p, b->jstate.p, b->jlstate.p));
@@ -2290,7 +2305,11 @@ int run_2d(nra_batch* b)
                 if (first && !b->joint_v2) HIP_TRY(hipStreamWaitEvent(qb, b->bdone[3 * i], 0));     // the tails read the R side
                 first = false;
                 HIP_TRY(hipEventRecord(b->ev[ev++], qb));
-                if (b->joint_v2)
+                if (b->joint_chain)
+                    LAUNCH_TRY(nra_launch_joint_midscan(g.R, b->has_n, qb, g.n_tail, b->jtail_tasks.p + g.tail_off,
+                                                         b->reads.p, b->regions.p, b->pool.p, b->q2bit.p, b->qnmask.p,
+                                                         b->sp, b->jk1list.p, b->jstate.p, b->jfs.p, b->jfb.p));
+                else if (b->joint_v2)
                     LAUNCH_TRY(nra_launch_joint_mid(g.R, b->has_n, qb, g.n_tail, b->jtail_tasks.p + g.tail_off,
                                                     b->reads.p, b->regions.p, b->pool.p, b->q2bit.p, b->qnmask.p,
                                                     b->sp, b->jstate.p, b->jfs.p, b->jfb.p));

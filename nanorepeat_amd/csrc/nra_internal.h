@@ -153,6 +153,9 @@ struct NraScoreParams {
 // int32 values per lane in one dumped wave state of the 2D prefix sweep (3 per row + 7), shared by
 // the kernel and the host so that the two cannot disagree
 #define NRA_JOINT_NSTATE(R) (3 * (R) + 7)
+// a COLUMN state of the prefix sweep (DIR 5, for k_joint_midscan) lives in the same slot, lane-major: per lane
+// [Hq | E_in | E2_in | Hup_prev, M] padded to 16-byte pieces (<= 3R + 5 < NSTATE dwords)
+#define NRA_JOINT_COLSTATE(R) ((3 * (R) + 2 + 3) / 4 * 4)
 // wave states of one group of 2D prefix sweeps: at most this many int32 (16 GiB)
 #define NRA_JOINT_STATE_CAP_INTS (4ull << 30)
 #define NRA_MAX_TLEN 65000     // int32 payload cells: tstart is 16 bits; + 64 pipeline columns
@@ -302,6 +305,15 @@ int nra_launch_joint_mid(int R, int has_n, hipStream_t st, int n_tasks, const Nr
                          const NraDevRead* reads, const NraDevRegion* regions, const uint8_t* pool,
                          const uint32_t* q2bit, const uint32_t* qnmask, NraScoreParams sp,
                          int32_t* state, int32_t* fsnap, int32_t* fb);
+// ... with the MID part as column-parallel scans (k_joint_midscan): the prefix sweep leaves column states (each lane on its own step)
+int nra_launch_joint_prefix_cols(int R, int has_n, hipStream_t st, int n_tasks, const NraJointTask* tasks,
+                                 const NraDevRead* reads, const NraDevRegion* regions, const uint8_t* pool,
+                                 const uint32_t* q2bit, const uint32_t* qnmask, NraScoreParams sp,
+                                 const int32_t* k1list, int32_t* state, const int32_t* pstate);
+int nra_launch_joint_midscan(int R, int has_n, hipStream_t st, int n_tasks, const NraJointTask* tasks,
+                             const NraDevRead* reads, const NraDevRegion* regions, const uint8_t* pool,
+                             const uint32_t* q2bit, const uint32_t* qnmask, NraScoreParams sp,
+                             const int32_t* k1list, const int32_t* state, int32_t* fsnap, int32_t* fb);
 int nra_launch_joint_combine(hipStream_t st, int n_tasks, const NraJointCombineTask* tasks, const NraDevRead* reads,
                              NraScoreParams sp, const int32_t* fsnap, const int32_t* rsnap, const int32_t* fb,
                              const int32_t* ra, int32_t* cell_score, int32_t* cell_wscore);

@@ -76,7 +76,8 @@ __device__ __forceinline__ int oriented_code(const NraDevRead& rd, const uint32_
 // Without the hint the compiler spends every register its occupancy bracket has (R = 18: 239).
 // DIR: 0 reverse sweep over rev(R); 1 prefix sweep; 2 tail sweep; 3 reverse sweep extended over rev(u2)^k2hi with a
 // column state per k2 (junction at the end of mid); 4 MID sweep (a tail that stops at the end of mid and leaves its
-// column state).
+// column state); 5 prefix sweep that leaves COLUMN states -- every lane its registers as it is about to take the last
+// column of L + u1^k1, on its own step -- for k_joint_midscan, which takes the MID part column by column.
 constexpr int joint_waves(int R, int DIR)
 {
     const int need = (DIR == 2 ? 7 : 4) * R + 70;
@@ -100,9 +101,10 @@ __global__ __launch_bounds__(WAVE, joint_waves(R, DIR)) void k_joint_sweep(int n
                                                       int32_t* __restrict__ cell_wscore,
                                                       const int32_t* __restrict__ pstate)   // DIR 0 / 1: packed states
 {
-    constexpr bool FWD = DIR == 1 || DIR == 2 || DIR == 4;      // read vs the template left to right
+    constexpr bool FWD = DIR == 1 || DIR == 2 || DIR >= 4;      // read vs the template left to right
     constexpr bool TAIL = DIR == 2 || DIR == 4;                 // resumes from a prefix sweep's wave state
     constexpr bool EXT = DIR == 3, MID = DIR == 4;
+    constexpr bool PRE = DIR == 1 || DIR == 5, COLPRE = DIR == 5;
     const int task = blockIdx.x;
     if (task >= n_tasks) return;
     const int lane = threadIdx.x;
@@ -120,9 +122,11 @@ __global__ __launch_bounds__(WAVE, joint_waves(R, DIR)) void k_joint_sweep(int n
     const uint8_t* __restrict__ p2 = pool + rg.p2_off;
     const int t0 = TAIL ? rg.l1 + rg.m1 * tk.k1 - 1 : 0;                       // real column of v = 0
     int si = 0;                                                                // DIR 1: next dump
-    int next_t = DIR == 1 ? rg.l1 + rg.m1 * k1list[tk.k1_off] - 1 : -1;
-    const int t_last = DIR == 1 ? rg.l1 + rg.m1 * k1list[tk.k1_off + tk.nk1 - 1] - 1 : 0;
-    const int ncols = DIR == 0 ? lenR : DIR == 1 ? t_last : MID ? 1 + rg.l2
+    auto t0_of = [&](int i) { return rg.l1 + rg.m1 * k1list[tk.k1_off + i] - 1; };   // last column of L + u1^k1_i
+    int next_t = PRE ? t0_of(0) : -1;
+    const int t_last = PRE ? t0_of(tk.nk1 - 1) : 0;
+    const int cmid = 1 + rg.l2;                                                // columns of a MID sweep
+    const int ncols = DIR == 0 ? lenR : PRE ? t_last : MID ? cmid
                       : (EXT ? lenR - 1 : rg.l2) + 1 + rg.m2 * (tk.k2lo + tk.k2step * (tk.n2 - 1));
     const int vfirst = (EXT ? lenR - 1 : rg.l2) + rg.m2 * tk.k2lo;             // DIR 2 / 3: first boundary
     const int vstep = rg.m2 * tk.k2step;
@@ -238,7 +242,8 @@ __global__ __launch_bounds__(WAVE, joint_waves(R, DIR)) void k_joint_sweep(int n
     // One flat step loop (a chunk loop around a 64-step loop made the compiler keep two copies of
     // the row registers).  Every 64 steps the lanes fetch the next 64 template columns.
     const int last_lane = imin(63, imax(Q - 1, 0) / R);
-    const int nsteps = DIR == 1 ? ncols + 1 : ncols + last_lane;
+    const int nsteps = DIR == 1 ? ncols + 1 : COLPRE ? ncols + last_lane + 1 : ncols + last_lane;
+    int my_next = COLPRE && lane <= last_lane ? next_t + lane : 0x7fffffff;    // COLPRE: the step of this lane's next dump
     int feed = NRA_PAD_T;
 #pragma unroll 1   // unrolling the step loop twice takes minutes to compile at R >= 20
     for (int step = step0; step < nsteps; ++step) {
@@ -270,6 +275,21 @@ __global__ __launch_bounds__(WAVE, joint_waves(R, DIR)) void k_joint_sweep(int n
                     sv[(size_t)(3 * R + 5) * 64] = accB; sv[(size_t)(3 * R + 6) * 64] = tt;
                     if (++si >= tk.nk1) break;
                     next_t = rg.l1 + rg.m1 * k1list[tk.k1_off + si] - 1;
+                }
+            }
+            if (COLPRE) {
+                if (step == my_next) {               // this lane is about to take the last column of L + u1^k1: its column state
+                    // lane-major, 16-byte pieces: [Hq | E_in | E2_in | Hup_prev, M] (one lane stores per step: wide stores)
+                    constexpr int N4 = NRA_JOINT_COLSTATE(R) / 4;
+                    int4* __restrict__ sv = reinterpret_cast<int4*>(state + tk.state + (size_t)si * (NSTATE * 64) + (size_t)lane * (4 * N4));
+                    int v[4 * N4];
+#pragma unroll
+                    for (int i = 0; i < 4 * N4; ++i)
+                        v[i] = i < R ? Hq[i] : i < 2 * R ? E[i - R] : i < 3 * R ? E2[i - 2 * R] : i == 3 * R ? Hup_prev : i == 3 * R + 1 ? M : 0;
+#pragma unroll
+                    for (int i = 0; i < N4; ++i) sv[i] = make_int4(v[4 * i], v[4 * i + 1], v[4 * i + 2], v[4 * i + 3]);
+                    ++si;
+                    my_next = si < tk.nk1 ? t0_of(si) + lane : 0x7fffffff;
                 }
             }
             int F = dpp_shr1(fresh, Fout);
@@ -389,7 +409,7 @@ __global__ __launch_bounds__(WAVE, joint_waves(R, DIR)) void k_joint_sweep(int n
             accS = imax(accS_in, tS);
             accB = imax(accB_in, M);
 
-            if (DIR != 1 && lane == last_lane && at_boundary) {
+            if (!PRE && lane == last_lane && at_boundary) {
                 if (DIR == 0) {
                     read_a[tk.read] = accB;                  // best alignment inside R (packed)
                 } else if (EXT) {
@@ -546,6 +566,179 @@ extern "C" int nra_launch_joint_tail(int R, int has_n, hipStream_t st, int n_tas
 {
     return launch_joint<2>(R, has_n, st, n_tasks, tasks, reads, regions, pool, q2bit, qnmask, sp, nullptr, state,
                            snap, read_a, cell_score, cell_wscore, nullptr);
+}
+#endif
+// ------------------------------------------------------------------------------------
+// k_joint_midscan: the MID part of a routed grid -- the last prefix column and `mid`, 1 + |mid| columns per (read, k1) --
+// column by column with ALL rows at once instead of as a systolic sweep (whose pipeline fill and drain, one step per
+// lane, are four fifths of a 14-column sweep).  One wave per read, its k1 values in turn; lane l holds rows
+// [l*R, l*R+R).  Input: the column states the prefix sweep left (DIR 5: every lane's registers as it is about to
+// take the last column of L + u1^k1); output: the column state at the end of mid (for k_joint_combine) and B(k1).
+//
+// A column: the diagonal and the two horizontal-gap states are row-local (the row above is one register or one DPP
+// move away); the two vertical-gap states are max-plus recurrences down the rows,
+//     F(g) = max(F(g-1) + fx, Hn(g-1) + fo [, floor]),     Hn = max(diagonal, E, E2)  (the cell without its vertical gaps)
+// -- H(g-1) in place of Hn(g-1) adds only "a vertical gap right after a vertical gap", which a single gap of the
+// cheaper-to-extend piece beats strictly -- and so prefix maxima:  F(g) = fx*(g-1) + max_{k<g} (Hn(k) + fo - fx*k):
+// an in-lane running maximum, one exclusive scan across the lanes (DPP row shifts and broadcasts), two adds.
+__device__ __forceinline__ int scan_excl_max(int x)        // exclusive prefix maximum across the 64 lanes (lane 0: JNEG * 2)
+{
+    const int NEG = 2 * JNEG;
+    x = imax(x, __builtin_amdgcn_update_dpp(NEG, x, 0x111 /*row_shr:1*/, 0xf, 0xf, false));
+    x = imax(x, __builtin_amdgcn_update_dpp(NEG, x, 0x112 /*row_shr:2*/, 0xf, 0xf, false));
+    x = imax(x, __builtin_amdgcn_update_dpp(NEG, x, 0x114 /*row_shr:4*/, 0xf, 0xf, false));
+    x = imax(x, __builtin_amdgcn_update_dpp(NEG, x, 0x118 /*row_shr:8*/, 0xf, 0xf, false));
+    x = imax(x, __builtin_amdgcn_update_dpp(NEG, x, 0x142 /*row_bcast:15*/, 0xa, 0xf, false));
+    x = imax(x, __builtin_amdgcn_update_dpp(NEG, x, 0x143 /*row_bcast:31*/, 0xc, 0xf, false));
+    return __builtin_amdgcn_update_dpp(NEG, x, 0x138 /*wave_shr:1*/, 0xf, 0xf, false);
+}
+
+template <int R, bool HAS_N>
+__global__ __launch_bounds__(WAVE) void k_joint_midscan(int n_tasks, const NraJointTask* __restrict__ tasks,
+                                                        const NraDevRead* __restrict__ reads,
+                                                        const NraDevRegion* __restrict__ regions,
+                                                        const uint8_t* __restrict__ pool,
+                                                        const uint32_t* __restrict__ q2bit,
+                                                        const uint32_t* __restrict__ qnmask, NraScoreParams sp,
+                                                        const int32_t* __restrict__ k1list,
+                                                        const int32_t* __restrict__ state,
+                                                        int32_t* __restrict__ fsnap, int32_t* __restrict__ fb)
+{
+    const int task = blockIdx.x;
+    if (task >= n_tasks) return;
+    const int lane = threadIdx.x;
+    const NraJointTask tk = tasks[task];
+    const NraDevRead rd = reads[tk.read];
+    const NraDevRegion rg = regions[rd.region];
+    const int Q = rd.qlen;
+    const uint8_t* __restrict__ p1 = pool + rg.p1_off;
+    const uint8_t* __restrict__ p2 = pool + rg.p2_off;
+    const int wa = imax(0, rg.l1 - 10);
+    const int cmid = 1 + rg.l2;
+    constexpr int NSTATE = NRA_JOINT_NSTATE(R);
+    const int last_lane = imin(63, imax(Q - 1, 0) / R);
+
+    uint32_t qcp[(R + 3) / 4];
+#pragma unroll
+    for (int i = 0; i < (R + 3) / 4; ++i) qcp[i] = 0;
+#pragma unroll
+    for (int i = 0; i < R; ++i)
+        qcp[i >> 2] |= (uint32_t)oriented_code<HAS_N>(rd, q2bit, qnmask, lane * R + i) << (8 * (i & 3));
+
+    const int sA = sp.match << 16, sB = -(sp.mismatch << 16), sN = -(sp.ambi << 16);
+    const int o1 = -(sp.open1 << 16), x1 = -(sp.ext1 << 16);
+    const int o2 = -(sp.open2 << 16), x2 = -(sp.ext2 << 16);
+    const int fresh = JBIAS;
+    const int o21 = o2 - o1;
+    const int g0 = lane * R;                                  // the lane's first row
+
+    for (int s = 0; s < tk.nk1; ++s) {
+        const int t0 = rg.l1 + rg.m1 * k1list[tk.k1_off + s] - 1;
+        constexpr int N4 = NRA_JOINT_COLSTATE(R) / 4;
+        const int4* __restrict__ sv = reinterpret_cast<const int4*>(state + tk.state + (size_t)s * (NSTATE * 64) + (size_t)lane * (4 * N4));
+        int cs[4 * N4];
+#pragma unroll
+        for (int i = 0; i < N4; ++i) { const int4 q = sv[i]; cs[4 * i] = q.x; cs[4 * i + 1] = q.y; cs[4 * i + 2] = q.z; cs[4 * i + 3] = q.w; }
+        int Hq[R], E[R], E2[R];
+#pragma unroll
+        for (int i = 0; i < R; ++i) { Hq[i] = cs[i]; E[i] = cs[R + i]; E2[i] = cs[2 * R + i]; }
+        int Hup = cs[3 * R], M = cs[3 * R + 1];
+        int fo1_last = o1;
+        for (int v = 0; v < cmid; ++v) {
+            const int j = t0 + v;
+            const int tcode = v == 0 ? p1[t0] : p2[v - 1];
+            // window payload of this column (k_joint_sweep, forward rules)
+            const bool inw = j >= wa;
+            const int pe = inw ? 2 : 0, pn = inw ? -4 : 0;
+            const int ex = inw ? (j == wa ? -4 : -2) : 0;
+            const int fo = inw ? -4 : 0, fx = inw ? -2 : 0;
+            const int fo_prev = inw ? -4 : 0;
+            // the diagonal of the lane's first row: H of the row above it in the PREVIOUS column = the last row of the lane
+            // above as it stands now (the first column's comes with the column state; above the read H = 0)
+            if (v > 0) Hup = dpp_shr1(fresh + fo1_last, Hq[R - 1]);
+            if (j == wa) {
+#pragma unroll
+                for (int i = 0; i < R; ++i) Hq[i] -= 4;
+                Hup -= 4;
+            }
+            const int fo1p = o1 + fo_prev;
+            const int s_eq = sA + pe - fo1p, s_ne = sB + pn - fo1p, n_eq = sN + pe - fo1p, n_ne = sN + pn - fo1p;
+            const int ex1 = x1 + ex, ex2 = x2 + ex;
+            const int fo1 = o1 + fo, fo2 = fo1 + o21, fx1 = x1 + fx, fx2 = x2 + fx;
+            int hn[R];
+            int run1 = 2 * JNEG, run2 = 2 * JNEG;                      // in-lane running maxima of Hn(k) + fo - fx*k
+            int c1[R], c2[R];
+            int d = Hup;
+#pragma unroll
+            for (int i = 0; i < R; ++i) {
+                const int qc_ = (int)((qcp[i >> 2] >> (8 * (i & 3))) & 0xffu);
+                const bool eq_ = qc_ == tcode;
+                int sc = eq_ ? s_eq : s_ne;
+                if (HAS_N) { if ((qc_ | tcode) & 4) sc = eq_ ? n_eq : n_ne; }
+                const int dd = d + sc;
+                d = Hq[i];                                             // the diagonal of the row below: H(i, j-1)
+                const int ein = imax(E[i] + ex1, Hq[i]);
+                const int e2in = imax(E2[i] + ex2, Hq[i] + o21);
+                E[i] = ein; E2[i] = e2in;
+                hn[i] = imax(imax(dd, ein), e2in);
+                c1[i] = run1; c2[i] = run2;                            // maxima over the lane's rows ABOVE row i
+                run1 = imax(run1, hn[i] + fo1 - fx1 * (g0 + i));
+                run2 = imax(run2, hn[i] + fo2 - fx2 * (g0 + i));
+            }
+            fo1_last = fo1;
+            const int above1 = scan_excl_max(run1), above2 = scan_excl_max(run2);     // ... over the rows of the lanes above
+#pragma unroll
+            for (int i = 0; i < R; ++i) {
+                const int g = g0 + i;
+                const int F = imax(fresh, imax(above1, c1[i]) + fx1 * (g - 1));
+                const int F2 = imax(above2, c2[i]) + fx2 * (g - 1);
+                const int h = imax(imax(hn[i], F), F2);
+                M = imax(M, h);
+                Hq[i] = h + fo1;
+            }
+        }
+        // the column state at the end of mid, planes [Hq | E_in | E2_in] of Q rows, and B(k1)
+        int32_t* __restrict__ fs = fsnap + tk.pstate + (size_t)s * 3 * Q;
+#pragma unroll
+        for (int i = 0; i < R; ++i) {
+            const int a = g0 + i;
+            if (a < Q) { fs[a] = Hq[i]; fs[Q + a] = E[i]; fs[2 * Q + a] = E2[i]; }
+        }
+        int best = lane <= last_lane ? M : 2 * JNEG;
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) best = imax(best, __shfl_xor(best, off, 64));
+        if (lane == 0) fb[tk.out + s] = best;
+    }
+}
+
+#if NRA_HAS_PART(22)
+extern "C" int nra_launch_joint_prefix_cols(int R, int has_n, hipStream_t st, int n_tasks, const NraJointTask* tasks,
+                                            const NraDevRead* reads, const NraDevRegion* regions, const uint8_t* pool,
+                                            const uint32_t* q2bit, const uint32_t* qnmask, NraScoreParams sp,
+                                            const int32_t* k1list, int32_t* state, const int32_t* pstate)
+{
+    return launch_joint<5>(R, has_n, st, n_tasks, tasks, reads, regions, pool, q2bit, qnmask, sp, k1list, state,
+                           nullptr, nullptr, nullptr, nullptr, pstate);
+}
+#endif
+#if NRA_HAS_PART(23)
+extern "C" int nra_launch_joint_midscan(int R, int has_n, hipStream_t st, int n_tasks, const NraJointTask* tasks,
+                                        const NraDevRead* reads, const NraDevRegion* regions, const uint8_t* pool,
+                                        const uint32_t* q2bit, const uint32_t* qnmask, NraScoreParams sp,
+                                        const int32_t* k1list, const int32_t* state, int32_t* fsnap, int32_t* fb)
+{
+    if (n_tasks <= 0) return 0;
+#define CASE(r)                                                                                     \
+    case r:                                                                                         \
+        if (has_n) k_joint_midscan<r, true><<<n_tasks, WAVE, 0, st>>>(n_tasks, tasks, reads, regions, pool, q2bit, qnmask, sp, k1list, state, fsnap, fb); \
+        else k_joint_midscan<r, false><<<n_tasks, WAVE, 0, st>>>(n_tasks, tasks, reads, regions, pool, q2bit, qnmask, sp, k1list, state, fsnap, fb);       \
+        break;
+    switch (R) {
+        NRA_R_LIST(CASE)
+    default: return (int)hipErrorInvalidValue;
+    }
+#undef CASE
+    return (int)hipGetLastError();
 }
 #endif
 #if NRA_HAS_PART(20)

@@ -378,23 +378,29 @@ def test_joint_routed_grid_equals_its_cell_list(capi, oracle):
               ((5, 1, 14), t1 - 1.5, t1 + 1.5, (1, 1, 8), t2 - 1 / 3, t2 + 2.5, strands),
               ((0, 4, 6), t1 - 8, t1 + 3, (0, 1, 9), np.where(np.arange(n) % 5 == 2, 99.0, t2 - 2), t2 + 2, None),
               ((3, 1, 20), t1 - 2, t1 + 2.5, (2, 1, 2), t2 - 9, t2 + 9, strands)]
+    # the three forms a routed grid can take: junction at the end of mid with a read's MID sweeps chained in one wave (the
+    # default), with one MID sweep per (read, k1), and the tail sweeps with the junction at R[0]
     with capi.Batch.create_2d_reads(j["region"], j["reads"]) as by_grid, \
+            capi.Batch.create_2d_reads(j["region"], j["reads"], flags=capi.F_JOINT_NO_CHAIN) as by_grid_mid, \
+            capi.Batch.create_2d_reads(j["region"], j["reads"], flags=capi.F_JOINT_TAILS) as by_grid_tails, \
             capi.Batch.create_2d_reads(j["region"], j["reads"]) as by_list:
         for a1, lo1, hi1, a2, lo2, hi2, st in rounds:
             grid = capi.Grid(a1, lo1, hi1, a2, lo2, hi2)
             cr, k1, k2 = capi.joint_grid_cells(grid)
-            assert by_grid.set_grid(grid, st) == len(cr) > 0
-            by_grid.run(); by_grid.sync()
-            g = by_grid.fetch()
-            by_list.set_cells(cr, k1, k2, st)
-            by_list.run(); by_list.sync()
-            l = by_list.fetch()
             o = oracle.joint_2d(j["region"], j["reads"], cr, k1, k2, read_strand=st)
             has = np.zeros(n, bool); has[cr] = True
-            for key in o:
-                sel = has if len(o[key]) == n else slice(None)
-                assert np.array_equal(np.asarray(g[key])[sel], np.asarray(o[key])[sel]), (a1, key)
-                assert np.array_equal(np.asarray(l[key])[sel], np.asarray(o[key])[sel]), (a1, key)
+            got = {}
+            for name, b in (("chained", by_grid), ("mid", by_grid_mid), ("tails", by_grid_tails)):
+                assert b.set_grid(grid, st) == len(cr) > 0
+                b.run(); b.sync()
+                got[name] = b.fetch()
+            by_list.set_cells(cr, k1, k2, st)
+            by_list.run(); by_list.sync()
+            got["list"] = by_list.fetch()
+            for name, g in got.items():
+                for key in o:
+                    sel = has if len(o[key]) == n else slice(None)
+                    assert np.array_equal(np.asarray(g[key])[sel], np.asarray(o[key])[sel]), (name, a1, key)
         # a grid that gives no read a cell is an empty round, not an error
         assert by_grid.set_grid(capi.Grid((0, 1, 4), t1 + 50, t1 + 60, (0, 1, 4), t2, t2 + 1), strands) == 0
 

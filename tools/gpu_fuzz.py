@@ -189,7 +189,8 @@ def fuzz_2d_grid(rng):
     t1 = np.array([t[0] for t in truth], np.float64); t2 = np.array([t[1] for t in truth], np.float64)
     strand = np.array(strand, np.int8)
     region = (L, u1, mid, u2, R)
-    with A.Batch.create_2d_reads(region, reads) as b:
+    flags = [0, A.F_JOINT_NO_CHAIN, A.F_JOINT_TAILS][int(rng.integers(0, 3))]
+    with A.Batch.create_2d_reads(region, reads, flags=flags) as b:
         for rnd in range(2):
             a1 = (int(rng.integers(0, 6)), int(rng.integers(1, 5)), int(rng.integers(1, 12)))
             a2 = (int(rng.integers(0, 4)), int(rng.integers(1, 4)), int(rng.integers(1, 10)))
@@ -209,7 +210,7 @@ def fuzz_2d_grid(rng):
             for k in K2:
                 sel = has if len(o[k]) == n else slice(None)
                 if not np.array_equal(np.asarray(g[k])[sel], np.asarray(o[k])[sel]):
-                    return dict(kind="2d-grid", round=rnd, key=k, region=region, reads=reads, grid=(a1, a2), bounds=[x.tolist() for x in (lo1, hi1, lo2, hi2)],
+                    return dict(kind="2d-grid", flags=flags, round=rnd, key=k, region=region, reads=reads, grid=(a1, a2), bounds=[x.tolist() for x in (lo1, hi1, lo2, hi2)],
                                 strands=None if st is None else st.tolist(), got=np.asarray(g[k]).tolist(), want=np.asarray(o[k]).tolist())
     return None
 
