@@ -784,16 +784,17 @@ __global__ __launch_bounds__(WAVE) void k_joint_combine(int n_tasks, const NraJo
     const int q1 = (sp.open1 - sp.ext1) << 16, q2 = (sp.open2 - sp.ext2) << 16;
     const int cH = -JBIAS - fo1_win, cE = -JBIAS + q1 + 2, cE2 = -JBIAS + q2 + 2;      // as the tail sweep's prologue
     const int lo = sp.min_score > 1 ? sp.min_score : 1;
-    // rows in chunks of 4 per lane (256 rows): the R side of a chunk stays in registers for all k1 of a k2, the twelve
-    // loads of a cell's chunk are independent (the loop is latency-bound otherwise: 19 dependent trips per cell)
-    constexpr int CH = 4;
-    __shared__ int part[64];                                  // running S of the cells (k1) of the current k2, per k1 < 64
+    // Rows in chunks of 4 per lane (256 rows), k1 values in blocks of 8: the R side of a chunk stays in registers for the
+    // block, the 96 loads of a (chunk, block) are independent (one dependent trip per cell and row group makes the loop
+    // latency-bound), a lane keeps its partial maxima of the block's cells and the wave reduces once per cell.
+    constexpr int CH = 4, IB = 8;
     for (int n = 0; n < tk.n2; ++n) {
         const int32_t* __restrict__ rs = rsnap + tk.rs + (size_t)n * 3 * Q;
         const int A = ra[tk.ra + n];
-        for (int i0 = 0; i0 < tk.n1; i0 += 64) {              // (grids with more than 64 k1 values per read: in rounds)
-            const int ni = imin(64, tk.n1 - i0);
-            if (lane < ni) part[lane] = JNEG;
+        for (int i0 = 0; i0 < tk.n1; i0 += IB) {
+            int tS[IB];
+#pragma unroll
+            for (int ii = 0; ii < IB; ++ii) tS[ii] = JNEG;
             for (int r0 = 0; r0 < Q - 1; r0 += 64 * CH) {
                 int hb[CH], eb[CH], e2b[CH];
 #pragma unroll
@@ -803,29 +804,31 @@ __global__ __launch_bounds__(WAVE) void k_joint_combine(int n_tasks, const NraJo
                     const int a = ok ? Q - 2 - r : 0;
                     hb[c] = ok ? rs[a] + cH : JNEG; eb[c] = ok ? rs[Q + a] + cE : JNEG; e2b[c] = ok ? rs[2 * Q + a] + cE2 : JNEG;
                 }
-                for (int i = 0; i < ni; ++i) {
-                    const int32_t* __restrict__ fs = fsnap + tk.fs + (size_t)(i0 + i) * 3 * Q;
-                    int tS = JNEG;
+#pragma unroll
+                for (int ii = 0; ii < IB; ++ii) {
+                    const int i = imin(i0 + ii, tk.n1 - 1);   // (past the last k1: the last one again, not written)
+                    const int32_t* __restrict__ fs = fsnap + tk.fs + (size_t)i * 3 * Q;
 #pragma unroll
                     for (int c = 0; c < CH; ++c) {
                         const int r = r0 + 64 * c + lane;
                         const int rr = r < Q ? r : 0;
-                        tS = imax(imax(tS, fs[rr] + hb[c]), imax(fs[Q + rr] + eb[c], fs[2 * Q + rr] + e2b[c]));
+                        tS[ii] = imax(imax(tS[ii], fs[rr] + hb[c]), imax(fs[Q + rr] + eb[c], fs[2 * Q + rr] + e2b[c]));
                     }
-#pragma unroll
-                    for (int off = 32; off > 0; off >>= 1) tS = imax(tS, __shfl_xor(tS, off, 64));
-                    if (lane == 0) part[i] = imax(part[i], tS);
                 }
             }
-            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-            if (lane < ni) {
-                const int V = imax(imax(part[lane], fb[tk.fb + i0 + lane]), A);
-                const int scv = V >> 16;
-                const int idx = tk.out + (i0 + lane) * tk.n2 + n;
-                if (scv >= lo) { cell_score[idx] = scv; cell_wscore[idx] = (V & 0xffff) - JBIAS; }
-                else { cell_score[idx] = -1; cell_wscore[idx] = 0; }
+#pragma unroll
+            for (int ii = 0; ii < IB; ++ii) {
+                int t = tS[ii];
+#pragma unroll
+                for (int off = 32; off > 0; off >>= 1) t = imax(t, __shfl_xor(t, off, 64));
+                if (lane == 0 && i0 + ii < tk.n1) {
+                    const int V = imax(imax(t, fb[tk.fb + i0 + ii]), A);
+                    const int scv = V >> 16;
+                    const int idx = tk.out + (i0 + ii) * tk.n2 + n;
+                    if (scv >= lo) { cell_score[idx] = scv; cell_wscore[idx] = (V & 0xffff) - JBIAS; }
+                    else { cell_score[idx] = -1; cell_wscore[idx] = 0; }
+                }
             }
-            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         }
     }
 }
