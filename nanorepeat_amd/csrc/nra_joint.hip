@@ -631,6 +631,7 @@ __global__ __launch_bounds__(WAVE) void k_joint_midscan(int n_tasks, const NraJo
     const int fresh = JBIAS;
     const int o21 = o2 - o1;
     const int g0 = lane * R;                                  // the lane's first row
+    __shared__ int tr[R * 64];                                // one plane of a column state, to transpose it for the store
 
     for (int s = 0; s < tk.nk1; ++s) {
         const int t0 = rg.l1 + rg.m1 * k1list[tk.k1_off + s] - 1;
@@ -698,11 +699,20 @@ __global__ __launch_bounds__(WAVE) void k_joint_midscan(int n_tasks, const NraJo
             }
         }
         // the column state at the end of mid, planes [Hq | E_in | E2_in] of Q rows, and B(k1)
+        // (through LDS: a lane holds R consecutive rows, a store instruction should cover 64 consecutive ones -- written
+        // straight from the registers the 80-byte pieces of neighbouring lanes share lines and the counter read 2.6 x the bytes)
         int32_t* __restrict__ fs = fsnap + tk.pstate + (size_t)s * 3 * Q;
 #pragma unroll
-        for (int i = 0; i < R; ++i) {
-            const int a = g0 + i;
-            if (a < Q) { fs[a] = Hq[i]; fs[Q + a] = E[i]; fs[2 * Q + a] = E2[i]; }
+        for (int pl = 0; pl < 3; ++pl) {
+#pragma unroll
+            for (int i = 0; i < R; ++i) tr[g0 + i] = pl == 0 ? Hq[i] : pl == 1 ? E[i] : E2[i];
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+#pragma unroll
+            for (int i = 0; i < R; ++i) {
+                const int a = 64 * i + lane;
+                if (a < Q) fs[(size_t)pl * Q + a] = tr[a];
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         }
         int best = lane <= last_lane ? M : 2 * JNEG;
 #pragma unroll
@@ -784,51 +794,63 @@ __global__ __launch_bounds__(WAVE) void k_joint_combine(int n_tasks, const NraJo
     const int q1 = (sp.open1 - sp.ext1) << 16, q2 = (sp.open2 - sp.ext2) << 16;
     const int cH = -JBIAS - fo1_win, cE = -JBIAS + q1 + 2, cE2 = -JBIAS + q2 + 2;      // as the tail sweep's prologue
     const int lo = sp.min_score > 1 ? sp.min_score : 1;
-    // Rows in chunks of 4 per lane (256 rows), k1 values in blocks of 8: the R side of a chunk stays in registers for the
-    // block, the 96 loads of a (chunk, block) are independent (one dependent trip per cell and row group makes the loop
-    // latency-bound), a lane keeps its partial maxima of the block's cells and the wave reduces once per cell.
-    constexpr int CH = 4, IB = 8;
-    for (int n = 0; n < tk.n2; ++n) {
-        const int32_t* __restrict__ rs = rsnap + tk.rs + (size_t)n * 3 * Q;
-        const int A = ra[tk.ra + n];
+    // Tiles of IB k1 values x NB k2 values, rows in chunks of CH per lane (128 rows): a chunk of both sides stays in
+    // registers for the tile's IB * NB cells -- every plane is read once per tile row / column instead of once per cell
+    // (8.7 -> ~4 GB per config-3 step) --, its loads are independent (one dependent trip per cell and row group makes the
+    // loop latency-bound), a lane keeps its partial maxima of the tile's cells and the wave reduces once per cell.
+    constexpr int CH = 2, IB = 8, NB = 6;
+    for (int n0 = 0; n0 < tk.n2; n0 += NB) {
         for (int i0 = 0; i0 < tk.n1; i0 += IB) {
-            int tS[IB];
+            int tS[IB][NB];
 #pragma unroll
-            for (int ii = 0; ii < IB; ++ii) tS[ii] = JNEG;
+            for (int ii = 0; ii < IB; ++ii)
+#pragma unroll
+                for (int nn = 0; nn < NB; ++nn) tS[ii][nn] = JNEG;
             for (int r0 = 0; r0 < Q - 1; r0 += 64 * CH) {
-                int hb[CH], eb[CH], e2b[CH];
+                int hb[NB][CH], eb[NB][CH], e2b[NB][CH];
 #pragma unroll
-                for (int c = 0; c < CH; ++c) {
-                    const int r = r0 + 64 * c + lane;
-                    const bool ok = r < Q - 1;                // row Q-1 has no partner on the R side
-                    const int a = ok ? Q - 2 - r : 0;
-                    hb[c] = ok ? rs[a] + cH : JNEG; eb[c] = ok ? rs[Q + a] + cE : JNEG; e2b[c] = ok ? rs[2 * Q + a] + cE2 : JNEG;
+                for (int nn = 0; nn < NB; ++nn) {
+                    const int n = imin(n0 + nn, tk.n2 - 1);           // (past the last k2 / k1: the last one again, not written)
+                    const int32_t* __restrict__ rs = rsnap + tk.rs + (size_t)n * 3 * Q;
+#pragma unroll
+                    for (int c = 0; c < CH; ++c) {
+                        const int r = r0 + 64 * c + lane;
+                        const bool ok = r < Q - 1;                    // row Q-1 has no partner on the R side
+                        const int a = ok ? Q - 2 - r : 0;
+                        hb[nn][c] = ok ? rs[a] + cH : JNEG; eb[nn][c] = ok ? rs[Q + a] + cE : JNEG;
+                        e2b[nn][c] = ok ? rs[2 * Q + a] + cE2 : JNEG;
+                    }
                 }
 #pragma unroll
                 for (int ii = 0; ii < IB; ++ii) {
-                    const int i = imin(i0 + ii, tk.n1 - 1);   // (past the last k1: the last one again, not written)
+                    const int i = imin(i0 + ii, tk.n1 - 1);
                     const int32_t* __restrict__ fs = fsnap + tk.fs + (size_t)i * 3 * Q;
 #pragma unroll
                     for (int c = 0; c < CH; ++c) {
                         const int r = r0 + 64 * c + lane;
                         const int rr = r < Q ? r : 0;
-                        tS[ii] = imax(imax(tS[ii], fs[rr] + hb[c]), imax(fs[Q + rr] + eb[c], fs[2 * Q + rr] + e2b[c]));
+                        const int hf = fs[rr], ef = fs[Q + rr], e2f = fs[2 * Q + rr];
+#pragma unroll
+                        for (int nn = 0; nn < NB; ++nn)
+                            tS[ii][nn] = imax(imax(tS[ii][nn], hf + hb[nn][c]), imax(ef + eb[nn][c], e2f + e2b[nn][c]));
                     }
                 }
             }
 #pragma unroll
-            for (int ii = 0; ii < IB; ++ii) {
-                int t = tS[ii];
+            for (int ii = 0; ii < IB; ++ii)
 #pragma unroll
-                for (int off = 32; off > 0; off >>= 1) t = imax(t, __shfl_xor(t, off, 64));
-                if (lane == 0 && i0 + ii < tk.n1) {
-                    const int V = imax(imax(t, fb[tk.fb + i0 + ii]), A);
-                    const int scv = V >> 16;
-                    const int idx = tk.out + (i0 + ii) * tk.n2 + n;
-                    if (scv >= lo) { cell_score[idx] = scv; cell_wscore[idx] = (V & 0xffff) - JBIAS; }
-                    else { cell_score[idx] = -1; cell_wscore[idx] = 0; }
+                for (int nn = 0; nn < NB; ++nn) {
+                    int t = tS[ii][nn];
+#pragma unroll
+                    for (int off = 32; off > 0; off >>= 1) t = imax(t, __shfl_xor(t, off, 64));
+                    if (lane == 0 && i0 + ii < tk.n1 && n0 + nn < tk.n2) {
+                        const int V = imax(imax(t, fb[tk.fb + i0 + ii]), ra[tk.ra + n0 + nn]);
+                        const int scv = V >> 16;
+                        const int idx = tk.out + (i0 + ii) * tk.n2 + n0 + nn;
+                        if (scv >= lo) { cell_score[idx] = scv; cell_wscore[idx] = (V & 0xffff) - JBIAS; }
+                        else { cell_score[idx] = -1; cell_wscore[idx] = 0; }
+                    }
                 }
-            }
         }
     }
 }

@@ -1,10 +1,10 @@
-"""Host/device timeline of one joint run (config 3) with the reads in groups: when each group's thread builds a cell
-list, sets it, waits for the device and reads the results.  python3 tools/joint_timeline.py [parts]"""
+"""Host/device timeline of one joint run (config 3): when the session (or each read group's thread, parts > 1) routes a
+grid, waits for the device and reads the results.  python3 tools/joint_timeline.py [parts]"""
 import copy, os, sys, threading, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from nanorepeat_amd import joint as J, synth
 
-parts = int(sys.argv[1]) if len(sys.argv) > 1 else 2
+parts = int(sys.argv[1]) if len(sys.argv) > 1 else 1
 if len(sys.argv) > 2 and sys.argv[2] == "torch":      # like bench.py: torch's HIP context first
     import torch
     torch.cuda.synchronize()
@@ -22,13 +22,10 @@ a = J.Repeat.parse(f"chr4:{len(left)}:{len(left) + 57}:{u1}:200")
 b = J.Repeat.parse(f"chr4:{len(left) + 57 + len(mid)}:{len(left) + 57 + len(mid) + 21}:{u2}:20")
 a.max_size += 10; b.max_size += 10
 log = []
-orig = J.GridSession.score
-
-
-def score(self, cell_read, k1, k2, read_strand):
+def score_grid(self, grid, read_strand):
     me = threading.current_thread().name
     t = [time.perf_counter()]
-    self.batch.set_cells(cell_read, k1, k2, read_strand); t.append(time.perf_counter())
+    n_cells = self.batch.set_grid(grid, read_strand); t.append(time.perf_counter())
     self.batch.run(); t.append(time.perf_counter())
     lk = self.in_turn
     if lk: self.host_lock.release()
@@ -37,10 +34,10 @@ def score(self, cell_read, k1, k2, read_strand):
     t.append(time.perf_counter())
     out = self.batch.fetch(per_candidate=False); t.append(time.perf_counter())
     log.append((me, t))
-    return out
+    return out, n_cells
 
 
-J.GridSession.score = score
+J.GridSession.score_grid = score_grid
 session = J.GridSession(J._joint_region(chrom, a, b), fq, parts=parts)
 runs = []
 for it in range(14):
@@ -53,6 +50,6 @@ for it in range(14):
 print("runs (ms):", runs)
 print(f"parts {parts}: last run {1e3 * (t1 - t0):.2f} ms")
 for me, t in sorted(log, key=lambda x: x[1][0]):
-    print(f"{me:12s} set_cells {1e3 * (t[0] - t0):7.2f} -> {1e3 * (t[1] - t0):7.2f}  run -> {1e3 * (t[2] - t0):7.2f}  "
+    print(f"{me:12s} set_grid {1e3 * (t[0] - t0):7.2f} -> {1e3 * (t[1] - t0):7.2f}  run -> {1e3 * (t[2] - t0):7.2f}  "
           f"sync -> {1e3 * (t[3] - t0):7.2f}  fetch -> {1e3 * (t[4] - t0):7.2f}")
 session.close()
