@@ -22,14 +22,25 @@ a.max_size += 10; b.max_size += 10
 KEYS = ("read_strand", "cell_score", "cell_wscore", "best_wscore", "sum_k1", "sum_k2", "n_ties", "status")
 rounds = []
 
-def both(region, reads, cr, k1, k2, **kw):
-    g = A.joint_2d(region, reads, cr, k1, k2, read_strand=kw.get("read_strand"))
+def score_grid(self, grid, read_strand):
+    """The product path (routed grid on the resident batch: junction at the end of mid, scans) with the per-cell
+    arrays fetched too, against the oracle on the cell list the library's routing gives."""
+    n_cells = self.batch.set_grid(grid, read_strand)
+    self.batch.run(); self.batch.sync()
+    g = self.batch.fetch(per_candidate=True)
+    cr, k1, k2 = A.joint_grid_cells(grid)
     t0 = time.time()
-    o = O.joint_2d(region, reads, cr, k1, k2, read_strand=kw.get("read_strand"))
-    rounds.append({"cells": len(cr), "cpu_s": time.time() - t0, **{k: bool(np.array_equal(g[k], o[k])) for k in KEYS}})
-    return g
+    o = O.joint_2d(self.region, self.reads, cr, k1, k2, read_strand=read_strand)
+    has = np.zeros(len(self.reads), bool); has[cr] = True
+    rounds.append({"cells": int(n_cells), "cpu_s": time.time() - t0,
+                   **{k: bool(np.array_equal(np.asarray(g[k])[has if len(o[k]) == len(has) else slice(None)],
+                                             np.asarray(o[k])[has if len(o[k]) == len(has) else slice(None)])) for k in KEYS}})
+    return g, n_cells
 
-fin = J.fine_tune_read_count(init, fq, chrom, copy.deepcopy(a), copy.deepcopy(b), scorer=both)
+J.GridSession.score_grid = score_grid
+for i in range(n):
+    init.read_strand_dict[f"r{i}"] = int(j["strand"][i])
+fin = J.fine_tune_read_count(init, fq, chrom, copy.deepcopy(a), copy.deepcopy(b))
 ok = all(all(v for k, v in r.items() if k in KEYS) for r in rounds)
-print(json.dumps({"reads": n, "rounds": rounds, "all_equal": ok}))
+print(json.dumps({"reads": n, "path": "nra_batch2d_set_grid (junction at the end of mid, k_joint_midscan, k_joint_combine)", "rounds": rounds, "all_equal": ok}))
 sys.exit(0 if ok else 1)
