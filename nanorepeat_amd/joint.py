@@ -69,14 +69,20 @@ class RepeatSize:
     step_size2: int = 1
 
 
-def choose_best_step_size(repeat, count_range_dict):
-    """nanoRepeat_joint.py:351-374 (first minimum wins: the sort is stable)."""
+def _all_ranges(count_range_dict):
+    """Every [min, max) of a round-1 range dict as an (n, 2) int64 array, in the dict's order (one flat pass)."""
+    return np.fromiter(chain.from_iterable(count_range_dict.values()), np.int64, 2 * len(count_range_dict)).reshape(-1, 2)
+
+
+def choose_best_step_size(repeat, count_range_dict, _ranges=None):
+    """nanoRepeat_joint.py:351-374 (first minimum wins: the sort is stable).  `_ranges`: the dict's values as an array,
+    when the caller has them already."""
     max_len = 50
     max_step_size = int(max_len / repeat.repeat_unit_size)
     if max_step_size < 1:
         max_step_size = 1
-    error_list = [b - a for a, b in count_range_dict.values()]
-    mean_range = np.mean(error_list)
+    span = _all_ranges(count_range_dict) if _ranges is None else _ranges
+    mean_range = np.mean(span[:, 1] - span[:, 0])
     best_size, best_count = None, None
     for size in range(1, max_step_size + 1):
         count = int(mean_range / size) + 1
@@ -430,13 +436,18 @@ class _Round1Arrays:
     """The round-1 knowledge of a session's reads as arrays, made once per fine_tune_read_count call: `rows` = the
     session read numbers with a range on both axes, their [min, max) ranges, every read's strand (0 = unknown)."""
 
-    def __init__(self, session, initial_estimation, strands):
+    def __init__(self, session, initial_estimation, strands, all_ranges=None):
         names = session.names
         r1, r2 = initial_estimation.repeat1_count_range_dict, initial_estimation.repeat2_count_range_dict
         self.source = initial_estimation
+        # every read's ranges in dict order (spans and step sizes come from ALL reads, nanoRepeat_joint.py:239-259, :365)
+        self.all1, self.all2 = all_ranges if all_ranges is not None else (_all_ranges(r1), _all_ranges(r2))
         self.rows = _rows_with(names, r1, r2)
-        self.range1 = _values_of(r1, names, self.rows, np.int64, 2)
-        self.range2 = _values_of(r2, names, self.rows, np.int64, 2)
+        if len(self.rows) == len(names) == len(r1) == len(r2) and list(r1) == names and list(r2) == names:
+            self.range1, self.range2 = self.all1, self.all2           # the session's reads in order: the same arrays
+        else:
+            self.range1 = _values_of(r1, names, self.rows, np.int64, 2)
+            self.range2 = _values_of(r2, names, self.rows, np.int64, 2)
         self.strand = None
         if strands is not None:
             if len(strands) == len(names) and list(strands) == names:
@@ -513,8 +524,9 @@ def round2_estimation_of_repeat_size(initial_estimation, fastq_dict, repeat_chro
         return _merge_parts(list(session.pool.map(lambda sub: round2_estimation_of_repeat_size(
             initial_estimation, fastq_dict, repeat_chrom_seq, repeat1, repeat2, data_type, num_threads, out_dir, device,
             scoring, scorer, strands, sub), session.subs)))
-    step_size1 = choose_best_step_size(repeat1, initial_estimation.repeat1_count_range_dict)
-    step_size2 = choose_best_step_size(repeat2, initial_estimation.repeat2_count_range_dict)
+    have = _ctx if _ctx is not None and _ctx.source is initial_estimation else None
+    step_size1 = choose_best_step_size(repeat1, initial_estimation.repeat1_count_range_dict, None if have is None else have.all1)
+    step_size2 = choose_best_step_size(repeat2, initial_estimation.repeat2_count_range_dict, None if have is None else have.all2)
     own = session is None
     if own:
         session = GridSession(_joint_region(repeat_chrom_seq, repeat1, repeat2), fastq_dict, device, scoring, scorer, parts=1)
@@ -594,9 +606,8 @@ def fine_tune_read_count(initial_estimation, fastq_dict, repeat_chrom_seq, repea
     reference builds at :264 (file ingestion is outside the hot path).  The reads are packed and
     uploaded once for both grid rounds (`session`: a GridSession to reuse, e.g. a benchmark's)."""
     _check_repeat_order(repeat1, repeat2)
-    for rep, ranges in ((repeat1, initial_estimation.repeat1_count_range_dict),
-                        (repeat2, initial_estimation.repeat2_count_range_dict)):
-        span = np.fromiter(chain.from_iterable(ranges.values()), np.int64, 2 * len(ranges)).reshape(-1, 2)
+    all_ranges = (_all_ranges(initial_estimation.repeat1_count_range_dict), _all_ranges(initial_estimation.repeat2_count_range_dict))
+    for rep, span in ((repeat1, all_ranges[0]), (repeat2, all_ranges[1])):
         lo = min(rep.max_size, int(span[:, 0].min())) if len(span) else rep.max_size
         hi = max(0, int(span[:, 1].max())) if len(span) else 0
         rep.round1_min_size, rep.round1_max_size = lo, min(hi, rep.max_size)            # :239-259
@@ -607,7 +618,7 @@ def fine_tune_read_count(initial_estimation, fastq_dict, repeat_chrom_seq, repea
     def both_rounds(sess, rep1, rep2):
         # a read's strand is known from round 1 when that was run here (the left template is forward)
         strands = dict(getattr(initial_estimation, "read_strand_dict", {}))
-        ctx = _Round1Arrays(sess, initial_estimation, strands)
+        ctx = _Round1Arrays(sess, initial_estimation, strands, all_ranges)
         est = round2_estimation_of_repeat_size(initial_estimation, fastq_dict, repeat_chrom_seq, rep1, rep2,
                                                data_type, num_threads, out_dir, device, scoring, scorer, strands, sess, ctx)
         if est.step_size1 > 1 and est.step_size2 > 1:                                    # :268
