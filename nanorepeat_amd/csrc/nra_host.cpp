@@ -484,11 +484,14 @@ struct nra_batch {
     size_t result_bytes = 0, result_stage_bytes = 0;
     // 2D
     DevBuf<int32_t> probe_score, probe_dummy, cell_k1, cell_k2;
+    DevBuf<NraGridRow> grid_rows;               // a routed grid instead of cell_k1 / cell_k2 (grid_step1 > 0)
+    int32_t grid_step1 = 0, grid_step2 = 0;
     DevBuf<NraTask> probe_tasks;                // chained 2D reads: (read, first cell) in both orientations
     DevBuf<int32_t> probe_count;
     DevBuf<uint32_t> cell_first, cell_cnt;
     DevBuf<int8_t> strand_in, strand_out;
     bool have_strand_in = false;
+    bool cells_need_clear = true;               // 2D: some cells are written by no kernel unless found
 
     std::vector<hipStream_t> bstreams;   // one per bucket: the sweep chains of different buckets overlap
     std::vector<hipEvent_t> bdone;       // bucket chain finished
@@ -1601,9 +1604,7 @@ int nra_batch2d_create_reads(int device, const nra_joint_region_t* reg, int32_t 
 
 namespace {
 
-// One read's share of a routed grid (nra_batch2d_set_grid): its cells are the product of n1 values of k1 from
-// k1lo in steps of the grid's step1 and n2 values of k2 from k2lo in steps of step2, k1-major.
-struct GridRow { int32_t k1lo, n1, k2lo, n2; };
+using GridRow = NraGridRow;
 struct JointGrid { int32_t step1, step2; const GridRow* rows; };
 
 // first index i in [0, count] with start + i * step >= x  (numpy.searchsorted(grid, x, side="left") on the grid values)
@@ -1694,16 +1695,9 @@ int nra_batch2d_set_grid(nra_batch_t* b, const int8_t* read_strand,
     int rc = route_grid(b->n_reads, start1, step1, count1, lo1, hi1, start2, step2, count2, lo2, hi2, rows, n);
     if (rc) return rc;
     if (n_cells_out) *n_cells_out = n;
-    // k1 / k2 of every cell, for the selector (and whoever fetches per-cell scores); the tasks come from the rows
-    std::vector<int32_t> k1((size_t)n), k2((size_t)n);
-    int64_t c = 0;
-    for (int32_t r = 0; r < b->n_reads; ++r) {
-        const GridRow& g = rows[(size_t)r];
-        for (int32_t i = 0; i < g.n1; ++i)
-            for (int32_t j = 0; j < g.n2; ++j, ++c) { k1[(size_t)c] = g.k1lo + i * step1; k2[(size_t)c] = g.k2lo + j * step2; }
-    }
     const JointGrid grid{step1, step2, rows.data()};
-    return set_cells_common(b, read_strand, n, nullptr, k1.data(), k2.data(), &grid);
+    // no per-cell arrays at all: the tasks come from the rows, the selector gets the rows (16 bytes a read)
+    return set_cells_common(b, read_strand, n, nullptr, nullptr, nullptr, &grid);
 }
 
 }  // extern "C"
@@ -1762,6 +1756,17 @@ int set_cells_common(nra_batch* b, const int8_t* read_strand, int64_t n_cells, c
         k1max = std::max(k1max, cell_k1[c]);
         k2max = std::max(k2max, cell_k2[c]);
     }
+    // k1 / k2 of a read's i-th listed cell
+    auto k1_of = [&](int32_t r, uint32_t i) -> int32_t {
+        if (!grid) return cell_k1[first[r] + i];
+        const GridRow& g = grid->rows[(size_t)r];
+        return g.k1lo + (int32_t)(i / (uint32_t)g.n2) * grid->step1;
+    };
+    auto k2_of = [&](int32_t r, uint32_t i) -> int32_t {
+        if (!grid) return cell_k2[first[r] + i];
+        const GridRow& g = grid->rows[(size_t)r];
+        return g.k2lo + (int32_t)(i % (uint32_t)g.n2) * grid->step2;
+    };
     const int32_t left_len = (int32_t)b->jr_left.size(), unit1_len = (int32_t)b->jr_unit1.size(),
                   mid_len = (int32_t)b->jr_mid.size(), unit2_len = (int32_t)b->jr_unit2.size(),
                   right_len = (int32_t)b->jr_right.size();
@@ -1789,12 +1794,17 @@ int set_cells_common(nra_batch* b, const int8_t* read_strand, int64_t n_cells, c
     std::vector<NraDevRegion> dregs(1, d);
 
     // (the rows-per-lane bucket of a read was fixed when the reads were packed)
-    std::vector<std::vector<int32_t>> by_bucket((size_t)kNumR + 1);
+    // (measured and dropped: a bucket as 2 - 4 sub-buckets with kernel chains of their own -- the short kernels at the
+    // end of one chain beside the long ones of the next -- is slower, 7.1 -> 7.7 / 8.7 / 10.5 ms of device time on config 3)
+    const int kChainBucket = kNumR;
+    std::vector<std::vector<int32_t>> by_bucket((size_t)kChainBucket + 1);
+    bool empty_reads_listed = false;
     for (int32_t r = 0; r < n_reads; ++r) {
+        if (cnt[r] > 0 && reads[r].qlen == 0) empty_reads_listed = true;
         if (cnt[r] == 0 || reads[r].qlen == 0) continue;
-        by_bucket[b->chained_reads[r] ? kNumR : b->jbucket[r]].push_back(r);
+        by_bucket[b->chained_reads[r] ? kChainBucket : b->jbucket[r]].push_back(r);
     }
-    const std::vector<int32_t>& chain_reads = by_bucket[kNumR];
+    const std::vector<int32_t>& chain_reads = by_bucket[kChainBucket];
     std::vector<NraPairTask> pair_tasks;
     std::vector<NraTask> queue_tasks, probe_tasks;
     std::vector<int32_t> queue_count, probe_count;
@@ -1809,6 +1819,9 @@ int set_cells_common(nra_batch* b, const int8_t* read_strand, int64_t n_cells, c
     // of mid.  The state kept from earlier cell lists differs between the two forms: switching drops it.
     b->joint_v2 = grid != nullptr && !b->brute && (flags & NRA_F_JOINT_TAILS) == 0;
     b->joint_chain = b->joint_v2 && (flags & NRA_F_JOINT_NO_CHAIN) == 0;
+    // k_joint_combine writes every cell of its reads, found or not: the cell arrays need no clearing unless some
+    // cells belong to no combine task (empty reads, reads scored cell by cell)
+    b->cells_need_clear = !b->joint_v2 || empty_reads_listed || !chain_reads.empty();
     if (b->joint_v2 != b->joint_v2_prev) {
         std::fill(b->rev_strand.begin(), b->rev_strand.end(), (int8_t)0);
         b->joint_v2_prev = b->joint_v2;
@@ -1835,10 +1848,10 @@ int set_cells_common(nra_batch* b, const int8_t* read_strand, int64_t n_cells, c
     // sweeps of the flanks outside the scoring window -- plus the strand probes.  With every strand given these
     // kernels are enqueued right here, before the (longer) list of prefix and tail sweeps is built and uploaded:
     // the host's share of a round then runs beside the device's first third of it.
-    for (int bi = kNumR; bi >= 0; --bi) {
+    for (int bi = kChainBucket; bi >= 0; --bi) {
         if (by_bucket[bi].empty()) continue;
         Bucket bk;
-        bk.chain = bi == kNumR;
+        bk.chain = bi == kChainBucket;
         bk.R = bk.chain ? NRA_CHAIN_R : kRList[bi];
         bk.pair_off = pair_tasks.size();
         bk.jbwd_off = jbwd.size();
@@ -1891,7 +1904,7 @@ int set_cells_common(nra_batch* b, const int8_t* read_strand, int64_t n_cells, c
             // strand probe against the read's first listed cell: half A = template, half B = its revcomp
             if (!bk.chain) {
                 NraPairTask t{};
-                t.read = r; t.k1a = t.k1b = cell_k1[first[r]]; t.k2a = t.k2b = cell_k2[first[r]];
+                t.read = r; t.k1a = t.k1b = k1_of(r, 0); t.k2a = t.k2b = k2_of(r, 0);
                 t.out_a = 2 * r; t.out_b = 2 * r + 1; t.flags = 3;     // B = reverse complement; raw scores
                 pair_tasks.push_back(t);
                 if (!b->all_strands_given)
@@ -1902,8 +1915,8 @@ int set_cells_common(nra_batch* b, const int8_t* read_strand, int64_t n_cells, c
                 shadow.rc = 1;
                 const int32_t sh = (int32_t)reads.size();
                 reads.push_back(shadow);
-                probe_tasks.push_back(NraTask{r, cell_k1[first[r]], cell_k2[first[r]], 2 * r});
-                probe_tasks.push_back(NraTask{sh, cell_k1[first[r]], cell_k2[first[r]], 2 * r + 1});
+                probe_tasks.push_back(NraTask{r, k1_of(r, 0), k2_of(r, 0), 2 * r});
+                probe_tasks.push_back(NraTask{sh, k1_of(r, 0), k2_of(r, 0), 2 * r + 1});
             }
         }
         bk.n_pair = (int)(pair_tasks.size() - bk.pair_off);
@@ -2062,13 +2075,21 @@ int set_cells_common(nra_batch* b, const int8_t* read_strand, int64_t n_cells, c
                 state_max = std::max(state_max, used);
             }
             // algorithmic cells: the rectangle of every (read, cell) alignment
-            {
+            if (grid && !per_cell) {
+                // a product grid: the sum of the template lengths in closed form
+                const GridRow& gr = grid->rows[(size_t)r];
+                const int64_t n1 = gr.n1, n2 = gr.n2;
+                const int64_t sum_k1 = n1 * gr.k1lo + (int64_t)grid->step1 * n1 * (n1 - 1) / 2;
+                const int64_t sum_k2 = n2 * gr.k2lo + (int64_t)grid->step2 * n2 * (n2 - 1) / 2;
+                alg_cells += (int64_t)reads[r].qlen * (n1 * n2 * ((int64_t)d.l1 + d.l2 + d.l3) + d.m1 * sum_k1 * n2 + d.m2 * sum_k2 * n1);
+            } else {
                 int64_t tl_sum = 0;
-                for (uint32_t c = first[r]; c < first[r] + cnt[r]; ++c) {
-                    const int tl = d.l1 + d.m1 * cell_k1[c] + d.l2 + d.m2 * cell_k2[c] + d.l3;
+                for (uint32_t i = 0; i < cnt[r]; ++i) {
+                    const int32_t k1 = k1_of(r, i), k2 = k2_of(r, i);
+                    const int tl = d.l1 + d.m1 * k1 + d.l2 + d.m2 * k2 + d.l3;
                     tl_sum += tl;
                     if (per_cell) {
-                        queue_tasks.push_back(NraTask{r, cell_k1[c], cell_k2[c], (int32_t)c});
+                        queue_tasks.push_back(NraTask{r, k1, k2, (int32_t)(first[r] + i)});
                         bk.cells_queue += sweep_cells(bk.R, tl);
                     }
                 }
@@ -2102,7 +2123,12 @@ int set_cells_common(nra_batch* b, const int8_t* read_strand, int64_t n_cells, c
             HIP_TRY(b->jcomb_tasks.upload(jcomb));
         }
     }
-    {
+    b->grid_step1 = b->grid_step2 = 0;
+    if (grid) {                                        // the selector computes k1 / k2 of a cell from the read's row
+        std::vector<GridRow> rows(grid->rows, grid->rows + n_reads);
+        HIP_TRY(b->grid_rows.upload(rows));
+        b->grid_step1 = grid->step1; b->grid_step2 = grid->step2;
+    } else {
         std::vector<int32_t> v(cell_k1, cell_k1 + n_cells); HIP_TRY(b->cell_k1.upload(v));
         std::vector<int32_t> w(cell_k2, cell_k2 + n_cells); HIP_TRY(b->cell_k2.upload(w));
     }
@@ -2217,18 +2243,20 @@ int run_2d_flanks(nra_batch* b)
             hipStream_t qa = b->bstreams[2 * i], qb = b->bstreams[2 * i + 1];
             HIP_TRY(hipStreamWaitEvent(qa, b->fork2_ev, 0));
             HIP_TRY(hipStreamWaitEvent(qb, b->fork2_ev, 0));
-            if (bk.n_jrpk > 0) {
-                HIP_TRY(hipEventRecord(b->ev[ev++], qa));
-                LAUNCH_TRY(nra_launch_joint_pk16(bk.R, b->has_n, qa, bk.n_jrpk, b->jrpk_tasks.p + bk.jrpk_off, b->reads.p,
-                                                 b->regions.p, b->pool.p, b->q2bit.p, b->qnmask.p, b->sp, 0, b->jrstate.p));
-                HIP_TRY(hipEventRecord(b->ev[ev++], qa));
-                b->n_score_ev++;
-            }
+            // the L side first: the older kernel's waves issue first, and the chain behind it (prefix sweep, MID scans,
+            // combine) is the longer one (config 3: 7.3 -> 7.1 ms of device time against the R side first)
             if (bk.n_jlpk > 0) {
                 HIP_TRY(hipEventRecord(b->ev[ev++], qb));
                 LAUNCH_TRY(nra_launch_joint_pk16(bk.R, b->has_n, qb, bk.n_jlpk, b->jlpk_tasks.p + bk.jlpk_off, b->reads.p,
                                                  b->regions.p, b->pool.p, b->q2bit.p, b->qnmask.p, b->sp, 1, b->jlstate.p));
                 HIP_TRY(hipEventRecord(b->ev[ev++], qb));
+                b->n_score_ev++;
+            }
+            if (bk.n_jrpk > 0) {
+                HIP_TRY(hipEventRecord(b->ev[ev++], qa));
+                LAUNCH_TRY(nra_launch_joint_pk16(bk.R, b->has_n, qa, bk.n_jrpk, b->jrpk_tasks.p + bk.jrpk_off, b->reads.p,
+                                                 b->regions.p, b->pool.p, b->q2bit.p, b->qnmask.p, b->sp, 0, b->jrstate.p));
+                HIP_TRY(hipEventRecord(b->ev[ev++], qa));
                 b->n_score_ev++;
             }
             HIP_TRY(hipEventRecord(b->ev[ev++], qa));
@@ -2262,9 +2290,11 @@ int run_2d(nra_batch* b)
     const size_t nc = std::max<size_t>((size_t)b->n_cands, 1);
     int ev = b->ev_next;
     const int max_waves = 256 * 16;
-    HIP_TRY(hipMemsetAsync(b->cand_score.p, 0xff, nc * 4, st));
-    HIP_TRY(hipMemsetAsync(b->cand_tstart.p, 0, nc * 4, st));
-    HIP_TRY(hipEventRecord(b->fork_ev, st));               // the cell arrays are cleared (the tails write them)
+    if (b->cells_need_clear) {
+        HIP_TRY(hipMemsetAsync(b->cand_score.p, 0xff, nc * 4, st));
+        HIP_TRY(hipMemsetAsync(b->cand_tstart.p, 0, nc * 4, st));
+        HIP_TRY(hipEventRecord(b->fork_ev, st));           // the cell arrays are cleared (the tails write them)
+    }
     // buckets scored cell by cell: all of them in brute-force mode, else the chained (long) reads only
     for (size_t i = 0; i < nb; ++i) {
         const Bucket& bk = b->buckets[i];
@@ -2287,7 +2317,7 @@ int run_2d(nra_batch* b)
             if (bk.chain) continue;
             hipStream_t qb = b->bstreams[2 * i + 1];
             HIP_TRY(hipStreamWaitEvent(st, b->bdone[3 * i], 0));
-            HIP_TRY(hipStreamWaitEvent(qb, b->fork_ev, 0));
+            if (b->cells_need_clear) HIP_TRY(hipStreamWaitEvent(qb, b->fork_ev, 0));
             bool first = true;
             for (const JointGroup& g : b->jgroups) {
                 if (g.bucket != (int)i) continue;
@@ -2342,6 +2372,7 @@ int run_2d(nra_batch* b)
     b->lst_pending.clear();
     HIP_TRY(hipEventRecord(b->phase_ev[1], st));
     LAUNCH_TRY(nra_launch_select_2d(st, b->n_reads, b->cell_first.p, b->cell_cnt.p, b->cell_k1.p, b->cell_k2.p,
+                                    b->grid_step1 > 0 ? b->grid_rows.p : nullptr, b->grid_step1, b->grid_step2,
                                     b->cand_score.p, b->cand_tstart.p, b->best_score.p, b->sum_k.p,
                                     b->sum_k2.p, b->n_ties.p, b->status.p));
     HIP_TRY(hipEventRecord(b->ev[1], st));

@@ -89,6 +89,10 @@ struct NraJointTask {
     int32_t phalf, resume;
 };
 
+// One read's share of a routed grid (nra_batch2d_set_grid): its cells are the product of n1 values of k1 from k1lo in
+// steps of the grid's step1 and n2 values of k2 from k2lo in steps of step2, k1-major.
+struct NraGridRow { int32_t k1lo, n1, k2lo, n2; };
+
 // One read of a routed grid for k_joint_combine: its n1 x n2 cells (k1-major at `out`) from the column states the
 // MID sweeps (fs: n1 slots of 3 x qlen) and the extended reverse sweep (rs: n2 slots) left, B(k1) at fb, A(k2) at ra.
 struct NraJointCombineTask {
@@ -350,6 +354,7 @@ int nra_launch_pick_strand(hipStream_t st, int n_reads, const int32_t* probe_sco
                            const int8_t* strand_in, int8_t* strand_out, NraDevRead* reads);
 int nra_launch_select_2d(hipStream_t st, int n_reads, const uint32_t* cell_first,
                          const uint32_t* cell_cnt, const int32_t* cell_k1, const int32_t* cell_k2,
+                         const NraGridRow* grid_rows, int grid_step1, int grid_step2,
                          const int32_t* cell_score, const int32_t* cell_wscore,
                          int32_t* best_w, int64_t* sum_k1, int64_t* sum_k2, int32_t* n_ties,
                          uint8_t* status);

@@ -434,6 +434,7 @@ __global__ __launch_bounds__(WAVE) void k_select_2d(int n_reads, const uint32_t*
                                                    const uint32_t* __restrict__ cell_cnt,
                                                    const int32_t* __restrict__ cell_k1,
                                                    const int32_t* __restrict__ cell_k2,
+                                                   const NraGridRow* __restrict__ grid_rows, int step1, int step2,
                                                    const int32_t* __restrict__ cell_score,
                                                    const int32_t* __restrict__ cell_wscore,
                                                    int32_t* __restrict__ best_w, int64_t* __restrict__ sum_k1,
@@ -453,6 +454,14 @@ __global__ __launch_bounds__(WAVE) void k_select_2d(int n_reads, const uint32_t*
         return;
     }
     long long s1 = 0, s2 = 0; int nt = 0;
+    if (grid_rows) {                          // a routed grid: the cell's k1 / k2 from the read's row (k1-major)
+        const NraGridRow g = grid_rows[r];
+        for (uint32_t c = lane; c < n; c += WAVE)
+            if (cell_score[f + c] >= 0 && cell_wscore[f + c] == w) {
+                const uint32_t i = c / (uint32_t)g.n2, j = c - i * (uint32_t)g.n2;
+                s1 += g.k1lo + (int)i * step1; s2 += g.k2lo + (int)j * step2; ++nt;
+            }
+    } else
     for (uint32_t c = lane; c < n; c += WAVE)
         if (cell_score[f + c] >= 0 && cell_wscore[f + c] == w) { s1 += cell_k1[f + c]; s2 += cell_k2[f + c]; ++nt; }
     s1 = wave_sum64(s1); s2 = wave_sum64(s2); nt = (int)wave_sum64(nt);
@@ -590,12 +599,13 @@ extern "C" int nra_launch_pick_strand(hipStream_t st, int n_reads, const int32_t
 
 extern "C" int nra_launch_select_2d(hipStream_t st, int n_reads, const uint32_t* cell_first,
                                     const uint32_t* cell_cnt, const int32_t* cell_k1, const int32_t* cell_k2,
+                                    const NraGridRow* grid_rows, int grid_step1, int grid_step2,
                                     const int32_t* cell_score, const int32_t* cell_wscore,
                                     int32_t* best_w, int64_t* sum_k1, int64_t* sum_k2, int32_t* n_ties,
                                     uint8_t* status)
 {
     if (n_reads <= 0) return 0;
-    k_select_2d<<<n_reads, WAVE, 0, st>>>(n_reads, cell_first, cell_cnt, cell_k1, cell_k2, cell_score,
+    k_select_2d<<<n_reads, WAVE, 0, st>>>(n_reads, cell_first, cell_cnt, cell_k1, cell_k2, grid_rows, grid_step1, grid_step2, cell_score,
                                           cell_wscore, best_w, sum_k1, sum_k2, n_ties, status);
     return (int)hipGetLastError();
 }
