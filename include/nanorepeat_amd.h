@@ -67,6 +67,9 @@ extern "C" {
 #define NRA_F_JOINT_NO_CHAIN 512 /* testing / comparison, 2D routed grids: the MID part (last prefix column + mid) as one systolic sweep per
                                  (read, k1) resuming from the prefix sweep's wave state, instead of column-parallel scans
                                  (k_joint_midscan) on the column states the prefix sweep leaves */
+#define NRA_F_JOINT_NO_KEEP 1024 /* testing / comparison, 2D routed grids: every grid of a batch sweeps its reads again, instead of keeping
+                                 the column states a coarse grid's sweeps leave at EVERY repeat count of a read's range, from which a
+                                 finer grid inside those ranges (the reference's round 3 after round 2) needs no sweep at all */
 #define NRA_F_BRUTE_FORCE  4  /* score the K candidates of a read as K independent alignments
                                  (k_score_pk16) instead of the junction decomposition (k_sweep_pk16) */
 

@@ -408,6 +408,7 @@ int64_t sweep128_cells(int R, int ncols) { return (int64_t)64 * R * ((int64_t)nc
 struct nra_batch {
     Arena arena;               // declared first: released after every DevBuf below
     Arena cell_arena;          // 2D: buffers that depend on the cell list; reset by nra_batch2d_set_cells
+    Arena keep_arena;          // 2D: column states kept from one routed grid for the next
     // 2D: what nra_batch2d_set_cells needs from the reads part
     std::vector<NraDevRead> host_reads;
     std::vector<uint8_t> chained_reads;
@@ -491,6 +492,14 @@ struct nra_batch {
     DevBuf<uint32_t> cell_first, cell_cnt;
     DevBuf<int8_t> strand_in, strand_out;
     bool have_strand_in = false;
+    // 2D routed grids: the column states the prefix sweep (at every k1 of keep_rows) and the extended reverse sweep (at
+    // every k2) left, kept for a later grid whose cells lie inside (nra_batch2d_invalidate / other strands drop them)
+    bool keep_valid = false, keep_pending = false;
+    std::vector<NraGridRow> keep_rows;
+    std::vector<int8_t> keep_strand;
+    std::vector<uint64_t> keep_state_off, keep_rs_off;
+    std::vector<int32_t> keep_ra_off;
+    int joint_keep = 0;                         // this cell list: 0 = nothing kept, 1 = sweeps that keep, 2 = no sweeps, kept states
     bool cells_need_clear = true;               // 2D: some cells are written by no kernel unless found
 
     std::vector<hipStream_t> bstreams;   // one per bucket: the sweep chains of different buckets overlap
@@ -729,6 +738,7 @@ int common_init(nra_batch* b, int device, const nra_scoring_t* sc, int flags)
     b->device = device;
     b->arena.device = device;
     b->cell_arena.device = device;
+    b->keep_arena.device = device;
     b->flags = flags;
     b->sp = to_params(*sc);
     HIP_TRY(g_handles.stream(device, &b->stream));
@@ -1605,7 +1615,9 @@ int nra_batch2d_create_reads(int device, const nra_joint_region_t* reg, int32_t 
 namespace {
 
 using GridRow = NraGridRow;
-struct JointGrid { int32_t step1, step2; const GridRow* rows; };
+// rows: the cells of every read.  keep: the repeat counts of every read the sweeps leave column states at, when these
+// are kept for a later, finer grid (same layout: k1lo, n1 / k2lo, n2 at step 1; a superset of the read's cells).
+struct JointGrid { int32_t step1, step2; const GridRow* rows; const GridRow* keep; };
 
 // first index i in [0, count] with start + i * step >= x  (numpy.searchsorted(grid, x, side="left") on the grid values)
 int32_t grid_lower_bound(int32_t start, int32_t step, int32_t count, double x)
@@ -1622,7 +1634,7 @@ int32_t grid_lower_bound(int32_t start, int32_t step, int32_t count, double x)
 // round 3): read r takes the grid values g of axis a with lo_a[r] <= g < hi_a[r]; none on one axis = no cells.
 int route_grid(int32_t n_reads, int32_t start1, int32_t step1, int32_t count1, const double* lo1, const double* hi1,
                int32_t start2, int32_t step2, int32_t count2, const double* lo2, const double* hi2,
-               std::vector<GridRow>& rows, int64_t& n_cells)
+               std::vector<GridRow>& rows, int64_t& n_cells, std::vector<GridRow>* keep = nullptr)
 {
     if (n_reads < 0 || step1 <= 0 || step2 <= 0 || count1 < 0 || count2 < 0 || start1 < 0 || start2 < 0)
         return fail(NRA_E_ARG, "bad grid (steps > 0, starts and counts >= 0)");
@@ -1638,6 +1650,32 @@ int route_grid(int32_t n_reads, int32_t start1, int32_t step1, int32_t count1, c
         if (b1 <= a1 || b2 <= a2) continue;
         rows[(size_t)r] = GridRow{start1 + a1 * step1, b1 - a1, start2 + a2 * step2, b2 - a2};
         n_cells += (int64_t)(b1 - a1) * (b2 - a2);
+    }
+    if (keep) {
+        // What a finer grid inside the same bounds can ask of a read: every count k with lo <= k < hi -- and, the way the
+        // reference refines (within one coarse step of a size between the coarse grid's first and last value), nothing
+        // more than one step below the first or above the last of the read's values.  A unit-step axis keeps its own.
+        keep->assign((size_t)n_reads, GridRow{0, 0, 0, 0});
+        auto span = [](int32_t first, int32_t n, int32_t step, double lo, double hi, int32_t& a, int32_t& count) {
+            const int32_t last = first + (n - 1) * step;
+            int64_t ka = first, kb = last;
+            if (step > 1) {
+                const double cl = std::ceil(lo), ch = std::ceil(hi);
+                const int64_t klo = cl < 0 ? 0 : (cl > 1e9 ? (int64_t)1e9 : (int64_t)cl);
+                const int64_t khi = ch > 1e9 ? (int64_t)1e9 : (int64_t)ch - 1;
+                ka = std::max<int64_t>(std::max<int64_t>(klo, (int64_t)first - step), 0);
+                kb = std::min<int64_t>(khi, (int64_t)last + step - 1);
+                ka = std::min<int64_t>(ka, first); kb = std::max<int64_t>(kb, last);
+            }
+            a = (int32_t)ka; count = (int32_t)(kb - ka + 1);
+        };
+        for (int32_t r = 0; r < n_reads; ++r) {
+            const GridRow& g = rows[(size_t)r];
+            if (g.n1 <= 0 || g.n2 <= 0) continue;
+            GridRow& k = (*keep)[(size_t)r];
+            span(g.k1lo, g.n1, step1, lo1[r], hi1[r], k.k1lo, k.n1);
+            span(g.k2lo, g.n2, step2, lo2[r], hi2[r], k.k2lo, k.n2);
+        }
     }
     return NRA_OK;
 }
@@ -1690,12 +1728,12 @@ int nra_batch2d_set_grid(nra_batch_t* b, const int8_t* read_strand,
                          int64_t* n_cells_out)
 {
     if (!b || b->kind != 2) return fail(NRA_E_ARG, "not a 2D batch");
-    std::vector<GridRow> rows;
+    std::vector<GridRow> rows, keep;
     int64_t n = 0;
-    int rc = route_grid(b->n_reads, start1, step1, count1, lo1, hi1, start2, step2, count2, lo2, hi2, rows, n);
+    int rc = route_grid(b->n_reads, start1, step1, count1, lo1, hi1, start2, step2, count2, lo2, hi2, rows, n, &keep);
     if (rc) return rc;
     if (n_cells_out) *n_cells_out = n;
-    const JointGrid grid{step1, step2, rows.data()};
+    const JointGrid grid{step1, step2, rows.data(), keep.data()};
     // no per-cell arrays at all: the tasks come from the rows, the selector gets the rows (16 bytes a read)
     return set_cells_common(b, read_strand, n, nullptr, nullptr, nullptr, &grid);
 }
@@ -1775,18 +1813,69 @@ int set_cells_common(nra_batch* b, const int8_t* read_strand, int64_t n_cells, c
     const int64_t tlmax = (int64_t)left_len + win - 20 + right_len;
     if (tlmax > NRA_MAX_TLEN) return fail(NRA_E_RANGE, "template too long");
 
+    // ---- Kept column states (routed grids with every strand given, MID scans).  A grid's sweeps leave a column state at
+    // every repeat count a finer grid inside the same bounds can ask for (grid->keep), not only at its own values: such a
+    // later grid -- the reference's round 3 after round 2 -- then needs no flank, prefix or reverse sweep at all, only
+    // the MID scans and the combine.  joint_keep: 0 = nothing kept, 1 = this list sweeps and keeps, 2 = no sweeps.
+    int32_t k1max_pool = k1max, k2max_pool = k2max;
+    int keep = 0;
+    {
+        const bool brute_now = (flags & NRA_F_BRUTE_FORCE) != 0 || left_len < 1 || right_len < 2;
+        bool strands_all = read_strand != nullptr && n_reads > 0;
+        if (read_strand)
+            for (int32_t r = 0; r < n_reads; ++r) if (cnt[r] > 0 && read_strand[r] == 0) strands_all = false;
+        auto swept = [&](int32_t r) { return cnt[r] > 0 && reads[r].qlen > 0 && !b->chained_reads[r]; };
+        if (grid && grid->keep && !brute_now && strands_all && n_cells > 0 &&
+            (flags & (NRA_F_JOINT_TAILS | NRA_F_JOINT_NO_CHAIN | NRA_F_JOINT_NO_KEEP)) == 0) {
+            bool reuse = b->keep_valid && b->keep_rows.size() == (size_t)n_reads;
+            for (int32_t r = 0; reuse && r < n_reads; ++r) {
+                if (!swept(r)) continue;
+                const GridRow& g = grid->rows[(size_t)r];
+                const NraGridRow& k = b->keep_rows[(size_t)r];
+                if (b->keep_strand[(size_t)r] != read_strand[r] || k.n1 <= 0 || k.n2 <= 0 || g.k1lo < k.k1lo ||
+                    g.k1lo + (g.n1 - 1) * grid->step1 > k.k1lo + k.n1 - 1 || g.k2lo < k.k2lo ||
+                    g.k2lo + (g.n2 - 1) * grid->step2 > k.k2lo + k.n2 - 1)
+                    reuse = false;
+            }
+            if (reuse) keep = 2;
+            else {
+                uint64_t bytes = 0;
+                int32_t k1hi = k1max, k2hi = k2max;
+                for (int32_t r = 0; r < n_reads; ++r) {
+                    if (!swept(r)) continue;
+                    const GridRow& k = grid->keep[(size_t)r];
+                    bytes += ((uint64_t)k.n1 * NRA_JOINT_NSTATE(kRList[b->jbucket[r]]) + (uint64_t)k.n2 * 3 * kRList[b->jbucket[r]]) * 256;
+                    k1hi = std::max(k1hi, k.k1lo + k.n1 - 1); k2hi = std::max(k2hi, k.k2lo + k.n2 - 1);
+                }
+                const int64_t tl_keep = (int64_t)left_len + (int64_t)unit1_len * k1hi + mid_len + (int64_t)unit2_len * k2hi + right_len;
+                if (bytes <= NRA_JOINT_KEEP_BUDGET && tl_keep <= NRA_MAX_TLEN) { keep = 1; k1max_pool = k1hi; k2max_pool = k2hi; }
+            }
+        }
+        if (keep != 2) b->keep_valid = false;       // what was kept is replaced (1) or not looked at again (0)
+        b->keep_pending = keep == 1;
+        b->joint_keep = keep;
+        if (keep == 1) {
+            b->keep_arena.reset();
+            b->keep_rows.assign(grid->keep, grid->keep + n_reads);
+            b->keep_strand.assign(read_strand, read_strand + n_reads);
+            b->keep_state_off.assign((size_t)n_reads, 0);
+            b->keep_rs_off.assign((size_t)n_reads, 0);
+            b->keep_ra_off.assign((size_t)n_reads, 0);
+        }
+    }
+
     clk.mark("2D cells: first/count");
     std::vector<uint8_t> pool;
     bool has_n = b->reads_have_n;
     NraDevRegion d{};
-    d.p1_off = pool_append(pool, b->jr_left.data(), left_len, b->jr_unit1.data(), unit1_len, k1max, has_n);
-    d.p2_off = pool_append(pool, b->jr_mid.data(), mid_len, b->jr_unit2.data(), unit2_len, k2max, has_n);
+    d.p1_off = pool_append(pool, b->jr_left.data(), left_len, b->jr_unit1.data(), unit1_len, k1max_pool, has_n);
+    d.p2_off = pool_append(pool, b->jr_mid.data(), mid_len, b->jr_unit2.data(), unit2_len, k2max_pool, has_n);
     d.p3_off = pool_append(pool, b->jr_right.data(), right_len, nullptr, 0, 0, has_n);
     {   // rev(R) + rev(u2)^k2max: the reverse sweeps (the extended ones run on into the second repeat)
         std::string rr(b->jr_right), ru(b->jr_unit2);
         std::reverse(rr.begin(), rr.end());
         std::reverse(ru.begin(), ru.end());
-        d.pr_off = pool_append(pool, rr.data(), right_len, ru.data(), unit2_len, k2max, has_n);
+        d.pr_off = pool_append(pool, rr.data(), right_len, ru.data(), unit2_len, k2max_pool, has_n);
     }
     d.l1 = left_len; d.m1 = unit1_len; d.l2 = mid_len; d.m2 = unit2_len; d.l3 = right_len;
     pool.push_back(0);
@@ -1865,20 +1954,26 @@ int set_cells_common(nra_batch* b, const int8_t* read_strand, int64_t n_cells, c
                 const int32_t pi = b->jpair_of[r];
                 const NraJointPairTask& pair = b->jpairs[(size_t)pi];
                 const bool stale = given == 0 || b->rev_strand[r] != given;     // nothing kept for this read and strand
-                if (b->joint_v2) {
-                    // the reverse sweep runs on over rev(u2)^k2hi and leaves a column state per k2 of the read: it
-                    // belongs to this cell list; only the packed sweep of rev(R) up to the window is kept
+                if (keep == 2) {
+                    // every column state this list needs was kept: no sweep on either side
+                    rs_off[(size_t)r] = b->keep_rs_off[(size_t)r]; ra_off[(size_t)r] = b->keep_ra_off[(size_t)r];
+                } else if (b->joint_v2) {
+                    // the reverse sweep runs on over rev(u2)^k2hi and leaves a column state per k2 of the read (of its
+                    // kept range, keep == 1); the packed sweep of rev(R) up to the window is kept in any case
                     const GridRow& gr = grid->rows[(size_t)r];
-                    NraJointTask tb{}; tb.read = r; tb.k2lo = gr.k2lo; tb.k2step = grid->step2; tb.n2 = gr.n2;
+                    const int32_t k2lo = keep == 1 ? grid->keep[(size_t)r].k2lo : gr.k2lo, k2n = keep == 1 ? grid->keep[(size_t)r].n2 : gr.n2,
+                                  k2step = keep == 1 ? 1 : grid->step2;
+                    NraJointTask tb{}; tb.read = r; tb.k2lo = k2lo; tb.k2step = k2step; tb.n2 = k2n;
                     tb.state = rs_total; tb.out = (int32_t)ra_total;
                     rs_off[(size_t)r] = rs_total; ra_off[(size_t)r] = (int32_t)ra_total;
-                    rs_total += (uint64_t)gr.n2 * 3 * (uint64_t)reads[r].qlen; ra_total += gr.n2;
+                    if (keep == 1) { b->keep_rs_off[(size_t)r] = rs_total; b->keep_ra_off[(size_t)r] = (int32_t)ra_total; }
+                    rs_total += (uint64_t)k2n * 3 * 64 * (uint64_t)bk.R; ra_total += k2n;
                     if (b->jpack_r) {
                         tb.resume = 1; tb.pstate = pair.state; tb.phalf = pair.read_b == r ? 1 : 0;
                         if (stale && !pair_r[pi]) { pair_r[pi] = 1; jrpk.push_back(pair); bk.cells_sweep += (int64_t)2 * 64 * bk.R * colsR; }
                     }
                     jbwd.push_back(tb);
-                    bk.cells_sweep += joint_cells(bk.R, d.l3 - (b->jpack_r ? colsR : 0) + d.m2 * (gr.k2lo + grid->step2 * (gr.n2 - 1)), reads[r].qlen);
+                    bk.cells_sweep += joint_cells(bk.R, d.l3 - (b->jpack_r ? colsR : 0) + d.m2 * (k2lo + k2step * (k2n - 1)), reads[r].qlen);
                     if (stale) { b->rev_strand[r] = 0; b->rev_pending.push_back({r, given}); }
                 } else if (stale) {
                     NraJointTask tb{}; tb.read = r; tb.k2step = 1; tb.n2 = 1;
@@ -1892,7 +1987,7 @@ int set_cells_common(nra_batch* b, const int8_t* read_strand, int64_t n_cells, c
                     b->rev_pending.push_back({r, given});
                 }
                 // the L side up to the window: swept once per pair and strand, kept for later cell lists
-                if (b->jpack_l && (given == 0 || b->lst_strand[r] != given) && !pair_l[pi]) {
+                if (keep != 2 && b->jpack_l && (given == 0 || b->lst_strand[r] != given) && !pair_l[pi]) {
                     pair_l[pi] = 1; jlpk.push_back(pair); bk.cells_sweep += (int64_t)2 * 64 * bk.R * colsL;
                     for (int32_t q : {pair.read_a, pair.read_b}) {
                         if (q < 0) continue;
@@ -1957,7 +2052,9 @@ int set_cells_common(nra_batch* b, const int8_t* read_strand, int64_t n_cells, c
         HIP_TRY(b->jbwd_tasks.upload(jbwd));
         HIP_TRY(b->jlpk_tasks.upload(jlpk));
         HIP_TRY(b->jrpk_tasks.upload(jrpk));
-        if (b->joint_v2) {
+        if (b->joint_v2 && keep != 2) {
+            ArenaScope kept(keep == 1 ? &b->keep_arena : &b->cell_arena);
+            if (keep == 1) b->keep_arena.expect((size_t)rs_total * 4 + (size_t)ra_total * 4 + (1u << 20));
             HIP_TRY(b->jrs.alloc((size_t)rs_total));
             HIP_TRY(b->jra.alloc((size_t)ra_total));
         }
@@ -2002,12 +2099,51 @@ int set_cells_common(nra_batch* b, const int8_t* read_strand, int64_t n_cells, c
                 if (grid) {
                     const GridRow& gr = grid->rows[(size_t)r];
                     for (int32_t i = 0; i < gr.n1; ++i) ks.push_back(gr.k1lo + i * grid->step1);
+                    if (keep != 0) {
+                        // kept column states: the prefix sweep (keep == 1; none at all, keep == 2) leaves one at EVERY count
+                        // of the read's kept range, the MID scans take the grid's own from among them
+                        const NraGridRow kr = keep == 1 ? grid->keep[(size_t)r] : b->keep_rows[(size_t)r];
+                        const uint64_t q3 = (uint64_t)3 * (uint64_t)reads[r].qlen;
+                        NraJointTask t{}; t.read = r; t.k1_off = (int32_t)k1list.size(); t.nk1 = gr.n1;
+                        t.k1 = kr.k1lo; t.k2step = 1;
+                        t.out = (int32_t)fb_total; t.pstate = fs_total;
+                        k1list.insert(k1list.end(), ks.begin(), ks.end());
+                        bk.cells_sweep += (int64_t)64 * bk.R * gr.n1 * (1 + d.l2);
+                        if (keep == 1) {
+                            NraJointTask tp{}; tp.read = r; tp.k1_off = (int32_t)k1list.size(); tp.nk1 = kr.n1;
+                            tp.state = used; tp.k2step = 1;
+                            if (b->jpack_l) { tp.resume = 1; tp.pstate = pair.state; tp.phalf = pair.read_b == r ? 1 : 0; }
+                            jpre.push_back(tp);
+                            for (int32_t i = 0; i < kr.n1; ++i) k1list.push_back(kr.k1lo + i);
+                            bk.cells_sweep += (int64_t)64 * bk.R * (d.l1 + d.m1 * (kr.k1lo + kr.n1 - 1) - 1 - (b->jpack_l ? colsL : 0));
+                            bk.cells_sweep += (int64_t)64 * bk.R * (1 + std::min(63, std::max(reads[r].qlen - 1, 0) / bk.R));   // its drain
+                            t.state = used;                         // (bucket-relative like tp.state: both move to the bucket's base below)
+                            used += slot * (uint64_t)kr.n1;
+                            state_max = std::max(state_max, used);
+                        } else
+                            t.state = b->keep_state_off[(size_t)r] | (1ull << 63);      // absolute already (marked; unmarked below)
+                        jtail.push_back(t);
+                        NraJointCombineTask ct{};
+                        ct.read = r; ct.n1 = gr.n1; ct.n2 = gr.n2; ct.out = (int32_t)first[r];
+                        ct.fb = (int32_t)fb_total; ct.ra = ra_off[(size_t)r]; ct.fs = fs_total; ct.rs = rs_off[(size_t)r];
+                        ct.rs_first = gr.k2lo - kr.k2lo; ct.rs_stride = grid->step2; ct.rs_plane = 64 * bk.R;
+                        jcomb.push_back(ct);
+                        fs_total += (uint64_t)gr.n1 * q3; fb_total += gr.n1;
+                        // algorithmic cells (closed form, as below)
+                        {
+                            const int64_t n1 = gr.n1, n2 = gr.n2;
+                            const int64_t sum_k1 = n1 * gr.k1lo + (int64_t)grid->step1 * n1 * (n1 - 1) / 2;
+                            const int64_t sum_k2 = n2 * gr.k2lo + (int64_t)grid->step2 * n2 * (n2 - 1) / 2;
+                            alg_cells += (int64_t)reads[r].qlen * (n1 * n2 * ((int64_t)d.l1 + d.l2 + d.l3) + d.m1 * sum_k1 * n2 + d.m2 * sum_k2 * n1);
+                        }
+                        continue;
+                    }
                 } else {
                     ks.assign(cell_k1 + first[r], cell_k1 + first[r] + cnt[r]);
                     if (!std::is_sorted(ks.begin(), ks.end())) std::sort(ks.begin(), ks.end());
                     ks.erase(std::unique(ks.begin(), ks.end()), ks.end());
                 }
-                if (used > 0 && used + slot * ks.size() > state_cap) {      // close the group
+                if (used > 0 && used + slot * ks.size() > state_cap) {      // close the group (never with kept states: budgeted above)
                     g.n_pre = (int)(jpre.size() - g.pre_off); g.n_tail = (int)(jtail.size() - g.tail_off);
                     b->jgroups.push_back(g);
                     g.pre_off = jpre.size(); g.tail_off = jtail.size();
@@ -2025,7 +2161,8 @@ int set_cells_common(nra_batch* b, const int8_t* read_strand, int64_t n_cells, c
                     const uint64_t q3 = (uint64_t)3 * (uint64_t)reads[r].qlen;
                     if (b->joint_chain) {
                         // the MID part of all the read's k1 in one wave, column by column (k_joint_midscan)
-                        NraJointTask t{}; t.read = r; t.k1_off = tp.k1_off; t.nk1 = tp.nk1; t.k2step = 1;
+                        NraJointTask t{}; t.read = r; t.k1_off = tp.k1_off; t.nk1 = tp.nk1;
+                        t.k1 = gr.k1lo; t.k2step = grid->step1;          // slot i of `state` holds k1lo + i * step1
                         t.out = (int32_t)fb_total; t.state = used; t.pstate = fs_total;
                         jtail.push_back(t);
                         bk.cells_sweep += (int64_t)64 * bk.R * gr.n1 * (1 + d.l2);
@@ -2042,6 +2179,7 @@ int set_cells_common(nra_batch* b, const int8_t* read_strand, int64_t n_cells, c
                     NraJointCombineTask ct{};
                     ct.read = r; ct.n1 = gr.n1; ct.n2 = gr.n2; ct.out = (int32_t)first[r];
                     ct.fb = (int32_t)fb_total; ct.ra = ra_off[(size_t)r]; ct.fs = fs_total; ct.rs = rs_off[(size_t)r];
+                    ct.rs_first = 0; ct.rs_stride = 1; ct.rs_plane = 64 * bk.R;
                     jcomb.push_back(ct);
                     fs_total += (uint64_t)gr.n1 * q3; fb_total += gr.n1;
                 } else if (grid) {
@@ -2098,9 +2236,15 @@ int set_cells_common(nra_batch* b, const int8_t* read_strand, int64_t n_cells, c
         }
         if (!per_cell) {
             g.n_pre = (int)(jpre.size() - g.pre_off); g.n_tail = (int)(jtail.size() - g.tail_off);
-            if (g.n_pre > 0) b->jgroups.push_back(g);
-            for (size_t i = bucket_pre0; i < jpre.size(); ++i) jpre[i].state += state_base;
-            for (size_t i = bucket_tail0; i < jtail.size(); ++i) jtail[i].state += state_base;
+            if (g.n_pre > 0 || g.n_tail > 0) b->jgroups.push_back(g);
+            for (size_t i = bucket_pre0; i < jpre.size(); ++i) {
+                jpre[i].state += state_base;
+                if (keep == 1) b->keep_state_off[(size_t)jpre[i].read] = jpre[i].state;
+            }
+            for (size_t i = bucket_tail0; i < jtail.size(); ++i) {
+                if (jtail[i].state >> 63) jtail[i].state &= ~(1ull << 63);      // a kept state: absolute
+                else jtail[i].state += state_base;
+            }
             state_base += state_max;
         }
         bk.n_queue = (int)(queue_tasks.size() - bk.queue_off);
@@ -2116,7 +2260,11 @@ int set_cells_common(nra_batch* b, const int8_t* read_strand, int64_t n_cells, c
         HIP_TRY(b->jpre_tasks.upload(jpre));
         HIP_TRY(b->jtail_tasks.upload(jtail));
         HIP_TRY(b->jk1list.upload(k1list));
-        HIP_TRY(b->jstate.alloc((size_t)state_base));
+        if (keep != 2) {
+            ArenaScope kept(keep == 1 ? &b->keep_arena : &b->cell_arena);
+            if (keep == 1) b->keep_arena.expect((size_t)state_base * 4 + (1u << 20));
+            HIP_TRY(b->jstate.alloc((size_t)state_base));
+        }
         if (b->joint_v2) {
             HIP_TRY(b->jfs.alloc((size_t)fs_total));
             HIP_TRY(b->jfb.alloc((size_t)fb_total));
@@ -2166,6 +2314,7 @@ int nra_batch2d_invalidate(nra_batch_t* b)
     if (!b || b->kind != 2) return fail(NRA_E_ARG, "not a 2D batch");
     std::fill(b->rev_strand.begin(), b->rev_strand.end(), (int8_t)0);
     std::fill(b->lst_strand.begin(), b->lst_strand.end(), (int8_t)0);
+    b->keep_valid = false;
     return NRA_OK;
 }
 
@@ -2370,6 +2519,7 @@ int run_2d(nra_batch* b)
     b->rev_pending.clear();
     for (const auto& pr2 : b->lst_pending) b->lst_strand[(size_t)pr2.first] = pr2.second;
     b->lst_pending.clear();
+    if (b->keep_pending) { b->keep_valid = true; b->keep_pending = false; }      // ... and so do the column states
     HIP_TRY(hipEventRecord(b->phase_ev[1], st));
     LAUNCH_TRY(nra_launch_select_2d(st, b->n_reads, b->cell_first.p, b->cell_cnt.p, b->cell_k1.p, b->cell_k2.p,
                                     b->grid_step1 > 0 ? b->grid_rows.p : nullptr, b->grid_step1, b->grid_step2,

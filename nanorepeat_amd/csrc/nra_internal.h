@@ -76,8 +76,10 @@ struct NraChainBlock {
 //     the wave state it left is at pstate (index into the packed-state buffer), this read in half `phalf`.
 //   Junction at the end of `mid` (routed grids, round 3 of the build): the reverse sweep runs on over rev(u2)^k2hi
 //     and leaves, at the column of every k2 = k2lo + n*k2step, n < n2, its rows' column state in slot n of `state`
-//     (3 planes of qlen int32) and A(k2) at out + n; a MID sweep (one per (read, k1)) resumes like a tail, sweeps
+//     (3 planes of 64 * R int32: the wave's rows, padding included) and A(k2) at out + n; a MID sweep (one per (read, k1)) resumes like a tail, sweeps
 //     the last prefix column + mid, and leaves its rows' column state at `pstate` and B(k1) at `out`.
+//   k_joint_midscan: the column state of repeat count k1 is slot (k1 - task.k1) / task.k2step of `state` (the prefix
+//     sweep may have left more of them than this grid asks for: kept column states).
 struct NraJointTask {
     int32_t read;
     int32_t k1;
@@ -95,10 +97,13 @@ struct NraGridRow { int32_t k1lo, n1, k2lo, n2; };
 
 // One read of a routed grid for k_joint_combine: its n1 x n2 cells (k1-major at `out`) from the column states the
 // MID sweeps (fs: n1 slots of 3 x qlen) and the extended reverse sweep (rs: n2 slots) left, B(k1) at fb, A(k2) at ra.
+// The R side's slots may hold more k2 values than the grid asks for (kept column states): the grid's n-th k2 is slot
+// rs_first + n * rs_stride of `rs` and of `ra`.
 struct NraJointCombineTask {
     int32_t read, n1, n2, out;
-    int32_t fb, ra, pad0, pad1;
+    int32_t fb, ra, rs_first, rs_stride;
     uint64_t fs, rs;
+    int32_t rs_plane, pad0;                     // rows of a plane of `rs`: 64 * (rows per lane of the read's bucket)
 };
 
 // Two reads of one rows-per-lane bucket whose payload-free columns -- L up to the scoring window, or rev(R) up to
@@ -162,6 +167,7 @@ struct NraScoreParams {
 #define NRA_JOINT_COLSTATE(R) ((3 * (R) + 2 + 3) / 4 * 4)
 // wave states of one group of 2D prefix sweeps: at most this many int32 (16 GiB)
 #define NRA_JOINT_STATE_CAP_INTS (4ull << 30)
+#define NRA_JOINT_KEEP_BUDGET (48ull << 30)    // bytes of column states kept from one routed grid for the next (else: not kept)
 #define NRA_MAX_TLEN 65000     // int32 payload cells: tstart is 16 bits; + 64 pipeline columns
 #define NRA_MAX_TLEN_WIDE 4000000   // int64 payload cells (score << 32 | payload)
 // rows per lane of the int64 payload kernels' unchained instantiations (a rare path: three sizes suffice)

@@ -397,11 +397,28 @@ __global__ __launch_bounds__(WAVE, joint_waves(R, DIR)) void k_joint_sweep(int n
                 // the lane's rows as they stand on a junction column: planes [H | E_in | E2_in] of Q rows.  EXT: slot
                 // nsnap (the lane's own count of boundaries passed) of the read's k2 list, H without the vertical open;
                 // MID: the one slot of this (read, k1), values as the junction combine takes them
-                int32_t* dst = EXT ? snap + tk.state + (size_t)nsnap * 3 * Q : snap + tk.pstate;
+                if (EXT) {
+                    // planes of 64 * R rows (the padding rows too: no guard; nobody reads them), the lane's R rows of a plane
+                    // in one piece: 16-byte stores where R allows (a lane is alone on its column: nothing to coalesce with)
+                    int32_t* __restrict__ dst = snap + tk.state + (size_t)nsnap * (3 * 64 * R) + lane * R;
+                    if (R % 4 == 0) {
 #pragma unroll
-                for (int i = 0; i < R; ++i) {
-                    const int a = lane * R + i;
-                    if (a < Q) { dst[a] = EXT ? Hq[i] - fo1 : Hq[i]; dst[Q + a] = E[i]; dst[2 * Q + a] = E2[i]; }
+                        for (int i = 0; i < R / 4 * 4; i += 4) {
+                            *reinterpret_cast<int4*>(dst + i) = make_int4(Hq[i] - fo1, Hq[i + 1] - fo1, Hq[i + 2] - fo1, Hq[i + 3] - fo1);
+                            *reinterpret_cast<int4*>(dst + 64 * R + i) = make_int4(E[i], E[i + 1], E[i + 2], E[i + 3]);
+                            *reinterpret_cast<int4*>(dst + 2 * 64 * R + i) = make_int4(E2[i], E2[i + 1], E2[i + 2], E2[i + 3]);
+                        }
+                    } else {
+#pragma unroll
+                        for (int i = 0; i < R; ++i) { dst[i] = Hq[i] - fo1; dst[64 * R + i] = E[i]; dst[2 * 64 * R + i] = E2[i]; }
+                    }
+                } else {
+                    int32_t* dst = snap + tk.pstate;
+#pragma unroll
+                    for (int i = 0; i < R; ++i) {
+                        const int a = lane * R + i;
+                        if (a < Q) { dst[a] = Hq[i]; dst[Q + a] = E[i]; dst[2 * Q + a] = E2[i]; }
+                    }
                 }
                 ++nsnap;
             }
@@ -634,9 +651,11 @@ __global__ __launch_bounds__(WAVE) void k_joint_midscan(int n_tasks, const NraJo
     __shared__ int tr[R * 64];                                // one plane of a column state, to transpose it for the store
 
     for (int s = 0; s < tk.nk1; ++s) {
-        const int t0 = rg.l1 + rg.m1 * k1list[tk.k1_off + s] - 1;
+        const int k1 = k1list[tk.k1_off + s];
+        const int t0 = rg.l1 + rg.m1 * k1 - 1;
+        const int slot = (k1 - tk.k1) / tk.k2step;           // (the prefix sweep may have left more column states than this list)
         constexpr int N4 = NRA_JOINT_COLSTATE(R) / 4;
-        const int4* __restrict__ sv = reinterpret_cast<const int4*>(state + tk.state + (size_t)s * (NSTATE * 64) + (size_t)lane * (4 * N4));
+        const int4* __restrict__ sv = reinterpret_cast<const int4*>(state + tk.state + (size_t)slot * (NSTATE * 64) + (size_t)lane * (4 * N4));
         int cs[4 * N4];
 #pragma unroll
         for (int i = 0; i < N4; ++i) { const int4 q = sv[i]; cs[4 * i] = q.x; cs[4 * i + 1] = q.y; cs[4 * i + 2] = q.z; cs[4 * i + 3] = q.w; }
@@ -811,14 +830,15 @@ __global__ __launch_bounds__(WAVE) void k_joint_combine(int n_tasks, const NraJo
 #pragma unroll
                 for (int nn = 0; nn < NB; ++nn) {
                     const int n = imin(n0 + nn, tk.n2 - 1);           // (past the last k2 / k1: the last one again, not written)
-                    const int32_t* __restrict__ rs = rsnap + tk.rs + (size_t)n * 3 * Q;
+                    const int P = tk.rs_plane;                        // rows of an R-side plane (padded to the wave's 64 * R)
+                    const int32_t* __restrict__ rs = rsnap + tk.rs + (size_t)(tk.rs_first + n * tk.rs_stride) * 3 * P;
 #pragma unroll
                     for (int c = 0; c < CH; ++c) {
                         const int r = r0 + 64 * c + lane;
                         const bool ok = r < Q - 1;                    // row Q-1 has no partner on the R side
                         const int a = ok ? Q - 2 - r : 0;
-                        hb[nn][c] = ok ? rs[a] + cH : JNEG; eb[nn][c] = ok ? rs[Q + a] + cE : JNEG;
-                        e2b[nn][c] = ok ? rs[2 * Q + a] + cE2 : JNEG;
+                        hb[nn][c] = ok ? rs[a] + cH : JNEG; eb[nn][c] = ok ? rs[P + a] + cE : JNEG;
+                        e2b[nn][c] = ok ? rs[2 * P + a] + cE2 : JNEG;
                     }
                 }
 #pragma unroll
@@ -844,7 +864,7 @@ __global__ __launch_bounds__(WAVE) void k_joint_combine(int n_tasks, const NraJo
 #pragma unroll
                     for (int off = 32; off > 0; off >>= 1) t = imax(t, __shfl_xor(t, off, 64));
                     if (lane == 0 && i0 + ii < tk.n1 && n0 + nn < tk.n2) {
-                        const int V = imax(imax(t, fb[tk.fb + i0 + ii]), ra[tk.ra + n0 + nn]);
+                        const int V = imax(imax(t, fb[tk.fb + i0 + ii]), ra[tk.ra + tk.rs_first + (n0 + nn) * tk.rs_stride]);
                         const int scv = V >> 16;
                         const int idx = tk.out + (i0 + ii) * tk.n2 + n0 + nn;
                         if (scv >= lo) { cell_score[idx] = scv; cell_wscore[idx] = (V & 0xffff) - JBIAS; }

@@ -405,6 +405,50 @@ def test_joint_routed_grid_equals_its_cell_list(capi, oracle):
         assert by_grid.set_grid(capi.Grid((0, 1, 4), t1 + 50, t1 + 60, (0, 1, 4), t2, t2 + 1), strands) == 0
 
 
+def test_joint_finer_grid_from_kept_column_states(capi, oracle):
+    """A coarse routed grid's sweeps leave a column state at every repeat count of a read's range; a finer grid inside
+    (the reference's round 3 after round 2, nanoRepeat_joint.py:275-349) runs no sweep at all -- fewer executed cells,
+    the same results as a batch that sweeps again (NRA_F_JOINT_NO_KEEP) and as the oracle.  A grid that leaves the kept
+    ranges, other strands, or nra_batch2d_invalidate make the library sweep again."""
+    j = synth.make_joint(17, alleles=((11, 6), (21, 4)), read_len=640, read_sd=60, anchor=330, seed=75)
+    n = len(j["reads"])
+    t1, t2 = j["truth"][:, 0].astype(np.float64), j["truth"][:, 1].astype(np.float64)
+    strands = j["strand"].astype(np.int8)
+    flipped = strands.copy(); flipped[3] = -flipped[3]
+    lo1, hi1, lo2, hi2 = t1 - 9, t1 + 8, np.maximum(t2 - 5, 0), t2 + 5
+    coarse = capi.Grid((1, 4, 9), lo1, hi1, (0, 3, 5), lo2, hi2)
+    size1, size2 = t1 + np.arange(n) % 3 - 1 + 0.5 * (np.arange(n) % 2), t2 + np.arange(n) % 2      # "round-2 sizes", some of them means of ties
+    fine = capi.Grid((0, 1, 40), np.maximum(size1 - 4, lo1), np.minimum(size1 + 4, hi1),
+                     (0, 1, 16), np.maximum(size2 - 3, lo2), np.minimum(size2 + 3, hi2))
+    wider = capi.Grid((0, 1, 40), lo1 - 3, hi1 + 3, (0, 1, 16), lo2, hi2 + 2)      # beyond what was kept
+    steps = [("coarse", coarse, strands, "sweeps"), ("fine", fine, strands, "kept"), ("fine again", fine, strands, "kept"),
+             ("fine, one read on the other strand", fine, flipped, "sweeps"), ("fine once more", fine, flipped, "kept"),
+             ("wider", wider, flipped, "sweeps"), ("coarse", coarse, strands, "sweeps"), ("invalidate", None, None, None),
+             ("fine after invalidate", fine, strands, "sweeps"), ("fine, strands probed", fine, None, "sweeps")]
+    with capi.Batch.create_2d_reads(j["region"], j["reads"]) as keeps, \
+            capi.Batch.create_2d_reads(j["region"], j["reads"], flags=capi.F_JOINT_NO_KEEP) as sweeps:
+        for what, grid, st, expect in steps:
+            if grid is None:
+                keeps.invalidate()
+                continue
+            cr, k1, k2 = capi.joint_grid_cells(grid)
+            o = oracle.joint_2d(j["region"], j["reads"], cr, k1, k2, read_strand=st)
+            has = np.zeros(n, bool); has[cr] = True
+            cells = {}
+            for name, b in (("keeps", keeps), ("sweeps", sweeps)):
+                assert b.set_grid(grid, st) == len(cr) > 0
+                b.run(); b.sync()
+                g = b.fetch()
+                cells[name] = b.stats()["executed_cells"]
+                for key in o:
+                    sel = has if len(o[key]) == n else slice(None)
+                    assert np.array_equal(np.asarray(g[key])[sel], np.asarray(o[key])[sel]), (what, name, key)
+            if expect == "kept":
+                assert cells["keeps"] < 0.5 * cells["sweeps"], (what, cells)
+            else:
+                assert cells["keeps"] >= cells["sweeps"], (what, cells)      # (a coarse grid keeps a little more than it needs)
+
+
 def test_joint_packed_flank_sweeps(capi, oracle):
     """The columns of L and rev(R) outside the scoring window are swept in packed int16 cells, two reads per
     wave, and the int32 sweeps resume from the state they leave: flanks just below / at / above the 64-column

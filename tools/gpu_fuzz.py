@@ -189,15 +189,28 @@ def fuzz_2d_grid(rng):
     t1 = np.array([t[0] for t in truth], np.float64); t2 = np.array([t[1] for t in truth], np.float64)
     strand = np.array(strand, np.int8)
     region = (L, u1, mid, u2, R)
-    flags = [0, A.F_JOINT_NO_CHAIN, A.F_JOINT_TAILS][int(rng.integers(0, 3))]
+    flags = [0, 0, A.F_JOINT_NO_CHAIN, A.F_JOINT_TAILS, A.F_JOINT_NO_KEEP][int(rng.integers(0, 5))]
+    prev = None
     with A.Batch.create_2d_reads(region, reads, flags=flags) as b:
-        for rnd in range(2):
-            a1 = (int(rng.integers(0, 6)), int(rng.integers(1, 5)), int(rng.integers(1, 12)))
-            a2 = (int(rng.integers(0, 4)), int(rng.integers(1, 4)), int(rng.integers(1, 10)))
-            w1, w2 = rng.integers(1, 9, size=n) + rng.choice([0.0, 0.5, 1 / 3], size=n), rng.integers(1, 6, size=n) + rng.choice([0.0, 0.5], size=n)
-            lo1, hi1, lo2, hi2 = t1 - w1, t1 + w1, t2 - w2, t2 + w2
-            if rng.random() < 0.3: hi2[int(rng.integers(0, n))] = -1.0          # a read without cells
-            st = strand if rng.random() < 0.8 else None
+        for rnd in range(int(rng.integers(2, 5))):
+            if prev is not None and rng.random() < 0.5:
+                # a finer grid inside the previous bounds, the way the reference's round 3 follows round 2: within one
+                # coarse step of a "size" between the read's first and last coarse value (kept column states, no sweeps)
+                (p1, q1, p2, q2, s1, s2) = prev
+                z1 = p1 + (q1 - p1) * rng.random(size=n); z2 = p2 + (q2 - p2) * rng.random(size=n)
+                if rng.random() < 0.5: z1, z2 = np.round(z1), np.round(2 * z2) / 2
+                lo1, hi1 = np.maximum(z1 - s1, p1), np.minimum(z1 + s1, q1)
+                lo2, hi2 = np.maximum(z2 - s2, p2), np.minimum(z2 + s2, q2)
+                a1 = (int(rng.integers(0, 3)), 1, 60); a2 = (int(rng.integers(0, 2)), 1, 40)
+            else:
+                a1 = (int(rng.integers(0, 6)), int(rng.integers(1, 5)), int(rng.integers(1, 12)))
+                a2 = (int(rng.integers(0, 4)), int(rng.integers(1, 4)), int(rng.integers(1, 10)))
+                w1, w2 = rng.integers(1, 9, size=n) + rng.choice([0.0, 0.5, 1 / 3], size=n), rng.integers(1, 6, size=n) + rng.choice([0.0, 0.5], size=n)
+                lo1, hi1, lo2, hi2 = t1 - w1, t1 + w1, t2 - w2, t2 + w2
+                if rng.random() < 0.3: hi2[int(rng.integers(0, n))] = -1.0          # a read without cells
+            prev = (lo1, hi1, lo2, hi2, a1[1], a2[1])
+            st = strand if rng.random() < 0.85 else None
+            if rng.random() < 0.1: b.invalidate()
             grid = A.Grid(a1, lo1, hi1, a2, lo2, hi2)
             cr, k1, k2 = A.joint_grid_cells(grid)
             if b.set_grid(grid, st) != len(cr):
