@@ -2,6 +2,8 @@
 grid, waits for the device and reads the results.  python3 tools/joint_timeline.py [parts]"""
 import copy, os, sys, threading, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import nanorepeat_amd
+nanorepeat_amd.apply_recommended_env()      # (like bench.py: 8 hardware queues)
 from nanorepeat_amd import joint as J, synth
 
 parts = int(sys.argv[1]) if len(sys.argv) > 1 else 1
