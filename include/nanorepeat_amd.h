@@ -289,10 +289,13 @@ int  nra_batch2d_set_grid(nra_batch_t* b, const int8_t* read_strand,
                           int32_t start1, int32_t step1, int32_t count1, const double* lo1, const double* hi1,
                           int32_t start2, int32_t step2, int32_t count2, const double* lo2, const double* hi2,
                           int64_t* n_cells);
-/* A later cell list reuses what an earlier one left on the device for the same read and strand (the reverse
- * sweep over the right flank, the state of the forward sweep at the end of the left flank).  nra_batch2d_invalidate
- * drops that: the next list starts like the first (a
- * benchmark repeating the two rounds on one resident batch calls it at the top of every repetition). */
+/* A later cell list reuses what an earlier one left on the device for the same read and strand: the packed sweeps of
+ * the two flanks, and -- routed grids with every strand given -- the column states on either side of the junction, which
+ * a grid's sweeps leave at EVERY repeat count k with lo_a[r] <= k < hi_a[r] (no further than one step beyond the read's
+ * first / last grid value), not only at the grid's own values: a later grid whose cells all lie inside (round 3 after
+ * round 2) runs no sweep at all (results identical; NRA_F_JOINT_NO_KEEP switches this off).  nra_batch2d_invalidate
+ * drops all of it: the next list starts like the first (a benchmark repeating the two rounds on one resident batch
+ * calls it at the top of every repetition). */
 int  nra_batch2d_invalidate(nra_batch_t* b);
 int  nra_batch_run(nra_batch_t* b);      /* enqueue every kernel of the path; returns at once */
 int  nra_batch_sync(nra_batch_t* b);     /* wait for the batch stream */

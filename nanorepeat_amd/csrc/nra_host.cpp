@@ -1273,7 +1273,8 @@ static int run_1d(nra_batch* b)
         // junction decomposition: per bucket a chain reverse sweep -> forward sweep, each chain on
         // its own stream so that short buckets fill the SIMDs a long bucket's tail leaves idle
         HIP_TRY(hipEventRecord(b->fork_ev, st));
-        // (the order the buckets' chains are launched in makes no difference: 5.50 - 5.61 ms either way on config 2)
+        // (the order the buckets' chains are launched in makes no difference: 5.50 - 5.61 ms either way on config 2;
+        // a bucket's tasks as 2 / 3 / 4 groups with chains of their own are slower: 5.65 -> 6.0 / 5.9 / 7.6 ms)
         for (size_t i = 0; i < nb; ++i) {
             const Bucket& bk = b->buckets[i];
             hipStream_t q = b->bstreams[i];
@@ -1851,7 +1852,14 @@ int set_cells_common(nra_batch* b, const int8_t* read_strand, int64_t n_cells, c
                     k1hi = std::max(k1hi, k.k1lo + k.n1 - 1); k2hi = std::max(k2hi, k.k2lo + k.n2 - 1);
                 }
                 const int64_t tl_keep = (int64_t)left_len + (int64_t)unit1_len * k1hi + mid_len + (int64_t)unit2_len * k2hi + right_len;
-                if (bytes <= NRA_JOINT_KEEP_BUDGET && tl_keep <= NRA_MAX_TLEN) { keep = 1; k1max_pool = k1hi; k2max_pool = k2hi; }
+                // ... within the budget, and within half of what the device has left (what the arena holds already counts as free)
+                bool fits = bytes <= NRA_JOINT_KEEP_BUDGET && tl_keep <= NRA_MAX_TLEN;
+                if (fits) {
+                    size_t held = 0, free_b = 0, total_b = 0;
+                    for (const Arena::Chunk& c : b->keep_arena.chunks) held += c.size;
+                    if (bytes > held) fits = hipMemGetInfo(&free_b, &total_b) == hipSuccess && bytes - held <= free_b / 2;
+                }
+                if (fits) { keep = 1; k1max_pool = k1hi; k2max_pool = k2hi; }
             }
         }
         if (keep != 2) b->keep_valid = false;       // what was kept is replaced (1) or not looked at again (0)
