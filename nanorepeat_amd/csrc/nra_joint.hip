@@ -795,19 +795,12 @@ extern "C" int nra_launch_joint_mid(int R, int has_n, hipStream_t st, int n_task
 // One wave per read; rows across the lanes (row = 64*t + lane: coalesced plane loads).  Cell (k1_i, k2_n):
 //   S = max over rows r of  Hq_f(r) + H_b(a) - fo1_win,  E_f(r) + E_b(a) + (q, +2),  E2_f(r) + E2_b(a) + (q2, +2),   a = Q-2-r
 //   V = max(S, B(k1_i), A(k2_n))  ->  score, window score        (the arithmetic of k_joint_sweep's tail combine)
-__global__ __launch_bounds__(WAVE) void k_joint_combine(int n_tasks, const NraJointCombineTask* __restrict__ tasks,
-                                                        const NraDevRead* __restrict__ reads, NraScoreParams sp,
-                                                        const int32_t* __restrict__ fsnap,
-                                                        const int32_t* __restrict__ rsnap,
-                                                        const int32_t* __restrict__ fb, const int32_t* __restrict__ ra,
-                                                        int32_t* __restrict__ cell_score,
-                                                        int32_t* __restrict__ cell_wscore)
+template <int IB, int NB>
+__device__ __forceinline__ void joint_combine_tiles(const NraJointCombineTask& tk, const int Q, const int lane, NraScoreParams sp,
+                                                    const int32_t* __restrict__ fsnap, const int32_t* __restrict__ rsnap,
+                                                    const int32_t* __restrict__ fb, const int32_t* __restrict__ ra,
+                                                    int32_t* __restrict__ cell_score, int32_t* __restrict__ cell_wscore)
 {
-    const int task = blockIdx.x;
-    if (task >= n_tasks) return;
-    const int lane = threadIdx.x;
-    const NraJointCombineTask tk = tasks[task];
-    const int Q = reads[tk.read].qlen;
     const int o1 = -(sp.open1 << 16);
     const int fo1_win = o1 - 4;
     const int q1 = (sp.open1 - sp.ext1) << 16, q2 = (sp.open2 - sp.ext2) << 16;
@@ -817,7 +810,7 @@ __global__ __launch_bounds__(WAVE) void k_joint_combine(int n_tasks, const NraJo
     // registers for the tile's IB * NB cells -- every plane is read once per tile row / column instead of once per cell
     // (8.7 -> ~4 GB per config-3 step) --, its loads are independent (one dependent trip per cell and row group makes the
     // loop latency-bound), a lane keeps its partial maxima of the tile's cells and the wave reduces once per cell.
-    constexpr int CH = 2, IB = 8, NB = 6;
+    constexpr int CH = 2;
     for (int n0 = 0; n0 < tk.n2; n0 += NB) {
         for (int i0 = 0; i0 < tk.n1; i0 += IB) {
             int tS[IB][NB];
@@ -873,6 +866,24 @@ __global__ __launch_bounds__(WAVE) void k_joint_combine(int n_tasks, const NraJo
                 }
         }
     }
+}
+
+__global__ __launch_bounds__(WAVE) void k_joint_combine(int n_tasks, const NraJointCombineTask* __restrict__ tasks,
+                                                        const NraDevRead* __restrict__ reads, NraScoreParams sp,
+                                                        const int32_t* __restrict__ fsnap,
+                                                        const int32_t* __restrict__ rsnap,
+                                                        const int32_t* __restrict__ fb, const int32_t* __restrict__ ra,
+                                                        int32_t* __restrict__ cell_score,
+                                                        int32_t* __restrict__ cell_wscore)
+{
+    const int task = blockIdx.x;
+    if (task >= n_tasks) return;
+    const int lane = threadIdx.x;
+    const NraJointCombineTask tk = tasks[task];
+    const int Q = reads[tk.read].qlen;
+    // the tile that takes all the read's k1 values in one pass, if there is one: every plane is then read once
+    if (tk.n1 <= 8) joint_combine_tiles<8, 6>(tk, Q, lane, sp, fsnap, rsnap, fb, ra, cell_score, cell_wscore);
+    else joint_combine_tiles<12, 6>(tk, Q, lane, sp, fsnap, rsnap, fb, ra, cell_score, cell_wscore);
 }
 
 extern "C" int nra_launch_joint_combine(hipStream_t st, int n_tasks, const NraJointCombineTask* tasks,
