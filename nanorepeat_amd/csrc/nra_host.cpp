@@ -1746,6 +1746,20 @@ int nra_batch2d_set_grid(nra_batch_t* b, const int8_t* read_strand,
 
 namespace {
 
+// A read's MID scans as several tasks of at most kMidscanChunk k1 values: a wave's scans are one dependent chain (load a
+// column state, 1 + |mid| columns of two lane scans each, store), so more, shorter waves hide it better than one wave per
+// read (config 3, round 3: 5 k1 values per read).  The pieces differ in where their lists, outputs and slots begin only.
+void push_midscan(std::vector<NraJointTask>& jtail, const NraJointTask& whole, uint64_t ints_per_k1)
+{
+    const int kMidscanChunk = 3;            // config 3, device ms per step: whole reads 6.23, 1: 6.23, 2: 6.18, 3: 6.15, 4: 6.16, 6: 6.40
+    for (int32_t c = 0; c < whole.nk1; c += kMidscanChunk) {
+        NraJointTask t = whole;
+        t.k1_off = whole.k1_off + c; t.nk1 = std::min<int32_t>(kMidscanChunk, whole.nk1 - c);
+        t.out = whole.out + c; t.pstate = whole.pstate + (uint64_t)c * ints_per_k1;
+        jtail.push_back(t);
+    }
+}
+
 int set_cells_common(nra_batch* b, const int8_t* read_strand, int64_t n_cells, const int32_t* cell_read,
                      const int32_t* cell_k1, const int32_t* cell_k2, const JointGrid* grid)
 {
@@ -2135,7 +2149,7 @@ int set_cells_common(nra_batch* b, const int8_t* read_strand, int64_t n_cells, c
                             state_max = std::max(state_max, used);
                         } else
                             t.state = b->keep_state_off[(size_t)r] | (1ull << 63);      // absolute already (marked; unmarked below)
-                        jtail.push_back(t);
+                        push_midscan(jtail, t, q3);
                         NraJointCombineTask ct{};
                         ct.read = r; ct.n1 = gr.n1; ct.n2 = gr.n2; ct.out = (int32_t)first[r];
                         ct.fb = (int32_t)fb_total; ct.ra = ra_off[(size_t)r]; ct.fs = fs_total; ct.rs = rs_off[(size_t)r];
@@ -2177,7 +2191,7 @@ int set_cells_common(nra_batch* b, const int8_t* read_strand, int64_t n_cells, c
                         NraJointTask t{}; t.read = r; t.k1_off = tp.k1_off; t.nk1 = tp.nk1;
                         t.k1 = gr.k1lo; t.k2step = grid->step1;          // slot i of `state` holds k1lo + i * step1
                         t.out = (int32_t)fb_total; t.state = used; t.pstate = fs_total;
-                        jtail.push_back(t);
+                        push_midscan(jtail, t, q3);
                         bk.cells_sweep += (int64_t)64 * bk.R * gr.n1 * (1 + d.l2);
                         bk.cells_sweep += (int64_t)64 * bk.R * (1 + std::min(63, std::max(reads[r].qlen - 1, 0) / bk.R));   // the prefix sweep's own drain
                     } else
