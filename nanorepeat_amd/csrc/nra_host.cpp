@@ -1957,6 +1957,10 @@ int set_cells_common(nra_batch* b, const int8_t* read_strand, int64_t n_cells, c
     int64_t alg_cells = 0;
     std::vector<int32_t> ks;
     std::vector<int> bucket_ids;                     // by_bucket index of every entry of b->buckets
+    if (!b->brute) {
+        jbwd.reserve((size_t)n_reads); jpre.reserve((size_t)n_reads); jcomb.reserve(b->joint_v2 ? (size_t)n_reads : 0);
+        jtail.reserve((size_t)n_reads * 2);
+    }
 
     // ---- part 1: what depends on the reads and their strands only -- the reverse sweeps over R and the packed
     // sweeps of the flanks outside the scoring window -- plus the strand probes.  With every strand given these
@@ -2022,13 +2026,15 @@ int set_cells_common(nra_batch* b, const int8_t* read_strand, int64_t n_cells, c
                 }
             }
             // strand probe against the read's first listed cell: half A = template, half B = its revcomp
+            // (no probe runs when every strand is given)
             if (!bk.chain) {
-                NraPairTask t{};
-                t.read = r; t.k1a = t.k1b = k1_of(r, 0); t.k2a = t.k2b = k2_of(r, 0);
-                t.out_a = 2 * r; t.out_b = 2 * r + 1; t.flags = 3;     // B = reverse complement; raw scores
-                pair_tasks.push_back(t);
-                if (!b->all_strands_given)
+                if (!b->all_strands_given) {
+                    NraPairTask t{};
+                    t.read = r; t.k1a = t.k1b = k1_of(r, 0); t.k2a = t.k2b = k2_of(r, 0);
+                    t.out_a = 2 * r; t.out_b = 2 * r + 1; t.flags = 3;     // B = reverse complement; raw scores
+                    pair_tasks.push_back(t);
                     bk.cells_pair += 2 * sweep_cells(bk.R, d.l1 + d.m1 * t.k1a + d.l2 + d.m2 * t.k2a + d.l3);
+                }
             } else {
                 // chained: the read and a reverse-complemented shadow of it against the same template
                 NraDevRead shadow = reads[r];
