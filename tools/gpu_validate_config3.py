@@ -32,7 +32,7 @@ def score_grid(self, grid, read_strand):
     t0 = time.time()
     o = O.joint_2d(self.region, self.reads, cr, k1, k2, read_strand=read_strand)
     has = np.zeros(len(self.reads), bool); has[cr] = True
-    rounds.append({"cells": int(n_cells), "cpu_s": time.time() - t0,
+    rounds.append({"cells": int(n_cells), "cpu_s": time.time() - t0, "executed_cells": int(self.batch.stats()["executed_cells"]),
                    **{k: bool(np.array_equal(np.asarray(g[k])[has if len(o[k]) == len(has) else slice(None)],
                                              np.asarray(o[k])[has if len(o[k]) == len(has) else slice(None)])) for k in KEYS}})
     return g, n_cells
@@ -42,5 +42,5 @@ for i in range(n):
     init.read_strand_dict[f"r{i}"] = int(j["strand"][i])
 fin = J.fine_tune_read_count(init, fq, chrom, copy.deepcopy(a), copy.deepcopy(b))
 ok = all(all(v for k, v in r.items() if k in KEYS) for r in rounds)
-print(json.dumps({"reads": n, "path": "nra_batch2d_set_grid (junction at the end of mid, k_joint_midscan, k_joint_combine)", "rounds": rounds, "all_equal": ok}))
+print(json.dumps({"reads": n, "path": "nra_batch2d_set_grid (junction at the end of mid, k_joint_midscan, k_joint_combine; strands given: round 3 from the column states round 2 kept, no sweeps -- see executed_cells)", "rounds": rounds, "all_equal": ok}))
 sys.exit(0 if ok else 1)
