@@ -378,6 +378,21 @@ void fold_small_buckets(std::vector<std::vector<int32_t>>& by_bucket, size_t min
     }
 }
 
+// SIMDs of a device (4 per compute unit; 1024 on MI355X)
+int device_simds(int device)
+{
+    static std::mutex mu;
+    static std::vector<int> cache;
+    std::lock_guard<std::mutex> lk(mu);
+    if ((int)cache.size() <= device) cache.resize((size_t)device + 1, 0);
+    if (cache[(size_t)device] == 0) {
+        int cus = 0;
+        if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) != hipSuccess || cus <= 0) cus = 256;
+        cache[(size_t)device] = 4 * cus;
+    }
+    return cache[(size_t)device];
+}
+
 // Every launch of the concurrent-block sweeps (k_sweep_ringmt) tags the granules it publishes with an epoch of its own:
 // process-wide, never 0 (a zeroed strip carries none).
 uint32_t next_epoch()
@@ -925,10 +940,40 @@ int nra_batch1d_create(int device, const nra_region_t* regions, int32_t n_region
     // extents do not fit the 16-bit payload of the int32 extents kernel.
     const bool test_chain = (flags & NRA_F_TEST_CHAIN) != 0;
     // reads of more rows than this leave the one-block kernels for the chained ones (NRA_CHAIN_FROM: experiments)
-    int chain_from = NRA_MAX_QLEN_1BLOCK;
+    int chain_from = NRA_RING_MT_FROM;
     if (const char* e = getenv("NRA_CHAIN_FROM")) chain_from = std::max(64, std::min(atoi(e), NRA_MAX_QLEN_1BLOCK));
     const bool ring_units = [&] { for (int32_t g = 0; g < n_regions; ++g) if (regions[g].unit_len > NRA_SWEEP_RING_MAX_M) return false; return true; }();
     if (!ring_units || brute || (flags & (NRA_F_DPP_SWEEP | NRA_F_SERIAL_CHAIN))) chain_from = NRA_MAX_QLEN_1BLOCK;
+    if (chain_from == NRA_RING_MT_FROM && !getenv("NRA_CHAIN_FROM")) {
+        // The reads of (NRA_RING_MT_FROM, 3072] rows can go either way: one register block of 40 / 48 rows per lane -- one
+        // wave per SIMD, padding in steps of 512 rows, 4.3 T cells/s x the fill of the launch's last round of the SIMDs --
+        // or row blocks of 12 .. 15 rows per lane, three waves per SIMD: 3.7 - 4.0 T cells/s once there are two rounds
+        // of them, 1.6 + 1.5 x rounds below that (the blocks of a read lag one another).  The model is fitted to
+        // tools/gpu_block_rows.py (1000 - 10 000 reads of 2.2 - 3 kb: it picks the faster of the two in every case measured;
+        // 1000 - 5000 such reads run up to 37 % faster as blocks, config 5 20.4 -> 17.5 ms).
+        int64_t n_class = 0, rows_single = 0, rows_blocks[NRA_RING_MT_R + 1] = {0}, rows_class[NRA_RING_MT_R + 1] = {0};
+        for (int32_t r = 0; r < n_reads; ++r) {
+            const int q = pr.reads[r].qlen;
+            if (kmin[r] > kmax[r] || q <= NRA_RING_MT_FROM || max_score(sc, q) > kScoreCapBit) continue;
+            for (int R = NRA_RING_MT_R_MIN; R <= NRA_RING_MT_R; ++R) {
+                const int64_t rows = ((int64_t)q + 64 * R - 1) / (64 * R) * (64 * R);
+                rows_blocks[R] += rows;
+                if (q <= NRA_MAX_QLEN_1BLOCK) rows_class[R] += rows;
+            }
+            if (q <= NRA_MAX_QLEN_1BLOCK) { ++n_class; rows_single += 64 * (int64_t)kRList[rows_for_qlen(q)]; }
+        }
+        if (n_class > 0) {
+            int R = NRA_RING_MT_R;
+            for (int r2 = NRA_RING_MT_R - 1; r2 >= NRA_RING_MT_R_MIN; --r2) if (rows_blocks[r2] < rows_blocks[R]) R = r2;
+            const double simds = (double)device_simds(b->device);
+            const double waves = (double)((n_class + 1) / 2), nblk = (double)rows_class[R] / (64.0 * R) / (double)n_class;
+            const double r1 = waves / simds, e1 = r1 / std::ceil(r1);
+            const double r2 = waves * nblk / (3.0 * simds);
+            const double t_single = (double)rows_single / (4.3 * e1);
+            const double t_blocks = (double)rows_class[R] / std::min(3.7 + 0.1 * (R - NRA_RING_MT_R_MIN), 1.6 + 1.5 * r2);
+            if (t_single <= t_blocks) chain_from = NRA_MAX_QLEN_1BLOCK;
+        }
+    }
     std::vector<uint8_t> chained((size_t)n_reads, 0);
     for (int32_t r = 0; r < n_reads; ++r) {
         if (kmin[r] > kmax[r]) continue;
@@ -1013,13 +1058,23 @@ int nra_batch1d_create(int device, const nra_region_t* regions, int32_t n_region
             // strips than the scratch budget holds (then: one wave per read, block after block, two strips)
             bk.mt = bk.ring && (flags & NRA_F_SERIAL_CHAIN) == 0;
             if (bk.mt) {
-                const int rows = 64 * (test_chain ? NRA_CHAIN_R_TEST : NRA_RING_MT_R);
+                const int rows = 64 * (test_chain ? NRA_CHAIN_R_TEST : NRA_RING_MT_R_MIN);      // (the shortest block there is)
                 int qmax = 0;
                 for (int32_t r : by_bucket[bi]) qmax = std::max(qmax, pr.reads[r].qlen);
                 const size_t fit = (size_t)(NRA_CHAIN_SCRATCH_BUDGET / 2) / ((size_t)5 * 8 * (size_t)b->chain_cap);
                 if ((size_t)((qmax + rows - 1) / rows) > fit + 1) bk.mt = false;
             }
             bk.R = test_chain ? NRA_CHAIN_R_TEST : (bk.mt ? NRA_RING_MT_R : bk.ring ? NRA_RING_CHAIN_R : NRA_CHAIN_R);
+            if (bk.mt && !test_chain && !bk.wide) {
+                // the block height that pads the bucket's reads least (ties: the taller block, fewer hand-offs; the int32
+                // blocks of the longest reads stay at 15: 7.7 kb cores 96 ms against 102 ms at 14 with 0.5 % fewer cells)
+                int64_t best = -1;
+                for (int R = NRA_RING_MT_R; R >= NRA_RING_MT_R_MIN; --R) {
+                    int64_t rows = 0;
+                    for (int32_t r : by_bucket[bi]) rows += ((int64_t)pr.reads[r].qlen + 64 * R - 1) / (64 * R) * (64 * R);
+                    if (best < 0 || rows < best) { best = rows; bk.R = R; }
+                }
+            }
         } else {
             bk.R = kRList[bk.half ? bi - kNumR - 2 : bi];
         }

@@ -1592,9 +1592,15 @@ static int launch_sweep_ringmt(int R, int has_n, int wide, hipStream_t st, int n
         else { if (has_n) k_sweep_ringmt<r, true, DIR, false><<<n_blocks, WAVE, 0, st>>>(ARGS);          \
                else k_sweep_ringmt<r, false, DIR, false><<<n_blocks, WAVE, 0, st>>>(ARGS); }             \
     } while (0)
-    if (R == NRA_RING_MT_R) LAUNCH(NRA_RING_MT_R);
-    else if (R == NRA_CHAIN_R_TEST) LAUNCH(NRA_CHAIN_R_TEST);
-    else return (int)hipErrorInvalidValue;
+    // (the host picks the block height that pads a bucket's reads least: NRA_RING_MT_R_MIN .. NRA_RING_MT_R rows per lane)
+    switch (R) {
+    case 15: LAUNCH(15); break;
+    case 14: LAUNCH(14); break;
+    case 13: LAUNCH(13); break;
+    case 12: LAUNCH(12); break;
+    case NRA_CHAIN_R_TEST: LAUNCH(NRA_CHAIN_R_TEST); break;
+    default: return (int)hipErrorInvalidValue;
+    }
 #undef LAUNCH
 #undef ARGS
     return (int)hipGetLastError();

@@ -16,7 +16,9 @@ from . import _capi
 
 # rows-per-lane instantiations of the sweep kernels (csrc/nra_internal.h NRA_R_LIST)
 _R_LIST = np.array([1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16, 18, 20, 22, 24, 28, 32, 40, 48], np.int64)
-_CHAIN_ROWS = 64 * 15      # NRA_RING_MT_R: reads beyond one register block run as chained blocks of 960 rows
+_CHAIN_FROM = 2048         # NRA_RING_MT_FROM: reads of more rows run as row blocks (units the LDS ring holds; else from 3072)
+_BLOCK_R = (15, 14, 13, 12)    # NRA_RING_MT_R .. NRA_RING_MT_R_MIN: rows per lane of a block, the height that pads a bucket least
+_PACKED_MAX_QLEN = 6750    # doubled scores of longer reads leave the int16 range: int32 blocks, a bucket of their own
 _HALF_WAVE_MAX_QLEN = 32 * 24     # NRA_RING32_MAX_R: up to here a read pair takes half a wave (k_sweep_ring32)
 _RING_MAX_UNIT = 8         # NRA_SWEEP_RING_MAX_M: longer units keep the DPP sweeps (128 columns in flight)
 
@@ -43,16 +45,57 @@ def _rows_per_lane(need, min_reads=0, span=2):
     return _R_LIST[idx]
 
 
+_SIMDS = 1024              # MI355X: 256 compute units x 4
+
+
+def _prefer_row_blocks(q, either):
+    """The library's choice for a batch's reads of (2048, 3072] rows (nra_batch1d_create, csrc/nra_host.cpp): one
+    register block per read -- one wave per SIMD, 4.3 T cells/s x the fill of the launch's last round of the SIMDs -- or
+    row blocks, three waves per SIMD, 3.7 - 4.0 T cells/s from two rounds on, 1.6 + 1.5 x rounds below."""
+    blocks = q[(q > _CHAIN_FROM) & (q <= _PACKED_MAX_QLEN)]
+    cls = q[either]
+    total = {r: int(((blocks + 64 * r - 1) // (64 * r) * (64 * r)).sum()) for r in _BLOCK_R}
+    best = _BLOCK_R[0]
+    for r in _BLOCK_R[1:]:                            # (ties: the taller block)
+        if total[r] < total[best]:
+            best = r
+    rows_blocks = int(((cls + 64 * best - 1) // (64 * best) * (64 * best)).sum())
+    rows_single = int((64 * _R_LIST[np.searchsorted(_R_LIST, (cls + 63) // 64)]).sum())
+    n = len(cls)
+    waves, nblk = (n + 1) // 2, rows_blocks / (64.0 * best) / n
+    r1 = waves / _SIMDS
+    e1 = r1 / np.ceil(r1)
+    r2 = waves * nblk / (3.0 * _SIMDS)
+    return rows_single / (4.3 * e1) > rows_blocks / min(3.7 + 0.1 * (best - _BLOCK_R[-1]), 1.6 + 1.5 * r2)
+
+
 def padded_rows(qlen, unit_len=None, fold=False):
     """Rows the sweeps execute for a read of qlen bases: 32 x rows-per-lane in the half-wave kernel (reads of up to
-    768 bases, units of up to 8), 64 x rows-per-lane up to 3072 bases, chained 960-row blocks beyond.  fold: the
-    reads are one batch, whose small rows-per-lane buckets are folded as the library folds them."""
+    768 bases, units of up to 8), 64 x rows-per-lane up to 2048 bases (3072 with longer units), row blocks of 64 x 12 .. 15
+    rows beyond.  fold: the reads are one batch, whose small rows-per-lane buckets are folded as the library folds them
+    and whose row blocks have one height."""
     q = np.asarray(qlen, np.int64)
     m = np.full(q.shape, 1, np.int64) if unit_len is None else np.asarray(unit_len, np.int64)
     is_chain = q > 64 * _R_LIST[-1]
+    either = ~is_chain & (q > _CHAIN_FROM)            # one register block (40 / 48 rows per lane) or row blocks
+    if either.any() and bool(np.all(m <= _RING_MAX_UNIT)):
+        if fold:
+            is_chain = is_chain | (either & _prefer_row_blocks(q, either))
+        else:
+            is_chain = is_chain | either              # (a read on its own: blocks)
     is_half = ~is_chain & (q <= _HALF_WAVE_MAX_QLEN) & (m <= _RING_MAX_UNIT)
     is_full = ~is_chain & ~is_half
-    rows = (q + _CHAIN_ROWS - 1) // _CHAIN_ROWS * _CHAIN_ROWS
+    rows = np.zeros(q.shape, np.int64)
+    wide = is_chain & (q > _PACKED_MAX_QLEN)       # int32 blocks: always 15 rows per lane
+    rows[wide] = (q[wide] + 64 * _BLOCK_R[0] - 1) // (64 * _BLOCK_R[0]) * (64 * _BLOCK_R[0])
+    for group in (is_chain & ~wide,):
+        if not group.any():
+            continue
+        padded = np.stack([(q[group] + 64 * r - 1) // (64 * r) * (64 * r) for r in _BLOCK_R])      # [height, read]
+        if fold:                                   # one batch: one height for the bucket (ties: the taller block; _BLOCK_R descends)
+            rows[group] = padded[int(np.argmin(padded.sum(axis=1)))]
+        else:
+            rows[group] = padded.min(axis=0)
     if is_half.any():
         rows = np.where(is_half, 0, rows)
         rows[is_half] = 32 * _rows_per_lane((q[is_half] + 31) // 32, 2048 if fold else 0)

@@ -551,6 +551,44 @@ def test_row_blocks_as_concurrent_waves(capi, oracle):
         assert np.array_equal(s[k], o[k]), k
 
 
+def test_row_block_heights_and_the_choice_for_2_to_3_kb_reads(capi, oracle):
+    """Reads of 2049 - 3072 bases run as row blocks when that is the cheaper form for the batch (a few reads: always),
+    in blocks of 64 x 12 .. 15 rows -- the height that pads the bucket least: one batch per height here, each against the
+    oracle, against one register block per read (NRA_CHAIN_FROM=3072), and with the executed cells dist.py predicts."""
+    import os
+    from nanorepeat_amd import dist as D
+    rng = np.random.default_rng(58)
+    L, R = synth.rand_seq(rng, 300), synth.rand_seq(rng, 260)
+    region = [(L, "TATTG", R)]
+    for k_true, rows_per_lane in ((410, 12), (450, 13), (490, 14), (530, 15)):
+        reads, kmin, kmax = [], [], []
+        for i in range(6):                  # (pairs of reads share a wave: an even number, for the cost model's sake)
+            reads.append(synth.apply_errors(rng, L[-90:] + "TATTG" * (k_true + i % 5) + R[:90], "hifi"))
+            kmin.append(k_true - 3); kmax.append(k_true + 6)
+        q = [len(r) for r in reads]
+        assert 64 * rows_per_lane * 2 < min(q) and max(q) <= 64 * rows_per_lane * 3, q
+        o = oracle.round3_1d(region, reads, kmin, kmax)
+        executed = {}
+        for form, env in (("blocks", None), ("one block", "3072")):
+            if env is None:
+                os.environ.pop("NRA_CHAIN_FROM", None)
+            else:
+                os.environ["NRA_CHAIN_FROM"] = env
+            try:
+                with capi.Batch.create_1d(region, reads, kmin, kmax) as b:
+                    b.run(); b.sync()
+                    g = b.fetch(); executed[form] = b.stats()["executed_cells"]
+            finally:
+                os.environ.pop("NRA_CHAIN_FROM", None)
+            for k in ("best_score", "sum_k", "n_ties", "status", "cand_score"):
+                assert np.array_equal(g[k], o[k]), (k_true, form, k)
+        # 3 blocks of the expected height against 40 / 48 rows per lane in one block
+        ratio = executed["blocks"] * (48 if max(q) > 2560 else 40) / (executed["one block"] * 3 * rows_per_lane)
+        assert abs(ratio - 1) < 0.01, (k_true, executed)
+        model = int(D.executed_cells(region, q, kmax, [0] * 6).sum())
+        assert abs(model - executed["blocks"]) <= 0.02 * executed["blocks"], (k_true, model, executed)
+
+
 def test_one_read_against_a_megabase_template(capi, oracle):
     """A template far beyond the 16-bit extents of the int32 cells (1.2 M columns: k = 240 000 units of 5 bases):
     the read runs as a chained int32 sweep and its ties through the int64 extents kernel.  The scratch strips of

@@ -1,7 +1,7 @@
 """Differential fuzzing of the HIP path against the CPU oracle: random regions, motifs, flank
 lengths, windows, scoring parameters, N bases and adversarial reads (missing flanks, junction
 indels, junk).  Usage: python tools/gpu_fuzz.py [n_rounds] [seed]"""
-import sys, time
+import os, sys, time
 import numpy as np
 sys.path.insert(0, '.')
 from nanorepeat_amd import _capi as A, synth
@@ -66,6 +66,33 @@ def fuzz_1d(rng):
         for k in keys:
             if not np.array_equal(g[k], o[k]):
                 return dict(kind="1d", flags=flags, key=k, L=L, unit=unit, R=R, reads=reads, kmin=kmin, kmax=kmax, sc=sc,
+                            got=g[k].tolist(), want=o[k].tolist())
+    return None
+
+
+def fuzz_1d_blocks(rng):
+    """Reads of 2 - 3.6 kb: row blocks of 64 x 12 .. 15 rows (the height that pads the batch least), the one-wave chain,
+    and one register block per read where that holds them (NRA_CHAIN_FROM=3072)."""
+    m = int(rng.integers(1, 9)); unit = synth.rand_unit(rng, m)
+    L = synth.rand_seq(rng, int(rng.choice([60, 150, 400]))); R = synth.rand_seq(rng, int(rng.choice([60, 150, 400])))
+    reads, kmin, kmax = [], [], []
+    for _ in range(int(rng.integers(1, 5))):
+        fl, fr = int(rng.integers(20, len(L) + 1)), int(rng.integers(20, len(R) + 1))
+        k = int((int(rng.integers(2060, 3600)) - fl - fr) // m)
+        s = synth.apply_errors(rng, L[len(L) - fl:] + unit * k + R[:fr], ["hifi", "ont_q20", "ont"][int(rng.integers(0, 3))])
+        reads.append(s if rng.random() < 0.8 else mangle(rng, s))
+        lo = max(0, k - int(rng.integers(0, 4))); kmin.append(lo); kmax.append(lo + int(rng.integers(0, 6)))
+    o = O.round3_1d([(L, unit, R)], reads, kmin, kmax)
+    for flags, env in ((0, None), (0, "3072"), (A.F_SERIAL_CHAIN, None)):
+        if env is None: os.environ.pop("NRA_CHAIN_FROM", None)
+        else: os.environ["NRA_CHAIN_FROM"] = env
+        try:
+            g = A.round3_1d([(L, unit, R)], reads, kmin, kmax, flags=flags)
+        finally:
+            os.environ.pop("NRA_CHAIN_FROM", None)
+        for k in K1:
+            if not np.array_equal(g[k], o[k]):
+                return dict(kind="1d-blocks", flags=flags, env=env, key=k, L=L, unit=unit, R=R, reads=reads, kmin=kmin, kmax=kmax,
                             got=g[k].tolist(), want=o[k].tolist())
     return None
 
@@ -234,7 +261,7 @@ if __name__ == "__main__":
     rng = np.random.default_rng(seed)
     t0 = time.time(); bad = 0
     for i in range(rounds):
-        for f in (fuzz_1d, fuzz_1d_multi, fuzz_2d, fuzz_2d_grid, fuzz_pairs):
+        for f in (fuzz_1d, fuzz_1d_multi, fuzz_1d_blocks, fuzz_2d, fuzz_2d_grid, fuzz_pairs):
             r = f(rng)
             if r is not None:
                 bad += 1
