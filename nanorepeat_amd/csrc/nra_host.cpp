@@ -945,12 +945,12 @@ int nra_batch1d_create(int device, const nra_region_t* regions, int32_t n_region
     const bool ring_units = [&] { for (int32_t g = 0; g < n_regions; ++g) if (regions[g].unit_len > NRA_SWEEP_RING_MAX_M) return false; return true; }();
     if (!ring_units || brute || (flags & (NRA_F_DPP_SWEEP | NRA_F_SERIAL_CHAIN))) chain_from = NRA_MAX_QLEN_1BLOCK;
     if (chain_from == NRA_RING_MT_FROM && !getenv("NRA_CHAIN_FROM")) {
-        // The reads of (NRA_RING_MT_FROM, 3072] rows can go either way: one register block of 40 / 48 rows per lane -- one
-        // wave per SIMD, padding in steps of 512 rows, 4.3 T cells/s x the fill of the launch's last round of the SIMDs --
-        // or row blocks of 12 .. 15 rows per lane, three waves per SIMD: 3.7 - 4.0 T cells/s once there are two rounds
-        // of them, 1.6 + 1.5 x rounds below that (the blocks of a read lag one another).  The model is fitted to
-        // tools/gpu_block_rows.py (1000 - 10 000 reads of 2.2 - 3 kb: it picks the faster of the two in every case measured;
-        // 1000 - 5000 such reads run up to 37 % faster as blocks, config 5 20.4 -> 17.5 ms).
+        // The reads of (NRA_RING_MT_FROM, 3072] rows can go either way: one register block of 28 - 48 rows per lane -- one
+        // wave per SIMD, padding in steps of 256 / 512 rows, 4.3 T cells/s x the fill of the launch's last round of the
+        // SIMDs -- or row blocks of 12 .. 15 rows per lane, three waves per SIMD: 3.7 - 4.0 T cells/s (4.1 - 4.4 with two
+        // blocks per read) once there are two rounds of them, 1.9 + 1.2 x rounds - 0.25 x (blocks per read - 2) below that
+        // (the blocks of a read lag one another).  The model is fitted to tools/gpu_block_rows.py (1000 - 10 000 reads of 1.6 - 3 kb: it picks the
+        // faster form, or one within 3 %, in 48 of 50 cases; such reads run up to 37 % faster as blocks, config 5 20.4 -> 17.3 ms).
         int64_t n_class = 0, rows_single = 0, rows_blocks[NRA_RING_MT_R + 1] = {0}, rows_class[NRA_RING_MT_R + 1] = {0};
         for (int32_t r = 0; r < n_reads; ++r) {
             const int q = pr.reads[r].qlen;
@@ -970,7 +970,8 @@ int nra_batch1d_create(int device, const nra_region_t* regions, int32_t n_region
             const double r1 = waves / simds, e1 = r1 / std::ceil(r1);
             const double r2 = waves * nblk / (3.0 * simds);
             const double t_single = (double)rows_single / (4.3 * e1);
-            const double t_blocks = (double)rows_class[R] / std::min(3.7 + 0.1 * (R - NRA_RING_MT_R_MIN), 1.6 + 1.5 * r2);
+            const double cap = 3.7 + 0.1 * (R - NRA_RING_MT_R_MIN) + (nblk < 2.5 ? 0.4 : 0.0);
+            const double t_blocks = (double)rows_class[R] / std::min(cap, 1.9 + 1.2 * r2 - 0.25 * (nblk - 2.0));
             if (t_single <= t_blocks) chain_from = NRA_MAX_QLEN_1BLOCK;
         }
     }
@@ -1020,7 +1021,6 @@ int nra_batch1d_create(int device, const nra_region_t* regions, int32_t n_region
     }
     if ((!by_bucket[kNumR].empty() || !by_bucket[kNumR + 1].empty()) && brute)
         return fail(NRA_E_RANGE, "NRA_F_TEST_CHAIN needs the junction decomposition (no brute force / ALL_EXTENTS, flanks >= 1)");
-    b->chain_cap = (chain_cols + 127) / 64 * 64 + 64;
     clk.mark("  reads to buckets");
     {   // small buckets fold into the next instantiation of their own kind
         std::vector<std::vector<int32_t>> full(by_bucket.begin(), by_bucket.begin() + kNumR);
@@ -1029,6 +1029,24 @@ int nra_batch1d_create(int device, const nra_region_t* regions, int32_t n_region
         fold_small_buckets(halfb, 2048, 2);
         for (int i = 0; i < kNumR; ++i) { by_bucket[i] = std::move(full[i]); by_bucket[kNumR + 2 + i] = std::move(halfb[i]); }
     }
+    if (chain_from < NRA_MAX_QLEN_1BLOCK && !test_chain && !by_bucket[kNumR + 1].empty()) {
+        // ... and what is left of the one-block buckets above one row block (reads of 961 - 3072 bases, fewer than 1024
+        // of a kind) joins the row blocks, where there are any: a length distribution that straddles NRA_RING_MT_FROM
+        // would otherwise leave a handful of reads a launch of their own (1000 reads of 1528 - 1582 bases, 24 of them
+        // below the line: 4.2 ms against 2.7)
+        for (int bi = 0; bi < kNumR; ++bi) {
+            if (kRList[bi] <= NRA_RING_MT_R || by_bucket[bi].empty() || by_bucket[bi].size() >= 1024) continue;
+            for (int32_t r : by_bucket[bi]) {
+                const nra_region_t& rg = regions[pr.reads[r].region];
+                chain_cols = std::max(chain_cols, rg.left_len + rg.unit_len * kmax[r] + rg.right_len);
+                chained[r] = 1;
+                read_bucket[r] = kNumR + 1;
+                by_bucket[kNumR + 1].push_back(r);
+            }
+            by_bucket[bi].clear();
+        }
+    }
+    b->chain_cap = (chain_cols + 127) / 64 * 64 + 64;
     clk.mark("  small buckets folded");
     size_t strip_total = 0, chain_queue_cap = 0, mt_strip_total = 0;
     std::vector<NraChainBlock> chain_blocks;

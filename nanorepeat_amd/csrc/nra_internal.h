@@ -260,8 +260,8 @@ int nra_launch_sweep_ring32_fwd(int R, int has_n, hipStream_t st, int n_tasks, c
 #ifndef NRA_RING_MT_R
 #define NRA_RING_MT_R 15
 #endif
-#define NRA_RING_MT_FROM 2048                  // reads of more rows than this run as row blocks: one register block would take 40 or
-                                               // 48 rows per lane (one wave per SIMD, steps of 512 rows of padding) -- config 5: 20.4 -> 17.3 ms
+#define NRA_RING_MT_FROM 1536                  // reads of more rows than this may run as row blocks: one register block would take 28 - 48
+                                               // rows per lane, one wave per SIMD (the batch takes the cheaper form: nra_batch1d_create)
 #define NRA_RING_MT_R_MIN 12                   // ... down to 12: the host takes the height that pads a bucket's reads least
 int nra_launch_sweep_ringchain_bwd(int R, int has_n, int wide, hipStream_t st, int n_tasks,
                                    const NraSweepTask* tasks, const NraDevRead* reads,

@@ -16,7 +16,7 @@ from . import _capi
 
 # rows-per-lane instantiations of the sweep kernels (csrc/nra_internal.h NRA_R_LIST)
 _R_LIST = np.array([1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16, 18, 20, 22, 24, 28, 32, 40, 48], np.int64)
-_CHAIN_FROM = 2048         # NRA_RING_MT_FROM: reads of more rows run as row blocks (units the LDS ring holds; else from 3072)
+_CHAIN_FROM = 1536         # NRA_RING_MT_FROM: reads of more rows may run as row blocks (units the LDS ring holds; else from 3072)
 _BLOCK_R = (15, 14, 13, 12)    # NRA_RING_MT_R .. NRA_RING_MT_R_MIN: rows per lane of a block, the height that pads a bucket least
 _PACKED_MAX_QLEN = 6750    # doubled scores of longer reads leave the int16 range: int32 blocks, a bucket of their own
 _HALF_WAVE_MAX_QLEN = 32 * 24     # NRA_RING32_MAX_R: up to here a read pair takes half a wave (k_sweep_ring32)
@@ -49,9 +49,9 @@ _SIMDS = 1024              # MI355X: 256 compute units x 4
 
 
 def _prefer_row_blocks(q, either):
-    """The library's choice for a batch's reads of (2048, 3072] rows (nra_batch1d_create, csrc/nra_host.cpp): one
+    """The library's choice for a batch's reads of (1536, 3072] rows (nra_batch1d_create, csrc/nra_host.cpp): one
     register block per read -- one wave per SIMD, 4.3 T cells/s x the fill of the launch's last round of the SIMDs -- or
-    row blocks, three waves per SIMD, 3.7 - 4.0 T cells/s from two rounds on, 1.6 + 1.5 x rounds below."""
+    row blocks, three waves per SIMD, 3.7 - 4.4 T cells/s from two rounds on, less below (the blocks of a read lag one another)."""
     blocks = q[(q > _CHAIN_FROM) & (q <= _PACKED_MAX_QLEN)]
     cls = q[either]
     total = {r: int(((blocks + 64 * r - 1) // (64 * r) * (64 * r)).sum()) for r in _BLOCK_R}
@@ -66,42 +66,48 @@ def _prefer_row_blocks(q, either):
     r1 = waves / _SIMDS
     e1 = r1 / np.ceil(r1)
     r2 = waves * nblk / (3.0 * _SIMDS)
-    return rows_single / (4.3 * e1) > rows_blocks / min(3.7 + 0.1 * (best - _BLOCK_R[-1]), 1.6 + 1.5 * r2)
+    cap = 3.7 + 0.1 * (best - _BLOCK_R[-1]) + (0.4 if nblk < 2.5 else 0.0)
+    return rows_single / (4.3 * e1) > rows_blocks / min(cap, 1.9 + 1.2 * r2 - 0.25 * (nblk - 2.0))
 
 
 def padded_rows(qlen, unit_len=None, fold=False):
     """Rows the sweeps execute for a read of qlen bases: 32 x rows-per-lane in the half-wave kernel (reads of up to
-    768 bases, units of up to 8), 64 x rows-per-lane up to 2048 bases (3072 with longer units), row blocks of 64 x 12 .. 15
-    rows beyond.  fold: the reads are one batch, whose small rows-per-lane buckets are folded as the library folds them
+    768 bases, units of up to 8), 64 x rows-per-lane up to 1536 bases (3072 with longer units, or where one block is the
+    cheaper form for the batch), row blocks of 64 x 12 .. 15 rows beyond.  fold: the reads are one batch, whose small rows-per-lane buckets are folded as the library folds them
     and whose row blocks have one height."""
     q = np.asarray(qlen, np.int64)
     m = np.full(q.shape, 1, np.int64) if unit_len is None else np.asarray(unit_len, np.int64)
     is_chain = q > 64 * _R_LIST[-1]
-    either = ~is_chain & (q > _CHAIN_FROM)            # one register block (40 / 48 rows per lane) or row blocks
-    if either.any() and bool(np.all(m <= _RING_MAX_UNIT)):
-        if fold:
-            is_chain = is_chain | (either & _prefer_row_blocks(q, either))
-        else:
-            is_chain = is_chain | either              # (a read on its own: blocks)
+    either = ~is_chain & (q > _CHAIN_FROM)            # one register block (28 .. 48 rows per lane) or row blocks
+    ring_units = bool(np.all(m <= _RING_MAX_UNIT))
+    blocks_chosen = ring_units and (not fold or not either.any() or bool(_prefer_row_blocks(q, either)))
+    if blocks_chosen:                                 # (a read on its own, fold = False: blocks)
+        is_chain = is_chain | either
     is_half = ~is_chain & (q <= _HALF_WAVE_MAX_QLEN) & (m <= _RING_MAX_UNIT)
     is_full = ~is_chain & ~is_half
     rows = np.zeros(q.shape, np.int64)
+    if is_full.any():
+        lanes = _rows_per_lane((q[is_full] + 63) // 64, 1024 if fold else 0)
+        if fold and blocks_chosen and bool((is_chain & (q <= _PACKED_MAX_QLEN)).any()):
+            # what is left of the one-block buckets above one row block joins the row blocks (fewer than 1024 reads of a kind)
+            count = np.bincount(lanes, minlength=int(_R_LIST[-1]) + 1)
+            moved = (lanes > _BLOCK_R[0]) & (count[lanes] < 1024)
+            idx = np.nonzero(is_full)[0]
+            is_chain[idx[moved]] = True
+            is_full[idx[moved]] = False
+            lanes = lanes[~moved]
+        rows[is_full] = 64 * lanes
     wide = is_chain & (q > _PACKED_MAX_QLEN)       # int32 blocks: always 15 rows per lane
     rows[wide] = (q[wide] + 64 * _BLOCK_R[0] - 1) // (64 * _BLOCK_R[0]) * (64 * _BLOCK_R[0])
-    for group in (is_chain & ~wide,):
-        if not group.any():
-            continue
+    group = is_chain & ~wide
+    if group.any():
         padded = np.stack([(q[group] + 64 * r - 1) // (64 * r) * (64 * r) for r in _BLOCK_R])      # [height, read]
         if fold:                                   # one batch: one height for the bucket (ties: the taller block; _BLOCK_R descends)
             rows[group] = padded[int(np.argmin(padded.sum(axis=1)))]
         else:
             rows[group] = padded.min(axis=0)
     if is_half.any():
-        rows = np.where(is_half, 0, rows)
         rows[is_half] = 32 * _rows_per_lane((q[is_half] + 31) // 32, 2048 if fold else 0)
-    if is_full.any():
-        rows = np.where(is_full, 0, rows)
-        rows[is_full] = 64 * _rows_per_lane((q[is_full] + 63) // 64, 1024 if fold else 0)
     return rows
 
 

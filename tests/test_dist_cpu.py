@@ -178,11 +178,16 @@ def test_region_block_sharder_properties():
     owner = D.shard_region_blocks(np.full(1000, 7), None, 8)
     assert np.bincount(owner, minlength=8).min() >= 100
     # executed-cell cost: padded rows x executed columns (csrc/nra_host.cpp: half-wave sweeps up to 768 bases with a
-    # pipeline 31 lanes deep, full-wave ones up to 2048 with 63, row blocks of 64 x 12 .. 15 rows beyond -- the height that
+    # pipeline 31 lanes deep, full-wave ones up to 1536 with 63, row blocks of 64 x 12 .. 15 rows beyond -- the height that
     # pads least; the forward pipeline is skewed by the unit length)
-    cells = D.executed_cells([("A" * 10, "CAG", "T" * 7)], [5, 65, 769, 2048, 2049, 3073], [4] * 6, fold=False)
+    cells = D.executed_cells([("A" * 10, "CAG", "T" * 7)], [5, 65, 769, 1536, 1537, 2049, 3073], [4] * 7, fold=False)
     assert cells.tolist() == [32 * (17 + 12 + 31 * 4), 96 * (17 + 12 + 31 * 4), 64 * 13 * (17 + 12 + 63 * 4),
-                              64 * 32 * (17 + 12 + 63 * 4), 3 * 768 * (17 + 12 + 63 * 4), 4 * 832 * (17 + 12 + 63 * 4)]
+                              64 * 24 * (17 + 12 + 63 * 4), 2 * 832 * (17 + 12 + 63 * 4), 3 * 768 * (17 + 12 + 63 * 4),
+                              4 * 832 * (17 + 12 + 63 * 4)]
+    # many reads of one length: one register block where the launch fills whole rounds of the SIMDs (4000 reads = 2000
+    # waves on 1024 SIMDs), row blocks where it does not (5000 reads) -- the library's own choice (nra_batch1d_create)
+    assert int(D.padded_rows(np.full(4000, 2230), np.full(4000, 5), fold=True)[0]) == 64 * 40
+    assert int(D.padded_rows(np.full(5000, 2230), np.full(5000, 5), fold=True)[0]) == 3 * 768
     # as one batch the row blocks have one height: 13 rows per lane pad 2049 + 3073 bases least (2496 + 3328 rows)
     assert D.executed_cells([("A" * 10, "CAG", "T" * 7)], [2049, 3073], [4, 4]).tolist() == [3 * 832 * (17 + 12 + 63 * 4), 4 * 832 * (17 + 12 + 63 * 4)]
     # as one batch: the lone 5-base read joins the 3-rows-per-lane bucket of the 65-base one (fold_small_buckets)
