@@ -635,7 +635,7 @@ def sub_record(args, config):
     """One of the other BASELINE workloads at N = 1 for the default run's `configs`: a few steps, a shorter CPU sample."""
     sub = argparse.Namespace(**vars(args))
     sub.config = config
-    sub.steps, sub.warmup = (2, 1) if config == 4 else (3, 1)
+    sub.steps, sub.warmup = {3: (12, 2), 4: (2, 1), 5: (5, 1)}[config]      # (config 3's 8 ms steps are half host: three of them are noise)
     sub.reads = 10000
     sub.one_shot_calls = min(args.one_shot_calls, 2 if config == 4 else 3)
     sub.cpu_seconds = 6.0
