@@ -615,17 +615,26 @@ def bench_joint(args):
         cores = host_cores()
         secs = getattr(args, "cpu_seconds", 10.0)
         m = min(n, int(6.4 * secs * cores)) if args.cpu_sample < 0 else min(args.cpu_sample, n)
-        cr, c1, c2 = [], [], []
-        for r in range(m):
-            for x in range(int(j["range1"][r][0]), int(j["range1"][r][1]), 7):
-                for y in range(int(j["range2"][r][0]), int(j["range2"][r][1]), 7):
-                    cr.append(r); c1.append(x); c2.append(y)
+        # a coarse routed grid (step 7 on both axes) over the first m reads' round-1 ranges: the oracle cell by cell, and the
+        # product path on the same grid (routing in the library, junction at the end of mid) for the comparison
+        r1, r2 = np.asarray(j["range1"][:m], np.float64), np.asarray(j["range2"][:m], np.float64)
+        grid = A.Grid((0, 7, int(r1[:, 1].max()) // 7 + 1), r1[:, 0], r1[:, 1], (0, 7, int(r2[:, 1].max()) // 7 + 1), r2[:, 0], r2[:, 1])
+        cr, c1, c2 = A.joint_grid_cells(grid)
+        strands_m = np.asarray(j["strand"][:m], np.int8)
         t0 = time.perf_counter()
-        O.joint_2d(j["region"], j["reads"][:m], cr, c1, c2, threads=cores)
+        want = O.joint_2d(j["region"], j["reads"][:m], cr, c1, c2, read_strand=strands_m, threads=cores)
         dtc = time.perf_counter() - t0
+        with A.Batch.create_2d_reads(j["region"], j["reads"][:m], device=local_rank) as sample_batch:
+            sample_batch.set_grid(grid, strands_m)
+            sample_batch.run(); sample_batch.sync()
+            have = sample_batch.fetch()
+        listed = np.zeros(m, bool); listed[cr] = True
+        same = all(np.array_equal(np.asarray(have[k])[listed if len(want[k]) == m else slice(None)],
+                                  np.asarray(want[k])[listed if len(want[k]) == m else slice(None)]) for k in want)
         line["cpu_baseline"] = {"value": len(cr) / dtc, "unit": "read-alignments/s", "cores": cores, "kind": "port",
-                                "sample": f"first {m} reads x their step-7 grid = {len(cr)} cells in {dtc:.1f} s; CPU "
-                                          "restatement (one optimal DP with window payload per cell), not minimap2"}
+                                "sample": f"first {m} reads x the step-7 grid over their round-1 ranges = {len(cr)} cells in {dtc:.1f} s; CPU "
+                                          "restatement (one optimal DP with window payload per cell), not minimap2",
+                                "gpu_matches_sample": bool(same)}
         if line["value_scorer_call"]:
             line["cpu_baseline"]["gpu_over_cpu"] = line["value_scorer_call"] / line["cpu_baseline"]["value"]
     return line
