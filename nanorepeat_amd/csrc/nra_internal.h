@@ -236,7 +236,8 @@ int nra_launch_sweep_ring_fwd(int R, int has_n, hipStream_t st, int n_tasks, con
                               int32_t* snap, int32_t* read_a, int32_t* cand_score, uint8_t* cand_flag);
 
 // half-wave LDS-ring sweeps (k_sweep_ring32): reads of up to 32 * NRA_RING32_MAX_R bases, two read pairs of one
-// region per wave (32 lanes each); R from NRA_R_LIST up to NRA_RING32_MAX_R (16: 301.8, 20: 299.7, 24: 297.4 ms on config 4)
+// region per wave (32 lanes each); R from NRA_R_LIST up to NRA_RING32_MAX_R (16: 301.8, 20: 299.7, 24: 297.4 ms on config 4;
+// 32, which would take config 2's 950-base reads too: 5.65 -> 7.1 ms there, 281 -> 288 ms on config 4)
 #define NRA_RING32_MAX_R 24
 int nra_launch_sweep_ring32_bwd(int R, int has_n, hipStream_t st, int n_tasks, const NraSweepTask* tasks,
                                 const NraDevRead* reads, const NraDevRegion* regions, const uint8_t* pool,
