@@ -949,8 +949,10 @@ int nra_batch1d_create(int device, const nra_region_t* regions, int32_t n_region
         // wave per SIMD, padding in steps of 256 / 512 rows, 4.3 T cells/s x the fill of the launch's last round of the
         // SIMDs -- or row blocks of 12 .. 15 rows per lane, three waves per SIMD: 3.7 - 4.0 T cells/s (4.1 - 4.4 with two
         // blocks per read) once there are two rounds of them, 1.9 + 1.2 x rounds - 0.25 x (blocks per read - 2) below that
-        // (the blocks of a read lag one another).  The model is fitted to tools/gpu_block_rows.py (1000 - 10 000 reads of 1.6 - 3 kb: it picks the
-        // faster form, or one within 3 %, in 48 of 50 cases; such reads run up to 37 % faster as blocks, config 5 20.4 -> 17.3 ms).
+        // (the blocks of a read lag one another).  The model is fitted to tools/gpu_block_rows.py: on 1000 - 10 000 reads
+        // of 1.6 - 3 kb it picks the faster form, or one within 3 %, in 54 of 54 cases
+        // (profiles/r03_row_blocks_or_one_block_54_cases.txt); such reads run up to 37 % faster as blocks, config 5
+        // 20.4 -> 17.3 ms.
         int64_t n_class = 0, rows_single = 0, rows_blocks[NRA_RING_MT_R + 1] = {0}, rows_class[NRA_RING_MT_R + 1] = {0};
         for (int32_t r = 0; r < n_reads; ++r) {
             const int q = pr.reads[r].qlen;
