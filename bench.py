@@ -447,7 +447,9 @@ def bench_1d(args):
         est = out["sum_k"][index][mine] / np.maximum(out["n_ties"][index][mine], 1)
         exact = float(np.mean(est == data["k_true"][mine])) if mine.any() else 0.0
         kern = ("k_score_pk16<R>" if args.brute else
-                "k_sweep_ring<R,dir> / k_sweep_ring32<R,dir> (reverse + forward sweeps of all read-length buckets)")
+                "k_sweep_ring<R,dir> / k_sweep_ring32<R,dir> (reverse + forward sweeps of all read-length buckets)" +
+                (" + k_sweep_ringmt<R,dir> (the reads beyond 1.5 kb as row blocks where that is the cheaper form)"
+                 if max(len(r) for r in data["reads"]) > 1536 else ""))
         line = {
             "metric": "read-alignments/sec (reads x candidate-k)",
             "value": n_align * args.steps / dt, "unit": "read-alignments/s",
