@@ -91,6 +91,8 @@ def parse():
                     help="config 3, comparison: tail sweeps with the junction at R[0] (NRA_F_JOINT_TAILS) instead of the junction at the end of mid")
     ap.add_argument("--joint-no-chain", action="store_true",
                     help="config 3, comparison: one MID sweep per (read, k1) (NRA_F_JOINT_NO_CHAIN) instead of a read's MID sweeps chained in one wave")
+    ap.add_argument("--joint-no-keep", action="store_true",
+                    help="config 3, comparison: round 3 sweeps again (NRA_F_JOINT_NO_KEEP) instead of running from the column states round 2 kept")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL)")
     ap.add_argument("--same-device", action="store_true",
                     help="rehearsal only: every rank uses GPU 0 (with --backend gloo on a one-GPU box)")
@@ -529,7 +531,8 @@ def bench_joint(args):
     b = J.Repeat.parse(f"chr4:{len(left) + 57 + len(mid)}:{len(left) + 57 + len(mid) + 21}:{u2}:20")
     a.max_size += 10; b.max_size += 10                               # nanoRepeat_joint.py:202-203
     from nanorepeat_amd import _capi as A
-    session = J.GridSession(J._joint_region(chrom, a, b), fq, device=local_rank, flags=(A.F_JOINT_TAILS if args.joint_tails else 0) | (A.F_JOINT_NO_CHAIN if args.joint_no_chain else 0))
+    session = J.GridSession(J._joint_region(chrom, a, b), fq, device=local_rank, flags=(A.F_JOINT_TAILS if args.joint_tails else 0) | (A.F_JOINT_NO_CHAIN if args.joint_no_chain else 0) |
+                                  (A.F_JOINT_NO_KEEP if args.joint_no_keep else 0))
     last = {}
 
     def step(sess=session):
