@@ -287,3 +287,31 @@ def test_joint_sharded_hip_path_two_ranks_one_gpu(capi, oracle):
     for r in range(world):
         for k in ("read_strand", "best_wscore", "sum_k1", "sum_k2", "n_ties", "status"):
             assert res[r][k] == want[k].tolist(), (r, k)
+
+
+def test_row_block_choice_agrees_with_the_measured_cases():
+    """dist._prefer_row_blocks mirrors nra_batch1d_create's choice between one register block and row blocks for the reads
+    of 1537 - 3072 bases; profiles/r03_row_blocks_or_one_block_54_cases.txt holds what both forms cost on an MI355X for
+    54 (batch size, read length) pairs: where one form is more than 5 % faster, the model takes it."""
+    import os
+    import re
+    from nanorepeat_amd import dist as D
+    path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles", "r03_row_blocks_or_one_block_54_cases.txt")
+    cases = 0
+    for line in open(path):
+        m = re.match(r"n(\d+) k(\d+) q(\d+): one block ([\d.]+) ms .*row blocks ([\d.]+) ms", line)
+        if not m:
+            continue
+        n, k, qmax, one, blocks = int(m.group(1)), int(m.group(2)), int(m.group(3)), float(m.group(4)), float(m.group(5))
+        # the reads of a case: 90 flank bases either side of TATTG x (k .. k + 4), a few HiFi errors (tools/gpu_block_rows.py)
+        q = 180 + 5 * (k + np.arange(n) % 5)
+        assert abs(int(q.max()) - qmax) <= 40, (n, k, qmax)
+        if q.min() <= 1536:
+            continue                     # (a batch that straddles the line is another rule: the small bucket joins the blocks)
+        cases += 1
+        took_blocks = bool(D._prefer_row_blocks(q, np.ones(n, bool)))
+        if blocks < 0.95 * one:
+            assert took_blocks, (n, k, one, blocks)
+        elif one < 0.95 * blocks:
+            assert not took_blocks, (n, k, one, blocks)
+    assert cases >= 40
