@@ -449,6 +449,35 @@ def test_joint_finer_grid_from_kept_column_states(capi, oracle):
                 assert cells["keeps"] >= cells["sweeps"], (what, cells)      # (a coarse grid keeps a little more than it needs)
 
 
+def test_joint_beyond_the_keep_budget_sweeps_again(capi):
+    """30 000 amplicon reads would keep 24 GB of column states, more than NRA_JOINT_KEEP_BUDGET: the batch keeps nothing,
+    round 3 sweeps again -- cell for cell what a NRA_F_JOINT_NO_KEEP batch computes and executes -- while 2000 reads of the
+    same kind do keep (fewer cells in round 3)."""
+    j = synth.make_joint(30000, seed=3)
+    t1, t2 = j["truth"][:, 0].astype(np.float64), j["truth"][:, 1].astype(np.float64)
+    strands = j["strand"].astype(np.int8)
+    coarse = capi.Grid((0, 4, 25), t1 - 20, t1 + 13, (0, 3, 8), np.zeros(len(t2)), t2 + 8)       # 33 + 15..18 counts kept per read: 0.8 MB
+    fine = capi.Grid((0, 1, 90), t1 - 2, t1 + 3, (0, 1, 24), np.maximum(t2 - 2, 0), t2 + 2)
+    for n, keeps in ((30000, False), (2000, True)):
+        sub = lambda g: capi.Grid(g.axes[0], g.bounds[0][:n], g.bounds[1][:n], g.axes[1], g.bounds[2][:n], g.bounds[3][:n])
+        got = {}
+        for name, flags in (("default", 0), ("no keep", capi.F_JOINT_NO_KEEP)):
+            with capi.Batch.create_2d_reads(j["region"], j["reads"][:n], flags=flags) as b:
+                for grid in (sub(coarse), sub(fine)):
+                    assert b.set_grid(grid, strands[:n]) > 0
+                    b.run(); b.sync()
+                    got.setdefault(name, []).append((b.fetch(), b.stats()["executed_cells"]))
+        for (a, cells_a), (c, cells_c) in zip(got["default"], got["no keep"]):
+            for key in a:
+                assert np.array_equal(a[key], c[key]), (n, key)
+        (_, r2_default), (_, r3_default) = got["default"]
+        (_, r2_nokeep), (_, r3_nokeep) = got["no keep"]
+        if keeps:
+            assert r2_default >= r2_nokeep and r3_default < 0.5 * r3_nokeep, (n, got["default"][1][1], r3_nokeep)
+        else:
+            assert (r2_default, r3_default) == (r2_nokeep, r3_nokeep), n
+
+
 def test_joint_packed_flank_sweeps(capi, oracle):
     """The columns of L and rev(R) outside the scoring window are swept in packed int16 cells, two reads per
     wave, and the int32 sweeps resume from the state they leave: flanks just below / at / above the 64-column
