@@ -1032,12 +1032,12 @@ int nra_batch1d_create(int device, const nra_region_t* regions, int32_t n_region
         for (int i = 0; i < kNumR; ++i) { by_bucket[i] = std::move(full[i]); by_bucket[kNumR + 2 + i] = std::move(halfb[i]); }
     }
     if (chain_from < NRA_MAX_QLEN_1BLOCK && !test_chain && !by_bucket[kNumR + 1].empty()) {
-        // ... and what is left of the one-block buckets above one row block (reads of 961 - 3072 bases, fewer than 1024
-        // of a kind) joins the row blocks, where there are any: a length distribution that straddles NRA_RING_MT_FROM
-        // would otherwise leave a handful of reads a launch of their own (1000 reads of 1528 - 1582 bases, 24 of them
-        // below the line: 4.2 ms against 2.7)
+        // ... and a handful of reads left in a one-block bucket above one row block (961 - 3072 bases, fewer than 256 of a
+        // kind: 128 waves) joins the row blocks, where there are any: a length distribution that straddles
+        // NRA_RING_MT_FROM would otherwise leave them a launch of their own (1000 reads of 1528 - 1582 bases, 24 of them
+        // below the line: 4.2 ms against 2.7).  Larger buckets stay: two blocks pad a 1000-base read by half.
         for (int bi = 0; bi < kNumR; ++bi) {
-            if (kRList[bi] <= NRA_RING_MT_R || by_bucket[bi].empty() || by_bucket[bi].size() >= 1024) continue;
+            if (kRList[bi] <= NRA_RING_MT_R || by_bucket[bi].empty() || by_bucket[bi].size() >= 256) continue;
             for (int32_t r : by_bucket[bi]) {
                 const nra_region_t& rg = regions[pr.reads[r].region];
                 chain_cols = std::max(chain_cols, rg.left_len + rg.unit_len * kmax[r] + rg.right_len);

@@ -89,9 +89,9 @@ def padded_rows(qlen, unit_len=None, fold=False):
     if is_full.any():
         lanes = _rows_per_lane((q[is_full] + 63) // 64, 1024 if fold else 0)
         if fold and blocks_chosen and bool((is_chain & (q <= _PACKED_MAX_QLEN)).any()):
-            # what is left of the one-block buckets above one row block joins the row blocks (fewer than 1024 reads of a kind)
+            # a handful of reads left in a one-block bucket above one row block joins the row blocks (fewer than 256 of a kind)
             count = np.bincount(lanes, minlength=int(_R_LIST[-1]) + 1)
-            moved = (lanes > _BLOCK_R[0]) & (count[lanes] < 1024)
+            moved = (lanes > _BLOCK_R[0]) & (count[lanes] < 256)
             idx = np.nonzero(is_full)[0]
             is_chain[idx[moved]] = True
             is_full[idx[moved]] = False
