@@ -379,6 +379,27 @@ static int check_scoring(const nro_scoring_t* sc)
            sc->gap_open1 >= 0 && sc->gap_open2 >= 0 && sc->sc_ambi >= 0;
 }
 
+/* The 1D selector on one read's PAF records (nanoRepeat_bam.py:408-434): record i = (k, AS, tstart, tend, tlen); a
+ * score < 0 is "no record" (below min_dp_score).  Sorted by AS descending, the records tied with the best AS that
+ * reach into both flanks (tstart < |L| and tlen - tend < |R|, :426-428) give sum_k / n_ties (their mean is the
+ * repeat size, :431); a best record that fails the flank test ends the loop: lower scores are never looked at (:425).
+ * Returns the read status: 0 = size from ties, 1 = keep the round-2 size (:433), 2 = no record at all (:418). */
+int nro_select_1d(int32_t n, const int32_t* k, const int32_t* score, const int32_t* tstart, const int32_t* tend,
+                  const int32_t* tlen, int32_t left_len, int32_t right_len,
+                  int32_t* best_score, int64_t* sum_k, int32_t* n_ties)
+{
+    int32_t smax = -1;
+    for (int32_t i = 0; i < n; ++i) if (score[i] > smax) smax = score[i];
+    int64_t sk = 0; int32_t nt = 0;
+    if (smax >= 0)
+        for (int32_t i = 0; i < n; ++i)
+            if (score[i] == smax && tstart[i] < left_len && tlen[i] - tend[i] < right_len) { sk += k[i]; ++nt; }
+    if (best_score) *best_score = smax;
+    if (sum_k) *sum_k = smax < 0 ? 0 : sk;
+    if (n_ties) *n_ties = smax < 0 ? 0 : nt;
+    return smax < 0 ? 2 : (nt > 0 ? 0 : 1);
+}
+
 int nro_round3_1d(const nro_region_t* regions, int32_t n_regions,
                   int32_t n_reads, const char* seqs, const int64_t* seq_off,
                   const int32_t* read_region,
@@ -459,7 +480,9 @@ int nro_round3_1d(const nro_region_t* regions, int32_t n_regions,
         else { S_all[c] = sc1; TS_all[c] = ts; TE_all[c] = te; }
         free(tgt);
     }
-    /* phase 2: the selector, nanoRepeat_bam.py:423-433 */
+    /* phase 2: the selector, nanoRepeat_bam.py:423-433 (nro_select_1d below) */
+    int32_t* krec = (int32_t*)malloc(sizeof(int32_t) * 2 * 8);
+    int32_t krec_cap = 8;
     for (int32_t r = 0; r < n_reads; ++r) {
         if (!Q[r]) continue;
         const int32_t g = read_region ? read_region[r] : 0;
@@ -467,18 +490,13 @@ int nro_round3_1d(const nro_region_t* regions, int32_t n_regions,
         const int32_t k0 = kmin[r], k1 = kmax[r];
         const int32_t K = k1 - k0 + 1;
         const int32_t* S = S_all + coff[r]; const int32_t* TS = TS_all + coff[r]; const int32_t* TE = TE_all + coff[r];
+        /* the PAF records of the read: one per candidate that reached min_dp_score (tname = k, tlen = |L| + m k + |R|) */
+        if (K > krec_cap) { krec_cap = K; krec = (int32_t*)realloc(krec, sizeof(int32_t) * 2 * (size_t)krec_cap); }
+        int32_t* rk = krec; int32_t* rtl = krec + krec_cap;
+        for (int32_t c = 0; c < K; ++c) { rk[c] = k0 + c; rtl[c] = ll + ul * (k0 + c) + rl; }
         int32_t smax = -1;
-        for (int32_t c = 0; c < K; ++c) if (S[c] > smax) smax = S[c];
-        int64_t sk = 0; int32_t nt = 0;
-        for (int32_t k = k0; k <= k1; ++k) {
-            const int32_t c = k - k0;
-            if (smax >= 0 && S[c] == smax) {
-                const int32_t tl = ll + ul * k + rl;
-                if (TS[c] < ll && tl - TE[c] < rl) { sk += k; ++nt; }
-            }
-        }
-        if (smax < 0) status[r] = 2;
-        else { best_score[r] = smax; sum_k[r] = sk; n_ties[r] = nt; status[r] = nt > 0 ? 0 : 1; }
+        status[r] = (uint8_t)nro_select_1d(K, rk, S, TS, TE, rtl, ll, rl, &smax, &sum_k[r], &n_ties[r]);
+        best_score[r] = smax < 0 ? 0 : smax;
         for (int32_t c = 0; c < K; ++c) {
             if (cand_score) cand_score[coff[r] + c] = S[c];
             int keep = all_ext || (smax >= 0 && S[c] == smax);
@@ -487,7 +505,7 @@ int nro_round3_1d(const nro_region_t* regions, int32_t n_regions,
         }
         free(Q[r]);
     }
-    free(Q); free(owner); free(S_all);
+    free(Q); free(owner); free(S_all); free(krec);
     for (int32_t g = 0; g < n_regions; ++g) { free(Lc[g]); free(Uc[g]); free(Rc[g]); }
     free(Lc); free(Uc); free(Rc); free(coff);
     return bad ? -1 : 0;

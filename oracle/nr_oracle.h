@@ -75,6 +75,13 @@ int32_t nro_cigar_region_score(const char* cigar, int32_t tstart, int32_t tend,
                                int32_t* num_match, int32_t* num_mismatch,
                                int32_t* num_ins, int32_t* num_del);
 
+/* The 1D selector on one read's PAF records (nanoRepeat_bam.py:408-434), the function nro_round3_1d applies to every
+ * read: record i = (k, AS, tstart, tend, tlen), AS < 0 = no record.  Returns the status (0 ties, 1 keep the round-2
+ * size, 2 no record); the read's size is sum_k / n_ties. */
+int nro_select_1d(int32_t n, const int32_t* k, const int32_t* score, const int32_t* tstart, const int32_t* tend,
+                  const int32_t* tlen, int32_t left_len, int32_t right_len,
+                  int32_t* best_score, int64_t* sum_k, int32_t* n_ties);
+
 /* Mirrors nra_round3_1d (include/nanorepeat_amd.h).  Always fills every candidate's
  * extents when flags has bit 0 set, else only for top-score ties (others -1). */
 int nro_round3_1d(const nro_region_t* regions, int32_t n_regions,

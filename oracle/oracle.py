@@ -71,6 +71,9 @@ def load():
     lib.nro_cigar_region_score.restype = C.c_int32
     lib.nro_cigar_region_score.argtypes = [C.c_char_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32,
                                            pi32, pi32, pi32, pi32]
+    lib.nro_select_1d.restype = C.c_int
+    lib.nro_select_1d.argtypes = [C.c_int32, pi32, pi32, pi32, pi32, pi32, C.c_int32, C.c_int32,
+                                  pi32, pi64, pi32]
     lib.nro_round3_1d.restype = C.c_int
     lib.nro_round3_1d.argtypes = [C.POINTER(Region), C.c_int32, C.c_int32, C.c_char_p, pi64, pi32,
                                   pi32, pi32, C.POINTER(Scoring), C.c_int32,
@@ -148,6 +151,16 @@ def cigar_region_score(cigar, tstart, tend, a, b):
     v = [C.c_int32(0) for _ in range(4)]
     s = load().nro_cigar_region_score(cigar.encode(), tstart, tend, a, b, *[C.byref(x) for x in v])
     return (s,) + tuple(x.value for x in v)
+
+
+def select_1d(records, left_len, right_len):
+    """The oracle's 1D selector (nro_select_1d, the one nro_round3_1d applies to every read) on PAF records
+    (k, AS, tstart, tend, tlen) -> (status, best_score, sum_k, n_ties).  nanoRepeat_bam.py:408-434."""
+    a = np.ascontiguousarray(np.asarray(records, np.int32).reshape(-1, 5).T)
+    best, sk, nt = C.c_int32(0), C.c_int64(0), C.c_int32(0)
+    st = load().nro_select_1d(a.shape[1], *[_ptr(np.ascontiguousarray(a[i]), C.c_int32) for i in range(5)],
+                              left_len, right_len, C.byref(best), C.byref(sk), C.byref(nt))
+    return st, best.value, sk.value, nt.value
 
 
 def _pack_reads(reads):

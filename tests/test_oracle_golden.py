@@ -24,23 +24,24 @@ def test_window_rule_matches_reference(golden_1d):
         assert c["n_templates"] == c["kmax"] - c["kmin"] + 1
 
 
-def _select_1d(left_len, right_len, r2, records):
-    """Python statement of the selector contract the C ABI implements (sum_k / n_ties / status)."""
-    if not records:
-        return None
-    top = max(r[1] for r in records)
-    ks = [k for (k, AS, ts, te, tl) in records if AS == top and ts < left_len and tl - te < right_len]
-    return float(np.mean(ks)) if ks else r2
-
-
-def test_selector_contract_matches_reference(golden_1d):
+def test_selector_contract_matches_reference(oracle, golden_1d):
+    """The reference's 207 selector vectors (PAF records -> round-3 size, nanoRepeat_bam.py:408-434) through the ORACLE's
+    selector -- nro_select_1d, the very function nro_round3_1d applies to every read -- and the host rule that turns
+    (status, sum_k, n_ties) into the size (round3.py: sum_k / n_ties, the round-2 size on status 1)."""
+    seen = set()
     for c in golden_1d["selector"]:
-        got = _select_1d(c["left_len"], c["right_len"], c["r2"], [tuple(r) for r in c["records"]])
-        if not c["records"]:
+        recs = [tuple(r) for r in c["records"]]
+        if not recs:
             # empty PAF: round3_estimation_from_alignment skips the read, size stays None
             assert c["result"] is None
-        else:
-            assert got == c["result"], c
+            assert oracle.select_1d(recs, c["left_len"], c["right_len"])[0] == 2
+            continue
+        st, best, sk, nt = oracle.select_1d(recs, c["left_len"], c["right_len"])
+        assert best == max(r[1] for r in recs)
+        assert st == (0 if nt > 0 else 1)
+        assert (sk / nt if st == 0 else c["r2"]) == c["result"], c
+        seen.add(st)
+    assert seen == {0, 1}
 
 
 def test_step_size_matches_reference(golden_2d):
