@@ -25,6 +25,11 @@ def golden_2d():
 
 
 @pytest.fixture(scope="session")
+def golden_wide():
+    return json.load(open(os.path.join(GOLDEN, "ref_wide.json")))
+
+
+@pytest.fixture(scope="session")
 def oracle():
     from oracle import oracle as O
     O.build()

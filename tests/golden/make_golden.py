@@ -3,7 +3,7 @@
 
 Run in the build container only (needs /root/reference):
 
-    PYTHONPATH=/root/reference/src python3 -B tests/golden/make_golden.py [1d 2d upstream io phasing joint_round1]
+    PYTHONPATH=/root/reference/src python3 -B tests/golden/make_golden.py [1d 2d wide upstream io phasing joint_round1]
 
 The reference's drivers import pysam / pyminimap2 / Levenshtein, none of which exist
 offline; empty placeholder modules are registered for them so the pure
@@ -467,6 +467,123 @@ def gen_2d(tmp):
     return fx
 
 
+# --------------------------------------------------------------------------- the reference's defaults at full size
+def score_only_aligner(min_score=80, both_strands=False):
+    """Like oracle_aligner but without the traceback (O.align: score and extents only): the 1D selector reads AS, tstart,
+    tend and tlen of a record, never its CIGAR (nanoRepeat_bam.py:423-428), so long templates stay cheap."""
+
+    def answer(cmd, toks, rec):
+        tfile, qfile = rec["files"][-2], rec["files"][-1]
+        out = []
+        for qname, qseq in read_fastx_names_seqs(qfile):
+            for tname, tseq in read_fasta(tfile):
+                s, ts, te = O.align(qseq, tseq)
+                if s >= min_score:
+                    out.append("\t".join(map(str, [qname, len(qseq), 0, len(qseq), "+", tname, len(tseq), ts, te,
+                                                    te - ts, te - ts, 60, "tp:A:P", f"AS:i:{s}", "cg:Z:1="])))
+        return "\n".join(out) + ("\n" if out else ""), ""
+
+    return answer
+
+
+def gen_wide(tmp):
+    """What the small e2e fixtures leave out: the reference's DEFAULT 1000-bp anchors (nanoRepeat.py:122), a read whose
+    round-2 size of >= 3000 gives the full K = 301 window (buffer capped at 150, nanoRepeat_bam.py:463-472), and joint
+    runs that record whether round 3 ran at all (final_step is [1, 1] either way, nanoRepeat_joint.py:268,345-346)."""
+    fx = {}
+    rng = random.Random(20261005)
+    e2e = []
+    for case_id, (unit, ks, errs, flank) in enumerate([
+        ("TATTG", (8, 21, 8, 21, 35, 21), (0.02, 0.01, 0.02), 100),        # K = 31 windows, cores of 240 - 380 bases
+        ("AC", (3000,), (0.004, 0.003, 0.004), 100),                       # r2 = 3001.3: window [2851, 3151], K = 301
+    ]):
+        left, right = rand_seq(1000, rng), rand_seq(1000, rng)
+        d = os.path.join(tmp, f"w{case_id}"); shutil.rmtree(d, ignore_errors=True); os.makedirs(d)
+        rr = make_region(left, unit, right, d)
+        reads = []
+        for i, kt in enumerate(ks):
+            core = mutate(left[-flank:] + unit * kt + right[:flank], *errs, rng)
+            r2 = kt + rng.choice([-1.2, -0.4, 0.0, 0.3, 1.3])
+            if kt >= 3000:
+                r2 = kt + 1.3
+            add_read(rr, f"read{i}", core, r2)
+            reads.append({"name": f"read{i}", "core": core, "r2": r2})
+        rec = Recorder(score_only_aligner(80))
+        ref_bam.pymm2.main = rec
+        ref_bam.round3_estimation("ont", False, rr, 4)
+        banks = [len(read_fasta(c["files"][0])) for c in rec.calls] if False else None
+        res = {n: fnum(rd.round3_repeat_size) for n, rd in rr.read_dict.items()}
+        windows = {r["name"]: [max(0, int(r["r2"] - min(150, max(15, int(0.05 * r["r2"]))))),
+                               int(r["r2"] + min(150, max(15, int(0.05 * r["r2"]))))] for r in reads}
+        rr.out_prefix = os.path.join(d, "out"); rr.no_details = False
+        ref_split.output_repeat_size_1d(rr)
+        e2e.append({"left": left, "unit": unit, "right": right, "fast_mode": False, "reads": reads, "round3": res,
+                    "n_records": {r["name"]: len([l for l in rr.read_dict[r["name"]].round3_paf_text.split("\n") if l]) for r in reads},
+                    "windows": windows,
+                    "repeat_size_txt": open(rr.out_prefix + ".repeat_size.txt").read(), "unique_id": rr.to_unique_id()})
+    fx["e2e_1d"] = e2e
+
+    # -- joint: both steps > 1 (round 3 runs), and an axis whose round-1 ranges are so narrow that its step is 1 (round 3 skipped)
+    e2e2 = []
+    for cid, (u1, u2, mid_s, alleles, errs, nreads, flank, w1, w2) in enumerate([
+        ("CAG", "CCG", "CAACAGCCGCCAC", ((17, 10), (30, 7)), (0.02, 0.01, 0.02), 6, 70, (9, 4), (6, 3)),
+        ("CAG", "CCG", "CAACAGCCGCCAC", ((17, 10), (30, 7)), (0.02, 0.01, 0.02), 6, 70, (9, 4), (1, 1)),
+        ("TATTG", "AC", "GGT", ((6, 12), (11, 3)), (0.01, 0.01, 0.01), 4, 70, (1, 2), (6, 3)),
+    ]):
+        d = os.path.join(tmp, f"wj{cid}"); shutil.rmtree(d, ignore_errors=True); os.makedirs(d)
+        Lx, Rx = rand_seq(160, rng), rand_seq(160, rng)
+        kref1, kref2 = 5, 4
+        chrom2 = Lx + u1 * kref1 + mid_s + u2 * kref2 + Rx
+        s1 = len(Lx); e1 = s1 + len(u1) * kref1; s2 = e1 + len(mid_s); e2_ = s2 + len(u2) * kref2
+        a = make_repeat("chrJ", s1, e1, u1, 40); b = make_repeat("chrJ", s2, e2_, u2, 20)
+        a.max_size += 10; b.max_size += 10
+        init = ref_joint.Round1Estimation()
+        reads = []
+        for i in range(nreads):
+            k1t, k2t = alleles[i % 2]
+            sq = mutate(Lx[-flank:] + u1 * k1t + mid_s + u2 * k2t + Rx[:flank], *errs, rng)
+            strand = 1
+            if i % 3 == 2:
+                sq = revcomp(sq); strand = -1
+            name = f"jr{i}"
+            init.repeat1_count_range_dict[name] = (max(0, k1t - w1[0]), k1t + w1[1])
+            init.repeat2_count_range_dict[name] = (max(0, k2t - w2[0]), k2t + w2[1])
+            reads.append({"name": name, "seq": sq, "strand": strand,
+                          "range1": list(init.repeat1_count_range_dict[name]),
+                          "range2": list(init.repeat2_count_range_dict[name])})
+        fqp = os.path.join(d, "in.fastq")
+        with open(fqp, "w") as f:
+            for r in reads:
+                f.write(f"@{r['name']}\n{r['seq']}\n+\n{'!' * len(r['seq'])}\n")
+        ref_joint.pymm2.main = Recorder(oracle_aligner(80, both_strands=True))
+        seen = {"round2": None, "round3_ran": False}
+        r2_fn, r3_fn = ref_joint.round2_estimation_of_repeat_size, ref_joint.round3_estimation_of_repeat_size
+
+        def spy2(*args, **kw):
+            est = r2_fn(*args, **kw)
+            seen["round2"] = {"step": [int(est.step_size1), int(est.step_size2)],
+                              "k1": {k: fnum(v) for k, v in est.repeat1_count_dict.items()},
+                              "k2": {k: fnum(v) for k, v in est.repeat2_count_dict.items()}}
+            return est
+
+        def spy3(*args, **kw):
+            seen["round3_ran"] = True
+            return r3_fn(*args, **kw)
+
+        ref_joint.round2_estimation_of_repeat_size, ref_joint.round3_estimation_of_repeat_size = spy2, spy3
+        try:
+            final = ref_joint.fine_tune_read_count(init, fqp, chrom2, a, b, "ont", 4, d)
+        finally:
+            ref_joint.round2_estimation_of_repeat_size, ref_joint.round3_estimation_of_repeat_size = r2_fn, r3_fn
+        e2e2.append({"chrom": chrom2, "repeat1": f"chrJ:{s1}:{e1}:{u1}:40", "repeat2": f"chrJ:{s2}:{e2_}:{u2}:20",
+                     "reads": reads, "round2": seen["round2"], "round3_ran": seen["round3_ran"],
+                     "final_step": [int(final.step_size1), int(final.step_size2)],
+                     "k1": {k: fnum(v) for k, v in final.repeat1_count_dict.items()},
+                     "k2": {k: fnum(v) for k, v in final.repeat2_count_dict.items()}})
+    fx["e2e_2d"] = e2e2
+    return fx
+
+
 # --------------------------------------------------------------------------- upstream rows (8f-1)
 def anchor_aligner(min_score=80):
     """Stand-in for the anchors-vs-reads call (nanoRepeat_bam.py:281): reads are the PAF queries,
@@ -781,8 +898,9 @@ def gen_joint_round1(tmp):
 
 
 def main():
-    which = set(sys.argv[1:]) or {"1d", "2d", "upstream", "io", "phasing", "joint_round1"}
-    gens = (("1d", "ref_1d.json", gen_1d), ("2d", "ref_2d.json", gen_2d), ("upstream", "ref_upstream.json", gen_upstream),
+    which = set(sys.argv[1:]) or {"1d", "2d", "wide", "upstream", "io", "phasing", "joint_round1"}
+    gens = (("1d", "ref_1d.json", gen_1d), ("2d", "ref_2d.json", gen_2d), ("wide", "ref_wide.json", gen_wide),
+            ("upstream", "ref_upstream.json", gen_upstream),
             ("io", "ref_io.json", gen_io), ("phasing", "ref_phasing.json", gen_phasing),
             ("joint_round1", "ref_joint_round1.json", gen_joint_round1))
     tmp = tempfile.mkdtemp(prefix="nr_golden_")

@@ -245,6 +245,16 @@ def test_joint_golden_end_to_end(capi, golden_2d):
         assert {k: float(v) for k, v in final.repeat2_count_dict.items()} == c["k2"]
 
 
+def test_reference_defaults_at_full_size_golden_end_to_end(capi, golden_wide, monkeypatch):
+    """ref_wide.json through the product host path + HIP: 1000-bp anchors, the K = 301 window of a 6.2 kb core, joint runs
+    with and without round 3 (a unit-step axis), the round-2 sizes on the way."""
+    from test_oracle_golden import run_wide_1d, run_wide_2d
+    for c in golden_wide["e2e_1d"]:
+        run_wide_1d(c)
+    for c in golden_wide["e2e_2d"]:
+        run_wide_2d(c, monkeypatch)
+
+
 # ------------------------------------------------------------------ full size: properties
 @pytest.fixture(scope="module")
 def config2_run(capi):

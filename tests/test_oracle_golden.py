@@ -190,6 +190,71 @@ def test_joint_end_to_end_matches_reference(oracle, golden_2d):
         assert {k: float(v) for k, v in split.repeat2_count_dict.items()} == c["k2"]
 
 
+def run_wide_1d(c, scorer=None):
+    """One 1D case of ref_wide.json through the host mirror (scorer: the oracle; None: the HIP library)."""
+    rr = R3.RepeatRegion()
+    rr.left_anchor_seq, rr.repeat_unit_seq, rr.right_anchor_seq = c["left"], c["unit"], c["right"]
+    rr.left_anchor_len, rr.right_anchor_len = len(c["left"]), len(c["right"])
+    rr.chrom, rr.start_pos, rr.end_pos = "chrT", 1000, 1100
+    for r in c["reads"]:
+        rr.read_dict[r["name"]] = R3.Read(r["name"], r["r2"])
+        rr.read_core_seq_dict[r["name"]] = r["core"]
+        assert list(R3.round3_window(r["r2"], c["fast_mode"])) == c["windows"][r["name"]]
+    kw = {} if scorer is None else {"scorer": scorer}
+    R3.round3_estimation("ont", c["fast_mode"], rr, 4, **kw)
+    got = {n: (None if rd.round3_repeat_size is None else float(rd.round3_repeat_size)) for n, rd in rr.read_dict.items()}
+    assert got == c["round3"]
+    assert rr.to_unique_id() == c["unique_id"]
+    assert R3.output_repeat_size_1d(rr) == c["repeat_size_txt"]
+
+
+def run_wide_2d(c, monkeypatch, scorer=None):
+    """One joint case of ref_wide.json: the final sizes, the round-2 sizes and steps on the way, and whether round 3 ran."""
+    a = J.Repeat().init_from_string(c["repeat1"]); b = J.Repeat().init_from_string(c["repeat2"])
+    a.max_size += 10; b.max_size += 10                      # nanoRepeat_joint.py:202-203
+    init = J.Round1Estimation()
+    fq = {}
+    for r in c["reads"]:
+        init.repeat1_count_range_dict[r["name"]] = tuple(r["range1"])
+        init.repeat2_count_range_dict[r["name"]] = tuple(r["range2"])
+        fq[r["name"]] = f"@{r['name']}\n{r['seq']}\n+\n{'!' * len(r['seq'])}\n"
+    seen = {"round3_ran": False}
+    r2_fn, r3_fn = J.round2_estimation_of_repeat_size, J.round3_estimation_of_repeat_size
+
+    def spy2(*args, **kw):
+        est = r2_fn(*args, **kw)
+        seen["round2"] = ([est.step_size1, est.step_size2], {k: float(v) for k, v in est.repeat1_count_dict.items()},
+                          {k: float(v) for k, v in est.repeat2_count_dict.items()})
+        return est
+
+    def spy3(*args, **kw):
+        seen["round3_ran"] = True
+        return r3_fn(*args, **kw)
+
+    monkeypatch.setattr(J, "round2_estimation_of_repeat_size", spy2)
+    monkeypatch.setattr(J, "round3_estimation_of_repeat_size", spy3)
+    kw = {} if scorer is None else {"scorer": scorer}
+    final = J.fine_tune_read_count(init, fq, c["chrom"], a, b, **kw)
+    monkeypatch.undo()
+    assert seen["round2"] == (c["round2"]["step"], c["round2"]["k1"], c["round2"]["k2"])
+    assert seen["round3_ran"] == c["round3_ran"]
+    assert [final.step_size1, final.step_size2] == c["final_step"]
+    assert {k: float(v) for k, v in final.repeat1_count_dict.items()} == c["k1"]
+    assert {k: float(v) for k, v in final.repeat2_count_dict.items()} == c["k2"]
+
+
+def test_reference_defaults_at_full_size_match_reference(oracle, golden_wide, monkeypatch):
+    """ref_wide.json: the reference's default 1000-bp anchors (nanoRepeat.py:122), a read with the full K = 301 window
+    (r2 >= 3000, nanoRepeat_bam.py:463-472), joint runs where round 3 ran and where a unit-step axis skipped it
+    (nanoRepeat_joint.py:268) -- with the oracle answering the aligner."""
+    assert [c["round3_ran"] for c in golden_wide["e2e_2d"]] == [True, False, False]
+    assert max(n for c in golden_wide["e2e_1d"] for n in c["n_records"].values()) == 301
+    for c in golden_wide["e2e_1d"]:
+        run_wide_1d(c, oracle.round3_1d)
+    for c in golden_wide["e2e_2d"]:
+        run_wide_2d(c, monkeypatch, oracle.joint_2d)
+
+
 def test_joint_selector_on_canned_paf(oracle, golden_2d):
     """estimate_two_repeats_from_paf on canned records: restated CIGAR rescoring + tie mean."""
     s = golden_2d["selector"]
