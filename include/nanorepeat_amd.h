@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define NRA_ABI_VERSION 3
+#define NRA_ABI_VERSION 4
 
 /* error codes */
 #define NRA_OK            0
@@ -36,6 +36,7 @@ extern "C" {
 #define NRA_E_DEVICE     -2   /* HIP runtime error / no device */
 #define NRA_E_RANGE      -3   /* a sequence exceeds what the entry point holds (limits on each declaration) */
 #define NRA_E_NOMEM      -4
+#define NRA_E_STATE      -5   /* the batch is not in the state the call needs (nra_batch2d_refine: the caller takes the two-call path) */
 
 /* per-read status (1D and 2D) */
 #define NRA_READ_OK        0  /* at least one best-scoring record passed the selector */
@@ -297,6 +298,22 @@ int  nra_batch2d_set_grid(nra_batch_t* b, const int8_t* read_strand,
  * drops all of it: the next list starts like the first (a benchmark repeating the two rounds on one resident batch
  * calls it at the top of every repetition). */
 int  nra_batch2d_invalidate(nra_batch_t* b);
+/* The reference's round 3 (round3_estimation_of_repeat_size, nanoRepeat_joint.py:275-349) as a REFINEMENT of the routed
+ * grid whose run has just been enqueued (set_grid -> nra_batch_run -> this call, before anything waits for the run):
+ * routed on the device from that grid's per-read results, without the host seeing them.  Read r with a result (status
+ * OK, n_ties > 0) has the sizes size_a = sum_ka / n_ties (float64, the mean of its tied cells, :473-474) and takes the
+ * unit-step cells k_a with  max(size_a - buf_a, lo_a[r]) <= k_a < min(size_a + buf_a, hi_a[r])  on both axes (:320-330:
+ * buf_a = the grid's step on axis a, [lo, hi) = the read's round-1 range, the bounds the grid was routed with; lo >= 0);
+ * a read without a result takes none.  The cells are scored from the column states the grid's sweeps kept (no sweep
+ * runs), and the per-read outputs of nra_batch2d_fetch are then the refinement's (status NO_RECORD for a read without
+ * cells); its per-cell arrays hold (2 buf1)(2 buf2) entries a read, the read's n1 x n2 cells first (k1-major),
+ * and nra_stats_t.n_alignments counts the cells of both grids.  What the host saves: a fetch, a second routing and task
+ * list, and the idle device between the two rounds.  NRA_E_STATE when the batch kept no column states for its current
+ * grid (strands not all given, explicit cell list, NRA_F_JOINT_NO_KEEP / _TAILS / _NO_CHAIN, reads beyond 3072 bases,
+ * kept states over budget) or the run was already waited for: the caller then fetches and calls nra_batch2d_set_grid
+ * for the finer grid itself -- same results.  NRA_E_RANGE from the fetch if a row falls outside the kept counts. */
+int  nra_batch2d_refine(nra_batch_t* b, int32_t buf1, int32_t buf2,
+                        const double* lo1, const double* hi1, const double* lo2, const double* hi2);
 int  nra_batch_run(nra_batch_t* b);      /* enqueue every kernel of the path; returns at once */
 int  nra_batch_sync(nra_batch_t* b);     /* wait for the batch stream */
 int  nra_batch_stats(nra_batch_t* b, nra_stats_t* st);   /* after sync */

@@ -517,6 +517,17 @@ struct nra_batch {
     std::vector<uint64_t> keep_state_off, keep_rs_off;
     std::vector<int32_t> keep_ra_off;
     int joint_keep = 0;                         // this cell list: 0 = nothing kept, 1 = sweeps that keep, 2 = no sweeps, kept states
+    // 2D: a refinement enqueued behind the run of a routed grid (nra_batch2d_refine): its routing happens on the device
+    DevBuf<double> rf_bounds;                   // lo1 | hi1 | lo2 | hi2, n_reads each
+    DevBuf<NraGridRow> rf_rows, rf_keep;        // the refinement's rows (device-written); the kept ranges
+    DevBuf<uint32_t> rf_first, rf_cnt;          // cells of a read: at read * cap; how many (device-written)
+    DevBuf<int64_t> rf_words;                   // [0] cells, [1] rows outside the kept ranges, [2] executed, [3] algorithmic cells
+    DevBuf<int32_t> rf_rowspad;                 // 64 * rows per lane of a read's bucket (0: not swept)
+    DevBuf<NraJointTask> rf_mid_tasks;
+    DevBuf<NraJointCombineTask> rf_comb_tasks;
+    DevBuf<int32_t> rf_fs, rf_fb;
+    bool refined = false, refine_read = false;  // this run carries a refinement; its counters have been read back
+    int64_t refine_bad_rows = 0;
     bool cells_need_clear = true;               // 2D: some cells are written by no kernel unless found
 
     std::vector<hipStream_t> bstreams;   // one per bucket: the sweep chains of different buckets overlap
@@ -2595,7 +2606,7 @@ int run_2d(nra_batch* b)
                 if (b->joint_chain)
                     LAUNCH_TRY(nra_launch_joint_midscan(g.R, b->has_n, qb, g.n_tail, b->jtail_tasks.p + g.tail_off,
                                                          b->reads.p, b->regions.p, b->pool.p, b->q2bit.p, b->qnmask.p,
-                                                         b->sp, b->jk1list.p, b->jstate.p, b->jfs.p, b->jfb.p));
+                                                         b->sp, b->jk1list.p, b->jstate.p, b->jfs.p, b->jfb.p, nullptr));
                 else if (b->joint_v2)
                     LAUNCH_TRY(nra_launch_joint_mid(g.R, b->has_n, qb, g.n_tail, b->jtail_tasks.p + g.tail_off,
                                                     b->reads.p, b->regions.p, b->pool.p, b->q2bit.p, b->qnmask.p,
@@ -2613,7 +2624,7 @@ int run_2d(nra_batch* b)
                 HIP_TRY(hipStreamWaitEvent(qb, b->bdone[3 * i], 0));                // ... the extended reverse sweeps'
                 HIP_TRY(hipEventRecord(b->ev[ev++], qb));
                 LAUNCH_TRY(nra_launch_joint_combine(qb, bk.n_comb, b->jcomb_tasks.p + bk.comb_off, b->reads.p, b->sp,
-                                                    b->jfs.p, b->jrs.p, b->jfb.p, b->jra.p, b->cand_score.p, b->cand_tstart.p));
+                                                    b->jfs.p, b->jrs.p, b->jfb.p, b->jra.p, b->cand_score.p, b->cand_tstart.p, nullptr));
                 HIP_TRY(hipEventRecord(b->ev[ev++], qb));
                 b->n_score_ev++;
             }
@@ -2634,6 +2645,22 @@ int run_2d(nra_batch* b)
                                     b->cand_score.p, b->cand_tstart.p, b->best_score.p, b->sum_k.p,
                                     b->sum_k2.p, b->n_ties.p, b->status.p));
     HIP_TRY(hipEventRecord(b->ev[1], st));
+    b->ev_next = ev;
+    b->refined = false; b->refine_read = false; b->refine_bad_rows = 0;
+    return NRA_OK;
+}
+
+// the counters a refinement left on the device (after its stream is idle): cells scored, rows that were not routable
+int finish_refine(nra_batch* b)
+{
+    if (!b->refined || b->refine_read) return NRA_OK;
+    int64_t w[4] = {0, 0, 0, 0};
+    HIP_TRY(hipMemcpy(w, b->rf_words.p, sizeof(w), hipMemcpyDeviceToHost));
+    b->stats.n_alignments += w[0];
+    b->stats.executed_cells += w[2];
+    b->stats.algorithmic_cells += w[3];
+    b->refine_bad_rows = w[1];
+    b->refine_read = true;
     return NRA_OK;
 }
 
@@ -2641,12 +2668,147 @@ int run_2d(nra_batch* b)
 
 extern "C" {
 
+// The reference's round 3 (nanoRepeat_joint.py:275-349) as a refinement of the routed grid whose run has just been
+// enqueued: routed on the device from that grid's per-read results, scored from the column states its sweeps kept.
+int nra_batch2d_refine(nra_batch_t* b, int32_t buf1, int32_t buf2, const double* lo1, const double* hi1,
+                       const double* lo2, const double* hi2)
+{
+    if (!b || b->kind != 2) return fail(NRA_E_ARG, "not a 2D batch");
+    if (buf1 <= 0 || buf2 <= 0 || buf1 > 4096 || buf2 > 4096) return fail(NRA_E_ARG, "bad refinement buffers");
+    const int32_t n_reads = b->n_reads;
+    if (n_reads > 0 && (!lo1 || !hi1 || !lo2 || !hi2)) return fail(NRA_E_ARG, "NULL bound array");
+    if (!b->ran || b->accounted || b->refined || !b->joint_v2 || !b->joint_chain || b->joint_keep == 0 || !b->keep_valid ||
+        b->brute || !b->all_strands_given || b->keep_rows.size() != (size_t)n_reads)
+        return fail(NRA_E_STATE, "no refinement: it follows nra_batch_run of a routed grid (nra_batch2d_set_grid, every strand "
+                                 "given) whose column states are kept, before anything waits for that run");
+    for (const Bucket& bk : b->buckets)
+        if (bk.chain) return fail(NRA_E_STATE, "no refinement: reads beyond one register block are scored cell by cell");
+    HIP_TRY(hipSetDevice(b->device));
+    ArenaScope arena_scope(&b->cell_arena);
+    const int cap1 = 2 * buf1, cap2 = 2 * buf2;
+    const int64_t cap = (int64_t)cap1 * cap2;
+    if (cap * n_reads > 0x7ff00000ll) return fail(NRA_E_RANGE, "too many cells");
+    const size_t nb = b->buckets.size();
+    const int kChunk = 3;                       // k1 values per MID-scan task (push_midscan)
+
+    // static tasks: what a read's refinement needs whatever its round-2 size turns out to be
+    std::vector<std::vector<NraJointTask>> mid(nb);
+    std::vector<std::vector<NraJointCombineTask>> comb(nb);
+    std::vector<int> bucket_of_R((size_t)NRA_MAX_R + 1, -1);
+    for (size_t i = 0; i < nb; ++i) bucket_of_R[(size_t)b->buckets[i].R] = (int)i;
+    std::vector<uint32_t> first((size_t)n_reads);
+    std::vector<int32_t> rowspad((size_t)n_reads, 0);
+    uint64_t fs_total = 0; int64_t fb_total = 0;
+    for (int32_t r = 0; r < n_reads; ++r) {
+        first[(size_t)r] = (uint32_t)((int64_t)r * cap);
+        const NraGridRow& k = b->keep_rows[(size_t)r];
+        if (k.n1 <= 0 || k.n2 <= 0 || b->host_reads[(size_t)r].qlen <= 0 || b->chained_reads[(size_t)r]) continue;
+        const int R = kRList[b->jbucket[(size_t)r]];
+        const int bi = bucket_of_R[(size_t)R];
+        if (bi < 0) return fail(NRA_E_STATE, "no refinement: a read's bucket did not run");
+        rowspad[(size_t)r] = 64 * R;
+        const uint64_t q3 = (uint64_t)3 * (uint64_t)b->host_reads[(size_t)r].qlen;
+        for (int c = 0; c < cap1; c += kChunk) {
+            NraJointTask t{}; t.read = r; t.k1_off = c; t.nk1 = std::min(kChunk, cap1 - c);
+            t.k1 = k.k1lo; t.k2step = 1; t.state = b->keep_state_off[(size_t)r];
+            t.pstate = fs_total + (uint64_t)c * q3; t.out = (int32_t)(fb_total + c);
+            mid[(size_t)bi].push_back(t);
+        }
+        NraJointCombineTask ct{};
+        ct.read = r; ct.out = (int32_t)first[(size_t)r]; ct.fb = (int32_t)fb_total; ct.ra = b->keep_ra_off[(size_t)r];
+        ct.fs = fs_total; ct.rs = b->keep_rs_off[(size_t)r]; ct.rs_first = k.k2lo; ct.rs_stride = 1; ct.rs_plane = 64 * R;
+        comb[(size_t)bi].push_back(ct);
+        fs_total += (uint64_t)cap1 * q3; fb_total += cap1;
+    }
+    std::vector<NraJointTask> mid_all; std::vector<NraJointCombineTask> comb_all;
+    std::vector<size_t> mid_off(nb), comb_off(nb);
+    for (size_t i = 0; i < nb; ++i) {
+        mid_off[i] = mid_all.size(); comb_off[i] = comb_all.size();
+        mid_all.insert(mid_all.end(), mid[i].begin(), mid[i].end());
+        comb_all.insert(comb_all.end(), comb[i].begin(), comb[i].end());
+    }
+    std::vector<double> bounds((size_t)4 * (size_t)std::max(n_reads, 1), 0.0);
+    for (int32_t r = 0; r < n_reads; ++r) {
+        bounds[(size_t)r] = lo1[r]; bounds[(size_t)n_reads + r] = hi1[r];
+        bounds[(size_t)2 * n_reads + r] = lo2[r]; bounds[(size_t)3 * n_reads + r] = hi2[r];
+    }
+    b->cell_arena.expect((size_t)fs_total * 4 + (size_t)cap * n_reads * 8 + (size_t)n_reads * 128 + (4u << 20));
+    HIP_TRY(b->rf_bounds.upload(bounds));
+    HIP_TRY(b->rf_keep.upload(b->keep_rows));
+    HIP_TRY(b->rf_first.upload(first));
+    HIP_TRY(b->rf_rowspad.upload(rowspad));
+    HIP_TRY(b->rf_mid_tasks.upload(mid_all));
+    HIP_TRY(b->rf_comb_tasks.upload(comb_all));
+    HIP_TRY(b->rf_rows.alloc((size_t)std::max(n_reads, 1)));
+    HIP_TRY(b->rf_cnt.alloc((size_t)std::max(n_reads, 1)));
+    HIP_TRY(b->rf_words.alloc(4));
+    HIP_TRY(b->rf_fs.alloc((size_t)fs_total));
+    HIP_TRY(b->rf_fb.alloc((size_t)fb_total));
+    // the refinement's cells: read-major, `cap` entries a read (its n1 x n2 cells first, k1-major)
+    HIP_TRY(b->cand_score.alloc((size_t)(cap * n_reads)));
+    HIP_TRY(b->cand_tstart.alloc((size_t)(cap * n_reads)));
+    b->n_cands = cap * n_reads;
+    {
+        const size_t need = (size_t)b->ev_next + 4 * nb + 4;
+        while (b->ev.size() < need) { hipEvent_t e; HIP_TRY(g_handles.event(b->device, true, &e)); b->ev.push_back(e); }
+    }
+
+    hipStream_t st = b->stream;
+    int ev = b->ev_next;
+    const size_t nc = (size_t)std::max<int64_t>(cap * n_reads, 1);
+    HIP_TRY(hipMemsetAsync(b->rf_words.p, 0, 4 * sizeof(int64_t), st));
+    HIP_TRY(hipMemsetAsync(b->cand_score.p, 0xff, nc * 4, st));
+    HIP_TRY(hipMemsetAsync(b->cand_tstart.p, 0, nc * 4, st));
+    const double* bd = b->rf_bounds.p;
+    LAUNCH_TRY(nra_launch_joint_refine_route(st, n_reads, b->status.p, b->n_ties.p, b->sum_k.p, b->sum_k2.p, bd, bd + n_reads,
+                                             bd + 2 * (size_t)n_reads, bd + 3 * (size_t)n_reads, buf1, buf2, b->rf_keep.p,
+                                             b->rf_rows.p, b->rf_cnt.p, b->rf_rowspad.p, b->reads.p, b->regions.p,
+                                             reinterpret_cast<unsigned long long*>(b->rf_words.p)));
+    HIP_TRY(hipEventRecord(b->fork2_ev, st));
+    for (size_t i = 0; i < nb; ++i) {
+        const Bucket& bk = b->buckets[i];
+        const int n_mid = (int)mid[i].size(), n_comb = (int)comb[i].size();
+        if (n_mid == 0) continue;
+        hipStream_t qb = b->bstreams[2 * i + 1];
+        HIP_TRY(hipStreamWaitEvent(qb, b->fork2_ev, 0));
+        HIP_TRY(hipEventRecord(b->ev[ev++], qb));
+        LAUNCH_TRY(nra_launch_joint_midscan(bk.R, b->has_n, qb, n_mid, b->rf_mid_tasks.p + mid_off[i], b->reads.p, b->regions.p,
+                                            b->pool.p, b->q2bit.p, b->qnmask.p, b->sp, nullptr, b->jstate.p, b->rf_fs.p,
+                                            b->rf_fb.p, b->rf_rows.p));
+        HIP_TRY(hipEventRecord(b->ev[ev++], qb));
+        b->n_score_ev++;
+        HIP_TRY(hipEventRecord(b->ev[ev++], qb));
+        LAUNCH_TRY(nra_launch_joint_combine(qb, n_comb, b->rf_comb_tasks.p + comb_off[i], b->reads.p, b->sp, b->rf_fs.p, b->jrs.p,
+                                            b->rf_fb.p, b->jra.p, b->cand_score.p, b->cand_tstart.p, b->rf_rows.p));
+        HIP_TRY(hipEventRecord(b->ev[ev++], qb));
+        b->n_score_ev++;
+        HIP_TRY(hipEventRecord(b->bdone[3 * i + 1], qb));
+        HIP_TRY(hipStreamWaitEvent(st, b->bdone[3 * i + 1], 0));
+    }
+    HIP_TRY(hipEventRecord(b->phase_ev[1], st));
+    LAUNCH_TRY(nra_launch_select_2d(st, n_reads, b->rf_first.p, b->rf_cnt.p, nullptr, nullptr, b->rf_rows.p, 1, 1,
+                                    b->cand_score.p, b->cand_tstart.p, b->best_score.p, b->sum_k.p, b->sum_k2.p, b->n_ties.p,
+                                    b->status.p));
+    HIP_TRY(hipEventRecord(b->ev[1], st));
+    b->ev_next = ev;
+    b->refined = true; b->refine_read = false;
+    b->grid_step1 = b->grid_step2 = 1;
+    return NRA_OK;
+}
+
 int nra_batch2d_fetch(nra_batch_t* b, int8_t* read_strand, int32_t* cell_score, int32_t* cell_wscore,
                       int32_t* best_wscore, int64_t* sum_k1, int64_t* sum_k2, int32_t* n_ties, uint8_t* status)
 {
     if (!b || b->kind != 2) return fail(NRA_E_ARG, "not a 2D batch");
     HIP_TRY(hipSetDevice(b->device));
     HIP_TRY(hipStreamSynchronize(b->stream));
+    {
+        int rc = finish_refine(b);
+        if (rc) return rc;
+        if (b->refine_bad_rows > 0)
+            return fail(NRA_E_RANGE, std::to_string(b->refine_bad_rows) + " reads of the refinement ask for repeat counts outside the "
+                                     "kept column states (bounds other than the grid's?)");
+    }
     const size_t n = (size_t)b->n_reads, nc = (size_t)b->n_cands;
     if (n) {
         int rc = fetch_results(b);
@@ -2946,6 +3108,7 @@ int nra_align_pairs_cigar(int device, int32_t n_seqs, const char* seqs, const in
 
 // ---- common -------------------------------------------------------------------------
 static int account_run(nra_batch* b);
+namespace { int finish_refine(nra_batch* b); }
 
 int nra_batch_run(nra_batch_t* b)
 {
@@ -2990,7 +3153,7 @@ static int account_run(nra_batch* b)
     b->stats.sum_total_ms += b->stats.total_ms;
     b->stats.sum_score_phase_ms += b->stats.score_phase_ms;
     b->accounted = true;
-    return NRA_OK;
+    return b->kind == 2 ? finish_refine(b) : NRA_OK;
 }
 
 int nra_batch_sync(nra_batch_t* b)

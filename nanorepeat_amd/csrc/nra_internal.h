@@ -328,10 +328,17 @@ int nra_launch_joint_prefix_cols(int R, int has_n, hipStream_t st, int n_tasks, 
 int nra_launch_joint_midscan(int R, int has_n, hipStream_t st, int n_tasks, const NraJointTask* tasks,
                              const NraDevRead* reads, const NraDevRegion* regions, const uint8_t* pool,
                              const uint32_t* q2bit, const uint32_t* qnmask, NraScoreParams sp,
-                             const int32_t* k1list, const int32_t* state, int32_t* fsnap, int32_t* fb);
+                             const int32_t* k1list, const int32_t* state, int32_t* fsnap, int32_t* fb,
+                             const NraGridRow* rows);
 int nra_launch_joint_combine(hipStream_t st, int n_tasks, const NraJointCombineTask* tasks, const NraDevRead* reads,
                              NraScoreParams sp, const int32_t* fsnap, const int32_t* rsnap, const int32_t* fb,
-                             const int32_t* ra, int32_t* cell_score, int32_t* cell_wscore);
+                             const int32_t* ra, int32_t* cell_score, int32_t* cell_wscore, const NraGridRow* rows);
+// a refinement routed on the device (nra_batch2d_refine): rows != NULL in the two launchers above
+int nra_launch_joint_refine_route(hipStream_t st, int n_reads, const uint8_t* status, const int32_t* n_ties,
+                                  const int64_t* sum_k1, const int64_t* sum_k2, const double* lo1, const double* hi1,
+                                  const double* lo2, const double* hi2, int buf1, int buf2, const NraGridRow* keep,
+                                  NraGridRow* rows, uint32_t* cell_cnt, const int32_t* rowspad, const NraDevRead* reads,
+                                  const NraDevRegion* regions, unsigned long long* words);
 int nra_launch_joint_tail(int R, int has_n, hipStream_t st, int n_tasks, const NraJointTask* tasks,
                           const NraDevRead* reads, const NraDevRegion* regions, const uint8_t* pool,
                           const uint32_t* q2bit, const uint32_t* qnmask, NraScoreParams sp,

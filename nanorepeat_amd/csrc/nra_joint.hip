@@ -619,12 +619,22 @@ __global__ __launch_bounds__(WAVE) void k_joint_midscan(int n_tasks, const NraJo
                                                         const uint32_t* __restrict__ qnmask, NraScoreParams sp,
                                                         const int32_t* __restrict__ k1list,
                                                         const int32_t* __restrict__ state,
-                                                        int32_t* __restrict__ fsnap, int32_t* __restrict__ fb)
+                                                        int32_t* __restrict__ fsnap, int32_t* __restrict__ fb,
+                                                        const NraGridRow* __restrict__ rows)
 {
     const int task = blockIdx.x;
     if (task >= n_tasks) return;
     const int lane = threadIdx.x;
     const NraJointTask tk = tasks[task];
+    // rows != NULL (a refinement routed on the device, k_joint_refine_route): the task is the read's k1 values number
+    // k1_off ... k1_off + nk1 - 1 of its row (unit step), as many of them as the row has
+    int nk1 = tk.nk1, k1_first = 0;
+    if (rows) {
+        const NraGridRow row = rows[tk.read];
+        nk1 = imin(nk1, row.n1 - tk.k1_off);
+        k1_first = row.k1lo + tk.k1_off;
+        if (nk1 <= 0) return;
+    }
     const NraDevRead rd = reads[tk.read];
     const NraDevRegion rg = regions[rd.region];
     const int Q = rd.qlen;
@@ -650,8 +660,8 @@ __global__ __launch_bounds__(WAVE) void k_joint_midscan(int n_tasks, const NraJo
     const int g0 = lane * R;                                  // the lane's first row
     __shared__ int tr[R * 64];                                // one plane of a column state, to transpose it for the store
 
-    for (int s = 0; s < tk.nk1; ++s) {
-        const int k1 = k1list[tk.k1_off + s];
+    for (int s = 0; s < nk1; ++s) {
+        const int k1 = rows ? k1_first + s : k1list[tk.k1_off + s];
         const int t0 = rg.l1 + rg.m1 * k1 - 1;
         const int slot = (k1 - tk.k1) / tk.k2step;           // (the prefix sweep may have left more column states than this list)
         constexpr int N4 = NRA_JOINT_COLSTATE(R) / 4;
@@ -754,13 +764,14 @@ extern "C" int nra_launch_joint_prefix_cols(int R, int has_n, hipStream_t st, in
 extern "C" int nra_launch_joint_midscan(int R, int has_n, hipStream_t st, int n_tasks, const NraJointTask* tasks,
                                         const NraDevRead* reads, const NraDevRegion* regions, const uint8_t* pool,
                                         const uint32_t* q2bit, const uint32_t* qnmask, NraScoreParams sp,
-                                        const int32_t* k1list, const int32_t* state, int32_t* fsnap, int32_t* fb)
+                                        const int32_t* k1list, const int32_t* state, int32_t* fsnap, int32_t* fb,
+                                        const NraGridRow* rows)
 {
     if (n_tasks <= 0) return 0;
 #define CASE(r)                                                                                     \
     case r:                                                                                         \
-        if (has_n) k_joint_midscan<r, true><<<n_tasks, WAVE, 0, st>>>(n_tasks, tasks, reads, regions, pool, q2bit, qnmask, sp, k1list, state, fsnap, fb); \
-        else k_joint_midscan<r, false><<<n_tasks, WAVE, 0, st>>>(n_tasks, tasks, reads, regions, pool, q2bit, qnmask, sp, k1list, state, fsnap, fb);       \
+        if (has_n) k_joint_midscan<r, true><<<n_tasks, WAVE, 0, st>>>(n_tasks, tasks, reads, regions, pool, q2bit, qnmask, sp, k1list, state, fsnap, fb, rows); \
+        else k_joint_midscan<r, false><<<n_tasks, WAVE, 0, st>>>(n_tasks, tasks, reads, regions, pool, q2bit, qnmask, sp, k1list, state, fsnap, fb, rows);       \
         break;
     switch (R) {
         NRA_R_LIST(CASE)
@@ -874,12 +885,21 @@ __global__ __launch_bounds__(WAVE) void k_joint_combine(int n_tasks, const NraJo
                                                         const int32_t* __restrict__ rsnap,
                                                         const int32_t* __restrict__ fb, const int32_t* __restrict__ ra,
                                                         int32_t* __restrict__ cell_score,
-                                                        int32_t* __restrict__ cell_wscore)
+                                                        int32_t* __restrict__ cell_wscore,
+                                                        const NraGridRow* __restrict__ rows)
 {
     const int task = blockIdx.x;
     if (task >= n_tasks) return;
     const int lane = threadIdx.x;
-    const NraJointCombineTask tk = tasks[task];
+    NraJointCombineTask tk = tasks[task];
+    if (rows) {
+        // a refinement routed on the device: the read's cells are its row's n1 x n2 (unit steps); the task holds the
+        // first repeat count of the R side's kept slots in rs_first
+        const NraGridRow row = rows[tk.read];
+        tk.n1 = row.n1; tk.n2 = row.n2;
+        tk.rs_first = row.k2lo - tk.rs_first; tk.rs_stride = 1;
+        if (row.n1 <= 0 || row.n2 <= 0) return;
+    }
     const int Q = reads[tk.read].qlen;
     // the tile that takes all the read's k1 values in one pass, if there is one: every plane is then read once
     if (tk.n1 <= 8) joint_combine_tiles<8, 6>(tk, Q, lane, sp, fsnap, rsnap, fb, ra, cell_score, cell_wscore);
@@ -889,10 +909,76 @@ __global__ __launch_bounds__(WAVE) void k_joint_combine(int n_tasks, const NraJo
 extern "C" int nra_launch_joint_combine(hipStream_t st, int n_tasks, const NraJointCombineTask* tasks,
                                         const NraDevRead* reads, NraScoreParams sp, const int32_t* fsnap,
                                         const int32_t* rsnap, const int32_t* fb, const int32_t* ra,
-                                        int32_t* cell_score, int32_t* cell_wscore)
+                                        int32_t* cell_score, int32_t* cell_wscore, const NraGridRow* rows)
 {
     if (n_tasks <= 0) return 0;
-    k_joint_combine<<<n_tasks, WAVE, 0, st>>>(n_tasks, tasks, reads, sp, fsnap, rsnap, fb, ra, cell_score, cell_wscore);
+    k_joint_combine<<<n_tasks, WAVE, 0, st>>>(n_tasks, tasks, reads, sp, fsnap, rsnap, fb, ra, cell_score, cell_wscore, rows);
+    return (int)hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------
+// k_joint_refine_route: the routing of the reference's round 3 (nanoRepeat_joint.py:315-330) on the device, from the
+// per-read results the selector of the grid before it (round 2) left there: size_a = sum_ka / n_ties (the mean of the
+// tied cells, :473-474, in float64 like numpy's), and read r takes the unit-step counts k with
+//     max(size_a - buf_a, lo_a[r]) <= k < min(size_a + buf_a, hi_a[r])          (lo, hi: its round-1 range)
+// on both axes -- at most 2 buf_a of them; none for a read without a round-2 size.  (The global grid the reference
+// walks, range(max(0, int(min size - buf)), int(max size + buf + 2)) at :298-303, holds every such k when lo >= 0.)
+// Every k lies among the counts the grid's sweeps kept column states at (route_grid's keep rows); a row that does not
+// is counted in words[1] (the host then fails the fetch) and gets no cells.
+__global__ void k_joint_refine_route(int n_reads, const uint8_t* __restrict__ status, const int32_t* __restrict__ n_ties,
+                                     const int64_t* __restrict__ sum_k1, const int64_t* __restrict__ sum_k2,
+                                     const double* __restrict__ lo1, const double* __restrict__ hi1,
+                                     const double* __restrict__ lo2, const double* __restrict__ hi2,
+                                     int buf1, int buf2, const NraGridRow* __restrict__ keep,
+                                     NraGridRow* __restrict__ rows, uint32_t* __restrict__ cell_cnt,
+                                     const int32_t* __restrict__ rowspad, const NraDevRead* __restrict__ reads,
+                                     const NraDevRegion* __restrict__ regions,
+                                     unsigned long long* __restrict__ words)      // [0] cells, [1] bad rows, [2] executed, [3] algorithmic cells
+{
+    const int r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= n_reads) return;
+    NraGridRow row{0, 0, 0, 0};
+    if (status[r] == 0 && n_ties[r] > 0 && rowspad[r] > 0) {
+        const double nt = (double)n_ties[r];
+        const double s1 = (double)sum_k1[r] / nt, s2 = (double)sum_k2[r] / nt;
+        const double a1 = fmax(s1 - (double)buf1, lo1[r]), b1 = fmin(s1 + (double)buf1, hi1[r]);
+        const double a2 = fmax(s2 - (double)buf2, lo2[r]), b2 = fmin(s2 + (double)buf2, hi2[r]);
+        if (a1 < b1 && a2 < b2) {
+            const int k1lo = imax((int)ceil(a1), 0), k1hi = (int)ceil(b1);      // first count >= a, first count >= b
+            const int k2lo = imax((int)ceil(a2), 0), k2hi = (int)ceil(b2);
+            if (k1hi > k1lo && k2hi > k2lo) {
+                const NraGridRow k = keep[r];
+                const bool inside = k1lo >= k.k1lo && k1hi <= k.k1lo + k.n1 && k2lo >= k.k2lo && k2hi <= k.k2lo + k.n2 &&
+                                    k1hi - k1lo <= 2 * buf1 && k2hi - k2lo <= 2 * buf2;
+                if (inside) row = NraGridRow{k1lo, k1hi - k1lo, k2lo, k2hi - k2lo};
+                else atomicAdd(&words[1], 1ull);
+            }
+        }
+    }
+    rows[r] = row;
+    cell_cnt[r] = (uint32_t)(row.n1 * row.n2);
+    if (row.n1 > 0) {
+        const NraDevRead rd = reads[r];
+        const NraDevRegion rg = regions[rd.region];
+        const long long n1 = row.n1, n2 = row.n2;
+        const long long sk1 = n1 * row.k1lo + n1 * (n1 - 1) / 2, sk2 = n2 * row.k2lo + n2 * (n2 - 1) / 2;
+        atomicAdd(&words[0], (unsigned long long)(n1 * n2));
+        atomicAdd(&words[2], (unsigned long long)((long long)rowspad[r] * n1 * (1 + rg.l2)));          // the MID scans
+        atomicAdd(&words[3], (unsigned long long)((long long)rd.qlen * (n1 * n2 * ((long long)rg.l1 + rg.l2 + rg.l3) +
+                                                                       rg.m1 * sk1 * n2 + rg.m2 * sk2 * n1)));
+    }
+}
+
+extern "C" int nra_launch_joint_refine_route(hipStream_t st, int n_reads, const uint8_t* status, const int32_t* n_ties,
+                                             const int64_t* sum_k1, const int64_t* sum_k2, const double* lo1,
+                                             const double* hi1, const double* lo2, const double* hi2, int buf1, int buf2,
+                                             const NraGridRow* keep, NraGridRow* rows, uint32_t* cell_cnt,
+                                             const int32_t* rowspad, const NraDevRead* reads, const NraDevRegion* regions,
+                                             unsigned long long* words)
+{
+    if (n_reads <= 0) return 0;
+    k_joint_refine_route<<<(n_reads + 255) / 256, 256, 0, st>>>(n_reads, status, n_ties, sum_k1, sum_k2, lo1, hi1, lo2, hi2,
+                                                                 buf1, buf2, keep, rows, cell_cnt, rowspad, reads, regions, words);
     return (int)hipGetLastError();
 }
 #endif

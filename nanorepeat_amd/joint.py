@@ -332,6 +332,7 @@ class GridSession:
         self.names = list(fastq_dict)
         self.device, self.scoring, self.scorer = device, scoring, scorer
         self.batch = None
+        self.refined = False        # the last score_grid carried the refinement it was asked for
         self._rounds = None         # `rounds`: set to a list to collect (n_cells, batch statistics, group) of every round
         self.subs, self.pool, self.host_lock = [], None, None
         self.in_turn = False        # this group's thread holds host_lock (fine_tune_read_count)
@@ -362,8 +363,12 @@ class GridSession:
         for sub in self.subs:
             sub.rounds = value
 
-    def score_grid(self, grid, read_strand):
-        """One grid round for this session's reads -> per-read tie sums (dict of arrays) and the number of cells."""
+    def score_grid(self, grid, read_strand, refine=None):
+        """One grid round for this session's reads -> per-read tie sums (dict of arrays) and the number of cells.
+        refine = (buf1, buf2, lo1, hi1, lo2, hi2): enqueue the reference's round 3 behind the grid's run
+        (nra_batch2d_refine) -- the results are then the refinement's and `self.refined` says so; where the batch cannot
+        (or with an oracle scorer), the grid's own results come back and the caller runs round 3 as a grid of its own."""
+        self.refined = False
         if self.scorer is not None:
             cell_read, k1, k2 = _capi.joint_grid_cells(grid)
             if len(cell_read) == 0:
@@ -374,6 +379,8 @@ class GridSession:
         if n_cells == 0:
             return None, 0
         self.batch.run()
+        if refine is not None:
+            self.refined = self.batch.refine(*refine)
         if self.in_turn:
             self.host_lock.release()               # another group's thread works on the host meanwhile
             try:
@@ -382,8 +389,11 @@ class GridSession:
                 self.host_lock.acquire()
         else:
             self.batch.sync()
-        if self.rounds is not None:
-            self.rounds.append((n_cells, self.batch.stats(), id(self)))
+        if self.rounds is not None or self.refined:
+            st = self.batch.stats()
+            n_cells = int(st["n_alignments"])              # (both grids' cells when a refinement ran)
+            if self.rounds is not None:
+                self.rounds.append((n_cells, st, id(self)))
         return self.batch.fetch(per_candidate=False), n_cells
 
     def new_run(self):
@@ -456,17 +466,22 @@ class _Round1Arrays:
                 self.strand = np.fromiter((strands.get(name, 0) for name in names), np.int8, len(names))
 
 
-def _score_round(session, ctx, rows, axis1, lo1, hi1, axis2, lo2, hi2, strands, steps):
-    """One grid round: `rows` = session read numbers with bounds [lo, hi) on each axis.  Returns a RepeatSize."""
+def _score_round(session, ctx, rows, axis1, lo1, hi1, axis2, lo2, hi2, strands, steps, refine=False):
+    """One grid round: `rows` = session read numbers with bounds [lo, hi) on each axis.  Returns a RepeatSize.
+    refine: also ask for the reference's round 3 behind it, on the device (buffers = this grid's steps, bounds = the same
+    round-1 ranges); `session.refined` tells whether the result is the refinement's (steps 1, 1) or the grid's own."""
     if len(rows) == 0:
         return RepeatSize()
     n = len(session.names)
     full = [np.zeros(n, np.float64) for _ in range(4)]                 # reads without bounds: empty [0, 0)
     for dst, src in zip(full, (lo1, hi1, lo2, hi2)):
         dst[rows] = src
-    out, n_cells = session.score_grid(_capi.Grid(axis1, full[0], full[1], axis2, full[2], full[3]), ctx.strand)
+    out, n_cells = session.score_grid(_capi.Grid(axis1, full[0], full[1], axis2, full[2], full[3]), ctx.strand,
+                                      (steps[0], steps[1], *full) if refine else None)
     if n_cells == 0:
         return RepeatSize()
+    if refine and session.refined:
+        steps = (1, 1)
     # a read with cells has status OK or NO_RECORD; the others are left at OK with no ties (nanoRepeat_joint.py:473-476)
     ok = np.nonzero((np.asarray(out["status"]) == _capi.READ_OK) & (np.asarray(out["n_ties"]) > 0))[0]
     nt = np.asarray(out["n_ties"], np.float64)[ok]
@@ -516,9 +531,13 @@ def _axis(lo, hi, step):
 
 def round2_estimation_of_repeat_size(initial_estimation, fastq_dict, repeat_chrom_seq, repeat1,
                                      repeat2, data_type="ont", num_threads=1, out_dir=None,
-                                     device=0, scoring=None, scorer=None, strands=None, session=None, _ctx=None):
+                                     device=0, scoring=None, scorer=None, strands=None, session=None, _ctx=None,
+                                     _refine=False):
     """Coarse grid (nanoRepeat_joint.py:376-425).  `strands` (dict, optional) carries each read's
-    orientation between rounds so round 3 does not probe it again; `session` the resident reads."""
+    orientation between rounds so round 3 does not probe it again; `session` the resident reads.
+    _refine (fine_tune_read_count): when both steps come out > 1 -- the reference then runs round 3 (:268) -- ask the
+    library to run that round behind this one on the device (nra_batch2d_refine); if it does, the estimate returned is
+    round 3's (steps 1, 1, `refined` set) and the caller skips its own round 3."""
     _check_repeat_order(repeat1, repeat2)
     if session is not None and session.subs:
         return _merge_parts(list(session.pool.map(lambda sub: round2_estimation_of_repeat_size(
@@ -538,11 +557,16 @@ def round2_estimation_of_repeat_size(initial_estimation, fastq_dict, repeat_chro
         est = _score_round(session, ctx, ctx.rows,
                            _axis(repeat1.round1_min_size, repeat1.round1_max_size + 1, step_size1), ctx.range1[:, 0], ctx.range1[:, 1],
                            _axis(repeat2.round1_min_size, repeat2.round1_max_size + 1, step_size2), ctx.range2[:, 0], ctx.range2[:, 1],
-                           strands, (step_size1, step_size2))
+                           strands, (step_size1, step_size2), refine=_refine and step_size1 > 1 and step_size2 > 1)
+        refined = bool(_refine and step_size1 > 1 and step_size2 > 1 and session.refined)
     finally:
         if own:
             session.close()
-    est.step_size1, est.step_size2 = step_size1, step_size2
+    if refined:
+        est.step_size1 = est.step_size2 = 1                       # nanoRepeat_joint.py:345-346
+        object.__setattr__(est, "refined", True)
+    else:
+        est.step_size1, est.step_size2 = step_size1, step_size2
     return est
 
 
@@ -601,10 +625,12 @@ def round3_estimation_of_repeat_size(initial_estimation, round2_estimation, fast
 
 def fine_tune_read_count(initial_estimation, fastq_dict, repeat_chrom_seq, repeat1, repeat2,
                          data_type="ont", num_threads=1, out_dir=None, device=0, scoring=None,
-                         scorer=None, session=None):
+                         scorer=None, session=None, refine=True):
     """nanoRepeat_joint.py:234-273.  Takes the FASTQ as the {readname: 4-line record} dict the
     reference builds at :264 (file ingestion is outside the hot path).  The reads are packed and
-    uploaded once for both grid rounds (`session`: a GridSession to reuse, e.g. a benchmark's)."""
+    uploaded once for both grid rounds (`session`: a GridSession to reuse, e.g. a benchmark's).
+    refine: let the library run round 3 behind round 2 on the device where it can (nra_batch2d_refine: one enqueue, one
+    fetch, no host work between the rounds); False = two grid calls with the host routing round 3 -- same results."""
     _check_repeat_order(repeat1, repeat2)
     all_ranges = (_all_ranges(initial_estimation.repeat1_count_range_dict), _all_ranges(initial_estimation.repeat2_count_range_dict))
     for rep, span in ((repeat1, all_ranges[0]), (repeat2, all_ranges[1])):
@@ -620,7 +646,10 @@ def fine_tune_read_count(initial_estimation, fastq_dict, repeat_chrom_seq, repea
         strands = dict(getattr(initial_estimation, "read_strand_dict", {}))
         ctx = _Round1Arrays(sess, initial_estimation, strands, all_ranges)
         est = round2_estimation_of_repeat_size(initial_estimation, fastq_dict, repeat_chrom_seq, rep1, rep2,
-                                               data_type, num_threads, out_dir, device, scoring, scorer, strands, sess, ctx)
+                                               data_type, num_threads, out_dir, device, scoring, scorer, strands, sess, ctx,
+                                               _refine=refine)
+        if getattr(est, "refined", False):        # round 3 ran behind round 2 on the device: this is its estimate
+            return est
         if est.step_size1 > 1 and est.step_size2 > 1:                                    # :268
             est = round3_estimation_of_repeat_size(initial_estimation, est, fastq_dict, repeat_chrom_seq, rep1,
                                                    rep2, data_type, num_threads, out_dir, device, scoring, scorer,

@@ -24,7 +24,7 @@ def test_header_symbols_are_exported(capi):
 
 def test_abi_version_and_defaults(capi):
     lib = capi.load()
-    assert lib.nra_abi_version() == 3
+    assert lib.nra_abi_version() == 4
     assert b"gfx950" in lib.nra_version()
     sc = capi.default_scoring()
     assert (sc.match, sc.mismatch, sc.gap_open1, sc.gap_ext1, sc.gap_open2, sc.gap_ext2,

@@ -251,8 +251,11 @@ def test_reference_defaults_at_full_size_golden_end_to_end(capi, golden_wide, mo
     from test_oracle_golden import run_wide_1d, run_wide_2d
     for c in golden_wide["e2e_1d"]:
         run_wide_1d(c)
+    refined = 0
     for c in golden_wide["e2e_2d"]:
-        run_wide_2d(c, monkeypatch)
+        run_wide_2d(c, monkeypatch)                       # two grid calls, round 3 routed on the host
+        refined += bool(run_wide_2d(c, monkeypatch, refine=True))      # round 3 behind round 2 on the device
+    assert refined == sum(c["round3_ran"] for c in golden_wide["e2e_2d"])
 
 
 # ------------------------------------------------------------------ full size: properties
@@ -457,6 +460,75 @@ def test_joint_finer_grid_from_kept_column_states(capi, oracle):
                 assert cells["keeps"] < 0.5 * cells["sweeps"], (what, cells)
             else:
                 assert cells["keeps"] >= cells["sweeps"], (what, cells)      # (a coarse grid keeps a little more than it needs)
+
+
+def test_joint_refinement_routed_on_the_device(capi, oracle):
+    """nra_batch2d_refine: the reference's round 3 (nanoRepeat_joint.py:275-349) enqueued behind round 2's run and routed
+    on the device from round 2's per-read results.  Equal, per read, to the two-call path -- fetch round 2, route the
+    finer grid on the host (max(size - s, lo) <= k < min(size + s, hi)), set_grid, run -- and to the oracle on that
+    finer grid; the statistics count both grids' cells; a batch without kept column states says NRA_E_STATE."""
+    j = synth.make_joint(40, alleles=((11, 6), (21, 4)), read_len=640, read_sd=60, anchor=330, seed=91)
+    n = len(j["reads"])
+    t1, t2 = j["truth"][:, 0].astype(np.float64), j["truth"][:, 1].astype(np.float64)
+    strands = j["strand"].astype(np.int8)
+    lo1, hi1, lo2, hi2 = t1 - 9, t1 + 8, np.maximum(t2 - 5, 0), t2 + 5
+    lo1[5], hi1[5] = 3.0, 3.0                                  # a read without cells: no round-2 size, no refinement
+    junk = list(j["reads"]); junk[7] = "ACGT" * 30             # a read no cell of which reaches min_dp_score
+    for s1, s2 in ((4, 3), (2, 2), (5, 2)):
+        coarse = capi.Grid((1, s1, 40 // s1), lo1, hi1, (0, s2, 16 // s2 + 1), lo2, hi2)
+        with capi.Batch.create_2d_reads(j["region"], junk) as two, capi.Batch.create_2d_reads(j["region"], junk) as one:
+            n2 = two.set_grid(coarse, strands)
+            two.run(); two.sync()
+            r2 = two.fetch(per_candidate=False)
+            ok = (r2["status"] == 0) & (r2["n_ties"] > 0)
+            assert ok.sum() >= n - 3 and not ok[5] and not ok[7]
+            nt = np.maximum(r2["n_ties"], 1).astype(np.float64)
+            z1, z2 = r2["sum_k1"] / nt, r2["sum_k2"] / nt
+            f = [np.where(ok, v, 0.0) for v in (np.maximum(z1 - s1, lo1), np.minimum(z1 + s1, hi1), np.maximum(z2 - s2, lo2), np.minimum(z2 + s2, hi2))]
+            fine = capi.Grid((0, 1, 60), f[0], f[1], (0, 1, 30), f[2], f[3])
+            n3 = two.set_grid(fine, strands)
+            two.run(); two.sync()
+            want = two.fetch(per_candidate=False)
+            cr, k1, k2 = capi.joint_grid_cells(fine)
+            o = oracle.joint_2d(j["region"], junk, cr, k1, k2, read_strand=strands)
+            has = np.zeros(n, bool); has[cr] = True
+
+            assert one.set_grid(coarse, strands) == n2
+            one.run()
+            assert one.refine(s1, s2, lo1, hi1, lo2, hi2)
+            one.sync()
+            st = one.stats()
+            got = one.fetch()
+            assert st["n_alignments"] == n2 + n3 == n2 + len(cr), (s1, s2)
+            for key in ("best_wscore", "sum_k1", "sum_k2", "n_ties", "status"):
+                assert np.array_equal(got[key], want[key]), (s1, s2, key)
+                assert np.array_equal(np.asarray(got[key])[has], np.asarray(o[key])[has]), (s1, s2, key)
+            assert (got["status"][~has] == 2).all()
+            # the refinement's cells: (2 s1)(2 s2) entries a read, its n1 x n2 cells first (k1-major, like the finer grid's list)
+            cap = 4 * s1 * s2
+            cs = got["cell_score"].reshape(n, cap); cw = got["cell_wscore"].reshape(n, cap)
+            for r in np.nonzero(has)[0]:
+                mine = np.nonzero(cr == r)[0]
+                assert np.array_equal(cs[r, :len(mine)], o["cell_score"][mine]) and np.array_equal(cw[r, :len(mine)], o["cell_wscore"][mine])
+                assert (cs[r, len(mine):] == -1).all()
+            # a second refinement of the same run, or one after the run was waited for: not in this state
+            assert not one.refine(s1, s2, lo1, hi1, lo2, hi2)
+            # the batch goes on: the next grid sweeps or reuses as before
+            assert one.set_grid(fine, strands) == n3
+            one.run(); one.sync()
+            again = one.fetch(per_candidate=False)
+            for key in again:
+                assert np.array_equal(again[key], want[key]), key
+    with capi.Batch.create_2d_reads(j["region"], junk, flags=capi.F_JOINT_NO_KEEP) as b:
+        assert b.set_grid(coarse, strands) > 0
+        b.run()
+        assert not b.refine(s1, s2, lo1, hi1, lo2, hi2)         # nothing kept: the caller takes the two-call path
+        b.sync()
+    with capi.Batch.create_2d_reads(j["region"], junk) as b:
+        assert b.set_grid(coarse, None) > 0                     # strands probed: nothing kept either
+        b.run()
+        assert not b.refine(s1, s2, lo1, hi1, lo2, hi2)
+        b.sync()
 
 
 def test_joint_beyond_the_keep_budget_sweeps_again(capi):

@@ -208,8 +208,9 @@ def run_wide_1d(c, scorer=None):
     assert R3.output_repeat_size_1d(rr) == c["repeat_size_txt"]
 
 
-def run_wide_2d(c, monkeypatch, scorer=None):
-    """One joint case of ref_wide.json: the final sizes, the round-2 sizes and steps on the way, and whether round 3 ran."""
+def run_wide_2d(c, monkeypatch, scorer=None, refine=False):
+    """One joint case of ref_wide.json: the final sizes, the round-2 sizes and steps on the way, and whether round 3 ran
+    (refine: round 3 behind round 2 on the device, nra_batch2d_refine -- the host then never sees the round-2 sizes)."""
     a = J.Repeat().init_from_string(c["repeat1"]); b = J.Repeat().init_from_string(c["repeat2"])
     a.max_size += 10; b.max_size += 10                      # nanoRepeat_joint.py:202-203
     init = J.Round1Estimation()
@@ -234,13 +235,17 @@ def run_wide_2d(c, monkeypatch, scorer=None):
     monkeypatch.setattr(J, "round2_estimation_of_repeat_size", spy2)
     monkeypatch.setattr(J, "round3_estimation_of_repeat_size", spy3)
     kw = {} if scorer is None else {"scorer": scorer}
-    final = J.fine_tune_read_count(init, fq, c["chrom"], a, b, **kw)
+    final = J.fine_tune_read_count(init, fq, c["chrom"], a, b, refine=refine, **kw)
     monkeypatch.undo()
-    assert seen["round2"] == (c["round2"]["step"], c["round2"]["k1"], c["round2"]["k2"])
-    assert seen["round3_ran"] == c["round3_ran"]
+    if getattr(final, "refined", False):
+        assert refine and c["round3_ran"] and seen["round2"][0] == [1, 1] and not seen["round3_ran"]
+    else:
+        assert seen["round2"] == (c["round2"]["step"], c["round2"]["k1"], c["round2"]["k2"])
+        assert seen["round3_ran"] == c["round3_ran"]
     assert [final.step_size1, final.step_size2] == c["final_step"]
     assert {k: float(v) for k, v in final.repeat1_count_dict.items()} == c["k1"]
     assert {k: float(v) for k, v in final.repeat2_count_dict.items()} == c["k2"]
+    return getattr(final, "refined", False)
 
 
 def test_reference_defaults_at_full_size_match_reference(oracle, golden_wide, monkeypatch):
