@@ -298,6 +298,14 @@ int  nra_batch2d_set_grid(nra_batch_t* b, const int8_t* read_strand,
  * drops all of it: the next list starts like the first (a benchmark repeating the two rounds on one resident batch
  * calls it at the top of every repetition). */
 int  nra_batch2d_invalidate(nra_batch_t* b);
+/* The flank sweeps ahead of the cell list.  What a joint run sweeps first -- L and rev(R) up to the scoring window, a third
+ * of a round's device time -- depends on the reads and their strands only.  A caller that knows every strand (round 1 of
+ * the reference does, nanoRepeat_joint.py:509-649) calls this right after nra_batch2d_create_reads / _invalidate, BEFORE it
+ * derives step sizes, bounds and grids on the host (:239-259, :351-374): the kernels are enqueued and the call returns;
+ * the cell lists that follow find the flank states valid for those strands and sweep no flank (a read with strand 0
+ * here, or another strand later, is swept by its cell list as before).  Results are identical with and without the
+ * call; a batch that sweeps no packed flanks (brute force, short flanks) does nothing. */
+int  nra_batch2d_sweep_flanks(nra_batch_t* b, const int8_t* read_strand);
 /* The reference's round 3 (round3_estimation_of_repeat_size, nanoRepeat_joint.py:275-349) as a REFINEMENT of the routed
  * grid whose run has just been enqueued (set_grid -> nra_batch_run -> this call, before anything waits for the run):
  * routed on the device from that grid's per-read results, without the host seeing them.  Read r with a result (status

@@ -28,7 +28,7 @@ F_SERIAL_CHAIN = 128  # testing / comparison, 1D: a long read's row blocks one a
 # every symbol include/nanorepeat_amd.h declares
 EXPORTS = ("nra_abi_version", "nra_version", "nra_last_error", "nra_device_count",
            "nra_default_scoring", "nra_release_cached_memory", "nra_round3_1d", "nra_joint_2d", "nra_align_pairs", "nra_align_pairs_cigar", "nra_batch1d_create",
-           "nra_batch2d_create", "nra_batch2d_create_reads", "nra_batch2d_set_cells", "nra_joint_grid_cells", "nra_batch2d_set_grid", "nra_batch2d_invalidate", "nra_batch2d_refine", "nra_batch_run", "nra_batch_sync", "nra_batch_stats",
+           "nra_batch2d_create", "nra_batch2d_create_reads", "nra_batch2d_set_cells", "nra_joint_grid_cells", "nra_batch2d_set_grid", "nra_batch2d_invalidate", "nra_batch2d_sweep_flanks", "nra_batch2d_refine", "nra_batch_run", "nra_batch_sync", "nra_batch_stats",
            "nra_batch1d_fetch", "nra_batch2d_fetch", "nra_batch_destroy")
 
 
@@ -130,6 +130,8 @@ def load():
     lib.nra_joint_grid_cells.argtypes = [C.c_int32] + grid_args + [C.c_int64, pi32, pi32, pi32]
     lib.nra_batch2d_set_grid.restype = C.c_int
     lib.nra_batch2d_set_grid.argtypes = [vp, pi8] + grid_args + [pi64]
+    lib.nra_batch2d_sweep_flanks.restype = C.c_int
+    lib.nra_batch2d_sweep_flanks.argtypes = [vp, pi8]
     lib.nra_batch2d_refine.restype = C.c_int
     lib.nra_batch2d_refine.argtypes = [vp, C.c_int32, C.c_int32, pf64, pf64, pf64, pf64]
     for f in (lib.nra_batch_run, lib.nra_batch_sync, lib.nra_batch2d_invalidate):
@@ -465,6 +467,13 @@ class Batch:
         _check(load().nra_batch2d_set_grid(self._h, _ptr(st, C.c_int8), *grid.c_args(), C.byref(n)))
         self.n_cand = int(n.value)
         return self.n_cand
+
+    def sweep_flanks(self, read_strand):
+        """nra_batch2d_sweep_flanks: enqueue the strand-only flank sweeps now, ahead of the cell list."""
+        st = np.ascontiguousarray(read_strand, np.int8)
+        if len(st) != self.n_reads:
+            raise ValueError("one strand per read of the batch")
+        _check(load().nra_batch2d_sweep_flanks(self._h, _ptr(st, C.c_int8)))
 
     def refine(self, buf1, buf2, lo1, hi1, lo2, hi2):
         """nra_batch2d_refine: the reference's round 3 enqueued behind the routed grid whose run() was just called, routed

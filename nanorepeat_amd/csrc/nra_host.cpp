@@ -517,6 +517,20 @@ struct nra_batch {
     std::vector<uint64_t> keep_state_off, keep_rs_off;
     std::vector<int32_t> keep_ra_off;
     int joint_keep = 0;                         // this cell list: 0 = nothing kept, 1 = sweeps that keep, 2 = no sweeps, kept states
+    // 2D: the packed sweep of rev(R) up to the window is valid for this strand of the read (like lst_strand for L)
+    std::vector<int8_t> rpk_strand;
+    std::vector<std::pair<int32_t, int8_t>> rpk_pending;
+    // 2D: flank sweeps enqueued ahead of the cell list (nra_batch2d_sweep_flanks): buffers of their own, alive as long as
+    // the batch (the cell list's pool / reads / task arrays are rebuilt in place while these kernels run)
+    DevBuf<uint8_t> warm_pool;
+    DevBuf<NraDevRegion> warm_region;
+    DevBuf<NraDevRead> warm_reads;
+    DevBuf<NraJointPairTask> warm_ltasks, warm_rtasks;
+    std::vector<hipEvent_t> warm_ev;            // end of the ahead-of-time sweeps: [2 i] rev(R) side, [2 i + 1] L side of part i
+    std::vector<int> warm_R;                    // rows per lane of part i
+    int warm_has_n = 0;
+    int64_t warm_cells = 0;                     // cells those sweeps execute (added to the statistics of the run they belong to)
+    bool warm_built = false, warm_pending = false;   // pending: enqueued, the next run's streams have not waited for them yet
     // 2D: a refinement enqueued behind the run of a routed grid (nra_batch2d_refine): its routing happens on the device
     DevBuf<double> rf_bounds;                   // lo1 | hi1 | lo2 | hi2, n_reads each
     DevBuf<NraGridRow> rf_rows, rf_keep;        // the refinement's rows (device-written); the kept ranges
@@ -551,6 +565,7 @@ struct nra_batch {
         for (hipEvent_t e : ev) if (e) g_handles.put_event(device, true, e);
         for (hipEvent_t e : phase_ev) if (e) g_handles.put_event(device, true, e);
         for (hipEvent_t e : bdone) if (e) g_handles.put_event(device, false, e);
+        for (hipEvent_t e : warm_ev) if (e) g_handles.put_event(device, false, e);
         if (fork_ev) g_handles.put_event(device, false, fork_ev);
         if (fork2_ev) g_handles.put_event(device, false, fork2_ev);
         for (hipStream_t q : bstreams) if (q) g_handles.put_stream(device, q);
@@ -1679,7 +1694,7 @@ int nra_batch2d_create_reads(int device, const nra_joint_region_t* reg, int32_t 
         b->jpack_r = fits && ints > 0 && cols_ok(reg->right_len);
         jpack_ints = ints;
     }
-    b->arena.expect(pr.q2bit.size() * 6 + (size_t)n_reads * 64 + (1u << 20) +
+    b->arena.expect(pr.q2bit.size() * 6 + (size_t)n_reads * 96 + (size_t)reg->left_len + (size_t)reg->right_len + (1u << 20) +
                     ((b->jpack_l ? jpack_ints : 0) + (b->jpack_r ? jpack_ints : 0)) * 4);
     HIP_TRY(b->q2bit.upload(pr.q2bit));
     HIP_TRY(b->qnmask.upload(pr.nmask));
@@ -1687,8 +1702,30 @@ int nra_batch2d_create_reads(int device, const nra_joint_region_t* reg, int32_t 
     b->reads_have_n = pr.has_n;
     b->host_reads = std::move(pr.reads);
     b->rev_strand.assign((size_t)n_reads, 0);
+    b->rpk_strand.assign((size_t)n_reads, 0);
     if (b->jpack_l) HIP_TRY(b->jlstate.alloc((size_t)jpack_ints));
     if (b->jpack_r) HIP_TRY(b->jrstate.alloc((size_t)jpack_ints));
+    if ((b->jpack_l || b->jpack_r) && reg->left_len >= 1 && reg->right_len >= 2 && n_reads > 0) {
+        // what flank sweeps ahead of a cell list read (nra_batch2d_sweep_flanks): L and rev(R) alone, the oriented reads,
+        // the pair tasks -- buffers of the batch, not of a cell list
+        std::vector<uint8_t> pool;
+        bool has_n = b->reads_have_n;
+        NraDevRegion d{};
+        d.p1_off = pool_append(pool, b->jr_left.data(), reg->left_len, nullptr, 0, 0, has_n);
+        std::string rr(b->jr_right);
+        std::reverse(rr.begin(), rr.end());
+        d.pr_off = pool_append(pool, rr.data(), reg->right_len, nullptr, 0, 0, has_n);
+        d.p2_off = d.p3_off = (uint32_t)pool.size();
+        d.l1 = reg->left_len; d.m1 = reg->unit1_len; d.l2 = reg->mid_len; d.m2 = reg->unit2_len; d.l3 = reg->right_len;
+        pool.push_back(0);
+        b->warm_has_n = has_n ? 1 : 0;
+        HIP_TRY(b->warm_pool.upload(pool));
+        HIP_TRY(b->warm_region.upload(std::vector<NraDevRegion>(1, d)));
+        HIP_TRY(b->warm_reads.alloc((size_t)n_reads));
+        HIP_TRY(b->warm_ltasks.alloc(b->jpairs.size()));
+        HIP_TRY(b->warm_rtasks.alloc(b->jpairs.size()));
+        b->warm_built = true;
+    }
     HIP_TRY(b->jsnap.alloc(b->n_q2bit_words * 16 * 3));    // R side of the junction per read base: kept across cell lists
     HIP_TRY(b->jread_a.alloc((size_t)n_reads));
     rc = alloc_results(b, (size_t)n_reads, true);      // best_wscore, n_ties, sum_k, sum_k2, status, strand_out
@@ -1863,8 +1900,10 @@ int set_cells_common(nra_batch* b, const int8_t* read_strand, int64_t n_cells, c
     }
     b->have_cells = false;
     b->ran = false;
+    const bool had_warm = b->warm_pending;                     // flank sweeps enqueued ahead of this list (nra_batch2d_sweep_flanks)
     b->rev_pending.clear();
     b->lst_pending.clear();
+    b->rpk_pending.clear();
     b->cell_arena.reset();
     ArenaScope arena_scope(&b->cell_arena);
     b->buckets.clear();
@@ -2069,6 +2108,20 @@ int set_cells_common(nra_batch* b, const int8_t* read_strand, int64_t n_cells, c
                 const int32_t pi = b->jpair_of[r];
                 const NraJointPairTask& pair = b->jpairs[(size_t)pi];
                 const bool stale = given == 0 || b->rev_strand[r] != given;     // nothing kept for this read and strand
+                // the packed sweep of rev(R) up to the window: once per pair and strand, kept for later cell lists
+                auto packed_r = [&]() {
+                    if (pair_r[pi]) return;
+                    bool need = false;
+                    for (int32_t q : {pair.read_a, pair.read_b})
+                        if (q >= 0 && (read_strand == nullptr || read_strand[q] == 0 || b->rpk_strand[q] != read_strand[q])) need = true;
+                    if (!need) return;
+                    pair_r[pi] = 1; jrpk.push_back(pair); bk.cells_sweep += (int64_t)2 * 64 * bk.R * colsR;
+                    for (int32_t q : {pair.read_a, pair.read_b}) {
+                        if (q < 0) continue;
+                        b->rpk_strand[q] = 0;
+                        b->rpk_pending.push_back({q, read_strand ? read_strand[q] : (int8_t)0});
+                    }
+                };
                 if (keep == 2) {
                     // every column state this list needs was kept: no sweep on either side
                     rs_off[(size_t)r] = b->keep_rs_off[(size_t)r]; ra_off[(size_t)r] = b->keep_ra_off[(size_t)r];
@@ -2085,7 +2138,7 @@ int set_cells_common(nra_batch* b, const int8_t* read_strand, int64_t n_cells, c
                     rs_total += (uint64_t)k2n * 3 * 64 * (uint64_t)bk.R; ra_total += k2n;
                     if (b->jpack_r) {
                         tb.resume = 1; tb.pstate = pair.state; tb.phalf = pair.read_b == r ? 1 : 0;
-                        if (stale && !pair_r[pi]) { pair_r[pi] = 1; jrpk.push_back(pair); bk.cells_sweep += (int64_t)2 * 64 * bk.R * colsR; }
+                        packed_r();
                     }
                     jbwd.push_back(tb);
                     bk.cells_sweep += joint_cells(bk.R, d.l3 - (b->jpack_r ? colsR : 0) + d.m2 * (k2lo + k2step * (k2n - 1)), reads[r].qlen);
@@ -2094,7 +2147,7 @@ int set_cells_common(nra_batch* b, const int8_t* read_strand, int64_t n_cells, c
                     NraJointTask tb{}; tb.read = r; tb.k2step = 1; tb.n2 = 1;
                     if (b->jpack_r) {
                         tb.resume = 1; tb.pstate = pair.state; tb.phalf = pair.read_b == r ? 1 : 0;
-                        if (!pair_r[pi]) { pair_r[pi] = 1; jrpk.push_back(pair); bk.cells_sweep += (int64_t)2 * 64 * bk.R * colsR; }
+                        packed_r();
                     }
                     jbwd.push_back(tb);
                     bk.cells_sweep += joint_cells(bk.R, d.l3 - (b->jpack_r ? colsR : 0), reads[r].qlen);
@@ -2186,7 +2239,7 @@ int set_cells_common(nra_batch* b, const int8_t* read_strand, int64_t n_cells, c
         return NRA_OK;
     };
     {
-        const int rc1 = ensure_handles(2 + 12 * nb + 2);
+        const int rc1 = ensure_handles((b->warm_pending ? (size_t)b->ev_next : 2) + 12 * nb + 2);
         if (rc1) return rc1;
     }
     clk.mark("2D cells: strand-only uploads, handles");
@@ -2405,7 +2458,7 @@ int set_cells_common(nra_batch* b, const int8_t* read_strand, int64_t n_cells, c
     HIP_TRY(b->cand_tstart.alloc((size_t)n_cells));    // cell_wscore
     clk.mark("2D cells: device buffers, H2D");
     {
-        const int rc1 = ensure_handles(2 + 12 * nb + 4 * b->jgroups.size() + 2);
+        const int rc1 = ensure_handles((b->warm_pending || b->flanks_enqueued ? (size_t)b->ev_next : 2) + 12 * nb + 4 * b->jgroups.size() + 2);
         if (rc1) return rc1;
     }
 
@@ -2413,6 +2466,7 @@ int set_cells_common(nra_batch* b, const int8_t* read_strand, int64_t n_cells, c
     b->stats.algorithmic_cells = alg_cells;
     int64_t ex = 0;
     for (const Bucket& bk : b->buckets) ex += bk.cells_pair + bk.cells_queue + bk.cells_sweep;
+    if (had_warm) ex += b->warm_cells;
     b->stats.executed_cells = ex;
     b->stats.algorithmic_bytes = (int64_t)b->n_q2bit_words * 4 + (int64_t)pool.size() + n_cells * 8 + (int64_t)n_reads * 25;
     int64_t packed_ints = 0;
@@ -2433,7 +2487,117 @@ int nra_batch2d_invalidate(nra_batch_t* b)
     if (!b || b->kind != 2) return fail(NRA_E_ARG, "not a 2D batch");
     std::fill(b->rev_strand.begin(), b->rev_strand.end(), (int8_t)0);
     std::fill(b->lst_strand.begin(), b->lst_strand.end(), (int8_t)0);
+    std::fill(b->rpk_strand.begin(), b->rpk_strand.end(), (int8_t)0);
     b->keep_valid = false;
+    return NRA_OK;
+}
+
+// The flank sweeps of a joint run ahead of its cell list.  The packed sweeps of L and rev(R) outside the scoring window
+// (k_joint_pk16) depend on the reads and their strands only -- not on ranges, grids or cells -- and are the first third
+// of a round's device time: a caller that knows the strands (round 1 does) enqueues them HERE, before it derives step
+// sizes, bounds and grids on the host, and the device works through that host time instead of idling.  The cell lists
+// that follow find the flank states valid (like a later list of the same batch) and sweep no flank.
+int nra_batch2d_sweep_flanks(nra_batch_t* b, const int8_t* read_strand)
+{
+    if (!b || b->kind != 2) return fail(NRA_E_ARG, "not a 2D batch");
+    const int32_t n_reads = b->n_reads;
+    if (n_reads > 0 && !read_strand) return fail(NRA_E_ARG, "NULL strand array");
+    const int32_t left_len = (int32_t)b->jr_left.size(), right_len = (int32_t)b->jr_right.size();
+    if ((b->flags & NRA_F_BRUTE_FORCE) != 0 || left_len < 1 || right_len < 2 || (!b->jpack_l && !b->jpack_r) || n_reads == 0)
+        return NRA_OK;                                         // nothing this batch sweeps ahead of time
+    HIP_TRY(hipSetDevice(b->device));
+    if (b->ran) HIP_TRY(hipStreamSynchronize(b->stream));      // an earlier list's kernels read the flank states
+    if (b->flanks_enqueued || b->warm_pending) {
+        for (hipStream_t q : b->bstreams) HIP_TRY(hipStreamSynchronize(q));
+        HIP_TRY(hipStreamSynchronize(b->stream));
+    }
+    {
+        int rc0 = account_run_fwd(b);
+        if (rc0) return rc0;
+    }
+    ArenaScope arena_scope(&b->arena);
+    if (!b->warm_built) return NRA_OK;
+    // the reads as the kernels orient them (what k_pick_strand leaves in the cell list's own copy)
+    std::vector<NraDevRead> reads(b->host_reads.begin(), b->host_reads.begin() + n_reads);
+    for (int32_t r = 0; r < n_reads; ++r) reads[(size_t)r].rc = read_strand[r] < 0 ? 1 : 0;
+    // per rows-per-lane bucket (pairs are listed bucket by bucket): the pairs whose reads all come with a strand and
+    // whose state is not valid for it
+    struct Part { int R; size_t l_off, n_l, r_off, n_r; };
+    std::vector<Part> parts;
+    std::vector<NraJointPairTask> lt, rt;
+    std::vector<std::pair<int32_t, int8_t>> l_done, r_done;
+    for (size_t i = 0; i < b->jpairs.size();) {
+        const int bi = b->jbucket[(size_t)b->jpairs[i].read_a];
+        Part part{kRList[bi], lt.size(), 0, rt.size(), 0};
+        for (; i < b->jpairs.size() && b->jbucket[(size_t)b->jpairs[i].read_a] == bi; ++i) {
+            const NraJointPairTask& pair = b->jpairs[i];
+            bool all = true, stale_l = false, stale_r = false;
+            for (int32_t q : {pair.read_a, pair.read_b}) {
+                if (q < 0) continue;
+                if (read_strand[q] == 0) all = false;
+                if (b->lst_strand[(size_t)q] != read_strand[q]) stale_l = true;
+                if (b->rpk_strand[(size_t)q] != read_strand[q]) stale_r = true;
+            }
+            if (!all) continue;
+            for (int32_t q : {pair.read_a, pair.read_b}) {
+                if (q < 0) continue;
+                if (b->jpack_l && stale_l) l_done.push_back({q, read_strand[q]});
+                if (b->jpack_r && stale_r) r_done.push_back({q, read_strand[q]});
+            }
+            if (b->jpack_l && stale_l) lt.push_back(pair);
+            if (b->jpack_r && stale_r) rt.push_back(pair);
+        }
+        part.n_l = lt.size() - part.l_off; part.n_r = rt.size() - part.r_off;
+        if (part.n_l || part.n_r) parts.push_back(part);
+    }
+    if (parts.empty()) return NRA_OK;
+    std::reverse(parts.begin(), parts.end());                  // the longest reads first, like the cell lists' buckets
+    HIP_TRY(hipMemcpy(b->warm_reads.p, reads.data(), reads.size() * sizeof(NraDevRead), hipMemcpyHostToDevice));
+    if (!lt.empty()) HIP_TRY(hipMemcpy(b->warm_ltasks.p, lt.data(), lt.size() * sizeof(NraJointPairTask), hipMemcpyHostToDevice));
+    if (!rt.empty()) HIP_TRY(hipMemcpy(b->warm_rtasks.p, rt.data(), rt.size() * sizeof(NraJointPairTask), hipMemcpyHostToDevice));
+    const size_t np = parts.size();
+    while (b->bstreams.size() < 2 * np) { hipStream_t q; HIP_TRY(g_handles.stream(b->device, &q)); b->bstreams.push_back(q); }
+    while (b->warm_ev.size() < 2 * np) { hipEvent_t e; HIP_TRY(g_handles.event(b->device, false, &e)); b->warm_ev.push_back(e); }
+    while (b->ev.size() < 2 + 4 * np + 2) { hipEvent_t e; HIP_TRY(g_handles.event(b->device, true, &e)); b->ev.push_back(e); }
+    hipStream_t st = b->stream;
+    HIP_TRY(hipEventRecord(b->ev[0], st));
+    HIP_TRY(hipEventRecord(b->phase_ev[0], st));
+    HIP_TRY(hipEventRecord(b->fork2_ev, st));
+    int ev = 2;
+    b->n_score_ev = 0; b->n_ext_ev = 0;
+    const int colsL = NRA_JOINT_PACKED_COLS(left_len), colsR = NRA_JOINT_PACKED_COLS(right_len);
+    int64_t cells = 0;
+    for (size_t i = 0; i < np; ++i) {
+        const Part& pt = parts[i];
+        hipStream_t qa = b->bstreams[2 * i], qb = b->bstreams[2 * i + 1];
+        HIP_TRY(hipStreamWaitEvent(qa, b->fork2_ev, 0));
+        HIP_TRY(hipStreamWaitEvent(qb, b->fork2_ev, 0));
+        if (pt.n_l > 0) {                                       // the L side first (run_2d_flanks)
+            HIP_TRY(hipEventRecord(b->ev[ev++], qb));
+            LAUNCH_TRY(nra_launch_joint_pk16(pt.R, b->warm_has_n, qb, (int)pt.n_l, b->warm_ltasks.p + pt.l_off, b->warm_reads.p,
+                                             b->warm_region.p, b->warm_pool.p, b->q2bit.p, b->qnmask.p, b->sp, 1, b->jlstate.p));
+            HIP_TRY(hipEventRecord(b->ev[ev++], qb));
+            b->n_score_ev++;
+            cells += (int64_t)pt.n_l * 2 * 64 * pt.R * colsL;
+        }
+        if (pt.n_r > 0) {
+            HIP_TRY(hipEventRecord(b->ev[ev++], qa));
+            LAUNCH_TRY(nra_launch_joint_pk16(pt.R, b->warm_has_n, qa, (int)pt.n_r, b->warm_rtasks.p + pt.r_off, b->warm_reads.p,
+                                             b->warm_region.p, b->warm_pool.p, b->q2bit.p, b->qnmask.p, b->sp, 0, b->jrstate.p));
+            HIP_TRY(hipEventRecord(b->ev[ev++], qa));
+            b->n_score_ev++;
+            cells += (int64_t)pt.n_r * 2 * 64 * pt.R * colsR;
+        }
+        HIP_TRY(hipEventRecord(b->warm_ev[2 * i], qa));
+        HIP_TRY(hipEventRecord(b->warm_ev[2 * i + 1], qb));
+    }
+    b->warm_R.clear();
+    for (const Part& pt : parts) b->warm_R.push_back(pt.R);
+    b->ev_next = ev;
+    b->warm_pending = true;
+    b->warm_cells = cells;
+    for (const auto& pr2 : l_done) b->lst_strand[(size_t)pr2.first] = pr2.second;
+    for (const auto& pr2 : r_done) b->rpk_strand[(size_t)pr2.first] = pr2.second;
     return NRA_OK;
 }
 
@@ -2469,11 +2633,26 @@ int run_2d_flanks(nra_batch* b)
     hipStream_t st = b->stream;
     const size_t nb = b->buckets.size();
     const size_t nr = std::max<size_t>((size_t)b->n_reads, 1);
-    HIP_TRY(hipEventRecord(b->ev[0], st));
+    int ev = 2;
+    const bool warm = b->warm_pending;           // flank sweeps of this run went out ahead of the cell list: the run began there
+    if (warm) {
+        // a bucket's two chains wait for the sweeps of its own rows-per-lane class only (the R side's for the reverse
+        // chain, the L side's for the prefix chain): the classes overlap as they do within one run
+        ev = b->ev_next;
+        for (size_t i = 0; i < nb; ++i)
+            for (size_t w = 0; w < b->warm_R.size(); ++w)
+                if (b->warm_R[w] == b->buckets[i].R && !b->buckets[i].chain) {
+                    HIP_TRY(hipStreamWaitEvent(b->bstreams[2 * i], b->warm_ev[2 * w], 0));
+                    HIP_TRY(hipStreamWaitEvent(b->bstreams[2 * i + 1], b->warm_ev[2 * w + 1], 0));
+                }
+        b->warm_pending = false;
+    } else {
+        HIP_TRY(hipEventRecord(b->ev[0], st));
+        b->n_score_ev = 0;
+    }
+    b->n_ext_ev = 0;
     HIP_TRY(hipMemcpyAsync(b->reads.p, b->reads_init.p, nr * sizeof(NraDevRead), hipMemcpyDeviceToDevice, st));
     HIP_TRY(hipMemsetAsync(b->probe_score.p, 0xff, 2 * nr * 4, st));
-    int ev = 2;
-    b->n_score_ev = 0; b->n_ext_ev = 0;
     if (!b->all_strands_given) {
         HIP_TRY(hipEventRecord(b->fork_ev, st));
         for (size_t i = 0; i < nb; ++i) {
@@ -2501,7 +2680,7 @@ int run_2d_flanks(nra_batch* b)
     }
     LAUNCH_TRY(nra_launch_pick_strand(st, b->n_reads, b->probe_score.p,
                                       b->have_strand_in ? b->strand_in.p : nullptr, b->strand_out.p, b->reads.p));
-    HIP_TRY(hipEventRecord(b->phase_ev[0], st));
+    if (!warm) HIP_TRY(hipEventRecord(b->phase_ev[0], st));
     if (!b->brute) {
         // reverse sweeps over R (one per read) and the packed sweeps of both flanks (one per pair of reads)
         HIP_TRY(hipEventRecord(b->fork2_ev, st));
@@ -2638,6 +2817,8 @@ int run_2d(nra_batch* b)
     b->rev_pending.clear();
     for (const auto& pr2 : b->lst_pending) b->lst_strand[(size_t)pr2.first] = pr2.second;
     b->lst_pending.clear();
+    for (const auto& pr2 : b->rpk_pending) b->rpk_strand[(size_t)pr2.first] = pr2.second;
+    b->rpk_pending.clear();
     if (b->keep_pending) { b->keep_valid = true; b->keep_pending = false; }      // ... and so do the column states
     HIP_TRY(hipEventRecord(b->phase_ev[1], st));
     LAUNCH_TRY(nra_launch_select_2d(st, b->n_reads, b->cell_first.p, b->cell_cnt.p, b->cell_k1.p, b->cell_k2.p,

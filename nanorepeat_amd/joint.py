@@ -396,6 +396,20 @@ class GridSession:
                 self.rounds.append((n_cells, st, id(self)))
         return self.batch.fetch(per_candidate=False), n_cells
 
+    def sweep_flanks(self, read_strand_dict):
+        """The strand-only flank sweeps of the coming grid rounds, enqueued now (nra_batch2d_sweep_flanks): the device works
+        while the host derives ranges, step sizes and grids.  Reads without a known strand are left to their cell list."""
+        for sub in self.subs:
+            sub.sweep_flanks(read_strand_dict)
+        if self.batch is None or not read_strand_dict:
+            return
+        n = len(self.names)
+        if len(read_strand_dict) == n and list(read_strand_dict) == self.names:
+            strand = np.fromiter(read_strand_dict.values(), np.int8, n)
+        else:
+            strand = np.fromiter((read_strand_dict.get(name, 0) for name in self.names), np.int8, n)
+        self.batch.sweep_flanks(strand)
+
     def new_run(self):
         """The grid rounds are about to start over on these reads: nothing of an earlier run is reused."""
         for sub in self.subs:
@@ -632,14 +646,21 @@ def fine_tune_read_count(initial_estimation, fastq_dict, repeat_chrom_seq, repea
     refine: let the library run round 3 behind round 2 on the device where it can (nra_batch2d_refine: one enqueue, one
     fetch, no host work between the rounds); False = two grid calls with the host routing round 3 -- same results."""
     _check_repeat_order(repeat1, repeat2)
-    all_ranges = (_all_ranges(initial_estimation.repeat1_count_range_dict), _all_ranges(initial_estimation.repeat2_count_range_dict))
-    for rep, span in ((repeat1, all_ranges[0]), (repeat2, all_ranges[1])):
-        lo = min(rep.max_size, int(span[:, 0].min())) if len(span) else rep.max_size
-        hi = max(0, int(span[:, 1].max())) if len(span) else 0
-        rep.round1_min_size, rep.round1_max_size = lo, min(hi, rep.max_size)            # :239-259
     own = session is None
     if own:
         session = GridSession(_joint_region(repeat_chrom_seq, repeat1, repeat2), fastq_dict, device, scoring, scorer)
+    try:
+        # what the device sweeps first depends on the reads and their strands only: it goes out before any host work
+        session.sweep_flanks(getattr(initial_estimation, "read_strand_dict", None))
+        all_ranges = (_all_ranges(initial_estimation.repeat1_count_range_dict), _all_ranges(initial_estimation.repeat2_count_range_dict))
+        for rep, span in ((repeat1, all_ranges[0]), (repeat2, all_ranges[1])):
+            lo = min(rep.max_size, int(span[:, 0].min())) if len(span) else rep.max_size
+            hi = max(0, int(span[:, 1].max())) if len(span) else 0
+            rep.round1_min_size, rep.round1_max_size = lo, min(hi, rep.max_size)            # :239-259
+    except BaseException:
+        if own:
+            session.close()
+        raise
 
     def both_rounds(sess, rep1, rep2):
         # a read's strand is known from round 1 when that was run here (the left template is forward)

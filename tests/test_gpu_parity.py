@@ -531,6 +531,45 @@ def test_joint_refinement_routed_on_the_device(capi, oracle):
         b.sync()
 
 
+def test_joint_flank_sweeps_ahead_of_the_cell_list(capi, oracle):
+    """nra_batch2d_sweep_flanks: the strand-only packed sweeps of L and rev(R) enqueued before any cell list exists.  The
+    lists that follow -- routed grids, explicit cells, other strands for some reads, strands left to the probe -- give the
+    oracle's results, and the same executed cells as a batch that was never warmed (the work moved, it did not grow)."""
+    j = synth.make_joint(23, alleles=((11, 6), (21, 4)), read_len=640, read_sd=60, anchor=330, seed=12)
+    n = len(j["reads"])
+    t1, t2 = j["truth"][:, 0].astype(np.float64), j["truth"][:, 1].astype(np.float64)
+    strands = j["strand"].astype(np.int8)
+    partly = strands.copy(); partly[[2, 3, 11]] = 0           # strands round 1 did not find: their pairs are not swept ahead
+    flipped = strands.copy(); flipped[4] = -flipped[4]
+    grid = capi.Grid((1, 4, 9), t1 - 9, t1 + 8, (0, 3, 5), np.maximum(t2 - 5, 0), t2 + 5)
+    cr, k1, k2 = capi.joint_grid_cells(grid)
+    for ahead, given in ((strands, strands), (partly, strands), (strands, flipped), (partly, None), (strands, None)):
+        o = oracle.joint_2d(j["region"], j["reads"], cr, k1, k2, read_strand=given)
+        cells = {}
+        for warmed in (True, False):
+            with capi.Batch.create_2d_reads(j["region"], j["reads"]) as b:
+                if warmed:
+                    b.sweep_flanks(ahead)
+                    b.sweep_flanks(ahead)                         # (a second call finds nothing left to sweep)
+                assert b.set_grid(grid, given) == len(cr)
+                b.run(); b.sync()
+                g = b.fetch()
+                cells[warmed] = b.stats()["executed_cells"]
+                for key in o:
+                    assert np.array_equal(np.asarray(g[key]), np.asarray(o[key])), (warmed, key)
+                # ... and an explicit cell list on the same batch afterwards
+                b.set_cells(cr[::2], k1[::2], k2[::2], given)
+                b.run(); b.sync()
+                g2 = b.fetch()
+                o2 = oracle.joint_2d(j["region"], j["reads"], cr[::2], k1[::2], k2[::2], read_strand=given)
+                for key in o2:
+                    assert np.array_equal(np.asarray(g2[key]), np.asarray(o2[key])), (warmed, "cells", key)
+        if given is not None and (ahead == given).all():
+            assert cells[True] == cells[False], cells
+        else:
+            assert cells[True] >= cells[False], cells             # pairs swept ahead for a strand the list then does not use
+
+
 def test_joint_beyond_the_keep_budget_sweeps_again(capi):
     """30 000 amplicon reads would keep 24 GB of column states, more than NRA_JOINT_KEEP_BUDGET: the batch keeps nothing,
     round 3 sweeps again -- cell for cell what a NRA_F_JOINT_NO_KEEP batch computes and executes -- while 2000 reads of the

@@ -219,6 +219,8 @@ def run_wide_2d(c, monkeypatch, scorer=None, refine=False):
         init.repeat1_count_range_dict[r["name"]] = tuple(r["range1"])
         init.repeat2_count_range_dict[r["name"]] = tuple(r["range2"])
         fq[r["name"]] = f"@{r['name']}\n{r['seq']}\n+\n{'!' * len(r['seq'])}\n"
+        if refine:                  # round 1 knows the strand when it ran here; the library keeps column states only then
+            init.read_strand_dict[r["name"]] = r["strand"]
     seen = {"round3_ran": False}
     r2_fn, r3_fn = J.round2_estimation_of_repeat_size, J.round3_estimation_of_repeat_size
 

@@ -24,11 +24,16 @@ a = J.Repeat.parse(f"chr4:{len(left)}:{len(left) + 57}:{u1}:200")
 b = J.Repeat.parse(f"chr4:{len(left) + 57 + len(mid)}:{len(left) + 57 + len(mid) + 21}:{u2}:20")
 a.max_size += 10; b.max_size += 10
 log = []
-def score_grid(self, grid, read_strand):
+t_refine = []
+def score_grid(self, grid, read_strand, refine=None):
     me = threading.current_thread().name
     t = [time.perf_counter()]
     n_cells = self.batch.set_grid(grid, read_strand); t.append(time.perf_counter())
-    self.batch.run(); t.append(time.perf_counter())
+    self.batch.run()
+    tr = time.perf_counter()
+    self.refined = refine is not None and self.batch.refine(*refine)
+    t.append(time.perf_counter())
+    t_refine.append(1e3 * (t[-1] - tr))
     lk = self.in_turn
     if lk: self.host_lock.release()
     self.batch.sync()
@@ -54,4 +59,5 @@ print(f"parts {parts}: last run {1e3 * (t1 - t0):.2f} ms")
 for me, t in sorted(log, key=lambda x: x[1][0]):
     print(f"{me:12s} set_grid {1e3 * (t[0] - t0):7.2f} -> {1e3 * (t[1] - t0):7.2f}  run -> {1e3 * (t[2] - t0):7.2f}  "
           f"sync -> {1e3 * (t[3] - t0):7.2f}  fetch -> {1e3 * (t[4] - t0):7.2f}")
+print("refine call (ms):", [round(x, 2) for x in t_refine[-4:]])
 session.close()
