@@ -525,7 +525,7 @@ struct nra_batch {
     DevBuf<uint8_t> warm_pool;
     DevBuf<NraDevRegion> warm_region;
     DevBuf<NraDevRead> warm_reads;
-    DevBuf<NraJointPairTask> warm_ltasks, warm_rtasks;
+    DevBuf<NraJointPairTask> warm_tasks;
     std::vector<hipEvent_t> warm_ev;            // end of the ahead-of-time sweeps: [2 i] rev(R) side, [2 i + 1] L side of part i
     std::vector<int> warm_R;                    // rows per lane of part i
     int warm_has_n = 0;
@@ -1722,8 +1722,7 @@ int nra_batch2d_create_reads(int device, const nra_joint_region_t* reg, int32_t 
         HIP_TRY(b->warm_pool.upload(pool));
         HIP_TRY(b->warm_region.upload(std::vector<NraDevRegion>(1, d)));
         HIP_TRY(b->warm_reads.alloc((size_t)n_reads));
-        HIP_TRY(b->warm_ltasks.alloc(b->jpairs.size()));
-        HIP_TRY(b->warm_rtasks.alloc(b->jpairs.size()));
+        HIP_TRY(b->warm_tasks.alloc(2 * b->jpairs.size()));
         b->warm_built = true;
     }
     HIP_TRY(b->jsnap.alloc(b->n_q2bit_words * 16 * 3));    // R side of the junction per read base: kept across cell lists
@@ -2522,13 +2521,13 @@ int nra_batch2d_sweep_flanks(nra_batch_t* b, const int8_t* read_strand)
     for (int32_t r = 0; r < n_reads; ++r) reads[(size_t)r].rc = read_strand[r] < 0 ? 1 : 0;
     // per rows-per-lane bucket (pairs are listed bucket by bucket): the pairs whose reads all come with a strand and
     // whose state is not valid for it
-    struct Part { int R; size_t l_off, n_l, r_off, n_r; };
+    struct Part { int R; size_t off, n_l, n_r; };
     std::vector<Part> parts;
-    std::vector<NraJointPairTask> lt, rt;
+    std::vector<NraJointPairTask> mt;              // L- and R-side tasks of a pair next to each other; L marked in bit 63 of `state`
     std::vector<std::pair<int32_t, int8_t>> l_done, r_done;
     for (size_t i = 0; i < b->jpairs.size();) {
         const int bi = b->jbucket[(size_t)b->jpairs[i].read_a];
-        Part part{kRList[bi], lt.size(), 0, rt.size(), 0};
+        Part part{kRList[bi], mt.size(), 0, 0};
         for (; i < b->jpairs.size() && b->jbucket[(size_t)b->jpairs[i].read_a] == bi; ++i) {
             const NraJointPairTask& pair = b->jpairs[i];
             bool all = true, stale_l = false, stale_r = false;
@@ -2544,17 +2543,15 @@ int nra_batch2d_sweep_flanks(nra_batch_t* b, const int8_t* read_strand)
                 if (b->jpack_l && stale_l) l_done.push_back({q, read_strand[q]});
                 if (b->jpack_r && stale_r) r_done.push_back({q, read_strand[q]});
             }
-            if (b->jpack_l && stale_l) lt.push_back(pair);
-            if (b->jpack_r && stale_r) rt.push_back(pair);
+            if (b->jpack_l && stale_l) { NraJointPairTask t = pair; t.state |= 1ull << 63; mt.push_back(t); part.n_l++; }
+            if (b->jpack_r && stale_r) { mt.push_back(pair); part.n_r++; }
         }
-        part.n_l = lt.size() - part.l_off; part.n_r = rt.size() - part.r_off;
         if (part.n_l || part.n_r) parts.push_back(part);
     }
     if (parts.empty()) return NRA_OK;
     std::reverse(parts.begin(), parts.end());                  // the longest reads first, like the cell lists' buckets
     HIP_TRY(hipMemcpy(b->warm_reads.p, reads.data(), reads.size() * sizeof(NraDevRead), hipMemcpyHostToDevice));
-    if (!lt.empty()) HIP_TRY(hipMemcpy(b->warm_ltasks.p, lt.data(), lt.size() * sizeof(NraJointPairTask), hipMemcpyHostToDevice));
-    if (!rt.empty()) HIP_TRY(hipMemcpy(b->warm_rtasks.p, rt.data(), rt.size() * sizeof(NraJointPairTask), hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(b->warm_tasks.p, mt.data(), mt.size() * sizeof(NraJointPairTask), hipMemcpyHostToDevice));
     const size_t np = parts.size();
     while (b->bstreams.size() < 2 * np) { hipStream_t q; HIP_TRY(g_handles.stream(b->device, &q)); b->bstreams.push_back(q); }
     while (b->warm_ev.size() < 2 * np) { hipEvent_t e; HIP_TRY(g_handles.event(b->device, false, &e)); b->warm_ev.push_back(e); }
@@ -2572,24 +2569,17 @@ int nra_batch2d_sweep_flanks(nra_batch_t* b, const int8_t* read_strand)
         hipStream_t qa = b->bstreams[2 * i], qb = b->bstreams[2 * i + 1];
         HIP_TRY(hipStreamWaitEvent(qa, b->fork2_ev, 0));
         HIP_TRY(hipStreamWaitEvent(qb, b->fork2_ev, 0));
-        if (pt.n_l > 0) {                                       // the L side first (run_2d_flanks)
-            HIP_TRY(hipEventRecord(b->ev[ev++], qb));
-            LAUNCH_TRY(nra_launch_joint_pk16(pt.R, b->warm_has_n, qb, (int)pt.n_l, b->warm_ltasks.p + pt.l_off, b->warm_reads.p,
-                                             b->warm_region.p, b->warm_pool.p, b->q2bit.p, b->qnmask.p, b->sp, 1, b->jlstate.p));
-            HIP_TRY(hipEventRecord(b->ev[ev++], qb));
-            b->n_score_ev++;
-            cells += (int64_t)pt.n_l * 2 * 64 * pt.R * colsL;
-        }
-        if (pt.n_r > 0) {
-            HIP_TRY(hipEventRecord(b->ev[ev++], qa));
-            LAUNCH_TRY(nra_launch_joint_pk16(pt.R, b->warm_has_n, qa, (int)pt.n_r, b->warm_rtasks.p + pt.r_off, b->warm_reads.p,
-                                             b->warm_region.p, b->warm_pool.p, b->q2bit.p, b->qnmask.p, b->sp, 0, b->jrstate.p));
-            HIP_TRY(hipEventRecord(b->ev[ev++], qa));
-            b->n_score_ev++;
-            cells += (int64_t)pt.n_r * 2 * 64 * pt.R * colsR;
-        }
+        // both sides of a rows-per-lane class in ONE launch, L- and R-side tasks alternating: the two chains behind them
+        // (prefix sweeps; extended reverse sweeps) carry about the same work and meet again in the cells, so neither side's
+        // waves should be the older ones (two launches: the first one's waves issue first, its side finishes 1.4 ms ahead)
+        HIP_TRY(hipEventRecord(b->ev[ev++], qa));
+        LAUNCH_TRY(nra_launch_joint_pk16(pt.R, b->warm_has_n, qa, (int)(pt.n_l + pt.n_r), b->warm_tasks.p + pt.off, b->warm_reads.p,
+                                         b->warm_region.p, b->warm_pool.p, b->q2bit.p, b->qnmask.p, b->sp, -1, b->jrstate.p, b->jlstate.p));
+        HIP_TRY(hipEventRecord(b->ev[ev++], qa));
+        b->n_score_ev++;
+        cells += (int64_t)pt.n_l * 2 * 64 * pt.R * colsL + (int64_t)pt.n_r * 2 * 64 * pt.R * colsR;
         HIP_TRY(hipEventRecord(b->warm_ev[2 * i], qa));
-        HIP_TRY(hipEventRecord(b->warm_ev[2 * i + 1], qb));
+        HIP_TRY(hipEventRecord(b->warm_ev[2 * i + 1], qa));
     }
     b->warm_R.clear();
     for (const Part& pt : parts) b->warm_R.push_back(pt.R);
@@ -2695,14 +2685,14 @@ int run_2d_flanks(nra_batch* b)
             if (bk.n_jlpk > 0) {
                 HIP_TRY(hipEventRecord(b->ev[ev++], qb));
                 LAUNCH_TRY(nra_launch_joint_pk16(bk.R, b->has_n, qb, bk.n_jlpk, b->jlpk_tasks.p + bk.jlpk_off, b->reads.p,
-                                                 b->regions.p, b->pool.p, b->q2bit.p, b->qnmask.p, b->sp, 1, b->jlstate.p));
+                                                 b->regions.p, b->pool.p, b->q2bit.p, b->qnmask.p, b->sp, 1, b->jlstate.p, nullptr));
                 HIP_TRY(hipEventRecord(b->ev[ev++], qb));
                 b->n_score_ev++;
             }
             if (bk.n_jrpk > 0) {
                 HIP_TRY(hipEventRecord(b->ev[ev++], qa));
                 LAUNCH_TRY(nra_launch_joint_pk16(bk.R, b->has_n, qa, bk.n_jrpk, b->jrpk_tasks.p + bk.jrpk_off, b->reads.p,
-                                                 b->regions.p, b->pool.p, b->q2bit.p, b->qnmask.p, b->sp, 0, b->jrstate.p));
+                                                 b->regions.p, b->pool.p, b->q2bit.p, b->qnmask.p, b->sp, 0, b->jrstate.p, nullptr));
                 HIP_TRY(hipEventRecord(b->ev[ev++], qa));
                 b->n_score_ev++;
             }
