@@ -1979,8 +1979,15 @@ int set_cells_common(nra_batch* b, const int8_t* read_strand, int64_t n_cells, c
                     g.k2lo + (g.n2 - 1) * grid->step2 > k.k2lo + k.n2 - 1)
                     reuse = false;
             }
-            if (reuse) keep = 2;
-            else {
+            if (reuse) {
+                keep = 2;
+                // a refinement may follow (nra_batch2d_refine): its MID scans read the template up to the last kept count
+                for (int32_t r = 0; r < n_reads; ++r)
+                    if (swept(r)) {
+                        const NraGridRow& k = b->keep_rows[(size_t)r];
+                        k1max_pool = std::max(k1max_pool, k.k1lo + k.n1 - 1); k2max_pool = std::max(k2max_pool, k.k2lo + k.n2 - 1);
+                    }
+            } else {
                 uint64_t bytes = 0;
                 int32_t k1hi = k1max, k2hi = k2max;
                 for (int32_t r = 0; r < n_reads; ++r) {

@@ -106,21 +106,6 @@ struct NraJointCombineTask {
     int32_t rs_plane, pad0;                     // rows of a plane of `rs`: 64 * (rows per lane of the read's bucket)
 };
 
-// k_joint_cells: the MID scans of some k1 values of a read (k_joint_midscan's work) and, straight from the registers,
-// the read's cells with those k1 (k_joint_combine's work): no junction plane of the forward side ever leaves the wave.
-struct NraJointCellsTask {
-    int32_t read;
-    int32_t k1_off, nk1;            // the k1 values: k1list[k1_off .. k1_off + nk1); rows given (a refinement routed on the
-                                    // device): numbers k1_off .. of the read's row, as many as it has (at most nk1)
-    int32_t k1_slot0, slot_step;    // the column state of count k1 is slot (k1 - k1_slot0) / slot_step of `state`
-    int32_t i0;                     // index of the task's first k1 among the read's k1 values (cells are k1-major)
-    int32_t n2, out;                // the read's k2 count (rows given: the row's) and its first cell
-    int32_t rs_first, rs_stride;    // the n-th k2 is slot rs_first + n * rs_stride of `rs` / `ra` (rows given: rs_first = the
-                                    // count of slot 0, stride 1)
-    int32_t rs_plane, ra;           // rows of a plane of `rs` (64 * rows per lane of the bucket); A(k2) of slot 0
-    uint64_t state, rs;
-};
-
 // Two reads of one rows-per-lane bucket whose payload-free columns -- L up to the scoring window, or rev(R) up to
 // it -- are swept together in packed int16 cells (k_joint_pk16); the wave state goes to `state` (index into the
 // packed-state buffer): NRA_JOINT_NPSTATE(R) planes of 64 dwords, both reads in the halves of every dword.
@@ -349,13 +334,7 @@ int nra_launch_joint_midscan(int R, int has_n, hipStream_t st, int n_tasks, cons
 int nra_launch_joint_combine(hipStream_t st, int n_tasks, const NraJointCombineTask* tasks, const NraDevRead* reads,
                              NraScoreParams sp, const int32_t* fsnap, const int32_t* rsnap, const int32_t* fb,
                              const int32_t* ra, int32_t* cell_score, int32_t* cell_wscore, const NraGridRow* rows);
-// the two in one wave (k_joint_cells): MID scans + the cells, the forward junction state stays in registers
-int nra_launch_joint_cells(int R, int has_n, hipStream_t st, int n_tasks, const NraJointCellsTask* tasks,
-                           const NraDevRead* reads, const NraDevRegion* regions, const uint8_t* pool,
-                           const uint32_t* q2bit, const uint32_t* qnmask, NraScoreParams sp,
-                           const int32_t* k1list, const int32_t* state, const int32_t* rsnap, const int32_t* ra,
-                           int32_t* cell_score, int32_t* cell_wscore, const NraGridRow* rows);
-// a refinement routed on the device (nra_batch2d_refine): rows != NULL in the launchers above
+// a refinement routed on the device (nra_batch2d_refine): rows != NULL in the two launchers above
 int nra_launch_joint_refine_route(hipStream_t st, int n_reads, const uint8_t* status, const int32_t* n_ties,
                                   const int64_t* sum_k1, const int64_t* sum_k2, const double* lo1, const double* hi1,
                                   const double* lo2, const double* hi2, int buf1, int buf2, const NraGridRow* keep,

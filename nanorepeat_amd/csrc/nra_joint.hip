@@ -786,205 +786,6 @@ extern "C" int nra_launch_joint_midscan(int R, int has_n, hipStream_t st, int n_
     return (int)hipGetLastError();
 }
 #endif
-#if NRA_HAS_PART(24)
-// ------------------------------------------------------------------------------------
-// k_joint_cells: k_joint_midscan and k_joint_combine in one wave.  The MID scans end with the forward junction state of
-// one k1 -- Hq, E_in, E2_in of every row at the end of mid -- in the lane's registers; the cells (k1, k2_n) need exactly
-// that state against the R side's column states (the extended reverse sweep's planes).  Written out and read back, those
-// planes were 0.8 GB per config-3 round each way and two launches at the tail of a round; here the state is turned from
-// lane-major (a lane's R consecutive rows) to row-striped (row 64 t + lane) through LDS once per k1, and every k2 of the
-// read streams its three R-side planes past it with coalesced loads (the planes of a read are re-read per k1, from L2:
-// one wave takes all the k1 of its task in turn, 15 KB a plane set).
-//   S = max over rows r of  Hq_f(r) + H_b(a) - fo1_win,  E_f(r) + E_b(a) + (q, +2),  E2_f(r) + E2_b(a) + (q2, +2),   a = Q-2-r
-//   V = max(S, B(k1), A(k2))  ->  score, window score
-template <int R, bool HAS_N>
-__global__ __launch_bounds__(WAVE) void k_joint_cells(int n_tasks, const NraJointCellsTask* __restrict__ tasks,
-                                                      const NraDevRead* __restrict__ reads,
-                                                      const NraDevRegion* __restrict__ regions,
-                                                      const uint8_t* __restrict__ pool,
-                                                      const uint32_t* __restrict__ q2bit,
-                                                      const uint32_t* __restrict__ qnmask, NraScoreParams sp,
-                                                      const int32_t* __restrict__ k1list,
-                                                      const int32_t* __restrict__ state,
-                                                      const int32_t* __restrict__ rsnap, const int32_t* __restrict__ ra,
-                                                      int32_t* __restrict__ cell_score, int32_t* __restrict__ cell_wscore,
-                                                      const NraGridRow* __restrict__ rows)
-{
-    const int task = blockIdx.x;
-    if (task >= n_tasks) return;
-    const int lane = threadIdx.x;
-    NraJointCellsTask tk = tasks[task];
-    int k1_first = 0;
-    if (rows) {
-        const NraGridRow row = rows[tk.read];
-        tk.nk1 = imin(tk.nk1, row.n1 - tk.k1_off);
-        k1_first = row.k1lo + tk.k1_off;
-        tk.i0 = tk.k1_off;
-        tk.n2 = row.n2;
-        tk.rs_first = row.k2lo - tk.rs_first; tk.rs_stride = 1;
-        if (tk.nk1 <= 0 || row.n2 <= 0) return;
-    }
-    const NraDevRead rd = reads[tk.read];
-    const NraDevRegion rg = regions[rd.region];
-    const int Q = rd.qlen;
-    const uint8_t* __restrict__ p1 = pool + rg.p1_off;
-    const uint8_t* __restrict__ p2 = pool + rg.p2_off;
-    const int wa = imax(0, rg.l1 - 10);
-    const int cmid = 1 + rg.l2;
-    constexpr int NSTATE = NRA_JOINT_NSTATE(R);
-    const int last_lane = imin(63, imax(Q - 1, 0) / R);
-
-    uint32_t qcp[(R + 3) / 4];
-#pragma unroll
-    for (int i = 0; i < (R + 3) / 4; ++i) qcp[i] = 0;
-#pragma unroll
-    for (int i = 0; i < R; ++i)
-        qcp[i >> 2] |= (uint32_t)oriented_code<HAS_N>(rd, q2bit, qnmask, lane * R + i) << (8 * (i & 3));
-
-    const int sA = sp.match << 16, sB = -(sp.mismatch << 16), sN = -(sp.ambi << 16);
-    const int o1 = -(sp.open1 << 16), x1 = -(sp.ext1 << 16);
-    const int o2 = -(sp.open2 << 16), x2 = -(sp.ext2 << 16);
-    const int fresh = JBIAS;
-    const int o21 = o2 - o1;
-    const int g0 = lane * R;
-    // row r of a plane sits at r + r / R: a lane's R consecutive rows go out with stride R + 1 across the lanes (odd: no
-    // bank conflict), the striped read-back walks consecutive addresses
-    __shared__ int tr[(R + 1) * 64];
-    // junction constants (k_joint_combine / the tail sweep's prologue)
-    const int fo1_win = o1 - 4;
-    const int q1c = (sp.open1 - sp.ext1) << 16, q2c = (sp.open2 - sp.ext2) << 16;
-    const int cH = -JBIAS - fo1_win, cE = -JBIAS + q1c + 2, cE2 = -JBIAS + q2c + 2;
-    const int lo = sp.min_score > 1 ? sp.min_score : 1;
-    const int P = tk.rs_plane;
-
-    for (int s = 0; s < tk.nk1; ++s) {
-        const int k1 = rows ? k1_first + s : k1list[tk.k1_off + s];
-        const int t0 = rg.l1 + rg.m1 * k1 - 1;
-        const int slot = (k1 - tk.k1_slot0) / tk.slot_step;
-        constexpr int N4 = NRA_JOINT_COLSTATE(R) / 4;
-        const int4* __restrict__ sv = reinterpret_cast<const int4*>(state + tk.state + (size_t)slot * (NSTATE * 64) + (size_t)lane * (4 * N4));
-        int cs[4 * N4];
-#pragma unroll
-        for (int i = 0; i < N4; ++i) { const int4 q = sv[i]; cs[4 * i] = q.x; cs[4 * i + 1] = q.y; cs[4 * i + 2] = q.z; cs[4 * i + 3] = q.w; }
-        int Hq[R], E[R], E2[R];
-#pragma unroll
-        for (int i = 0; i < R; ++i) { Hq[i] = cs[i]; E[i] = cs[R + i]; E2[i] = cs[2 * R + i]; }
-        int Hup = cs[3 * R], M = cs[3 * R + 1];
-        int fo1_last = o1;
-        for (int v = 0; v < cmid; ++v) {                       // (the column of k_joint_midscan)
-            const int j = t0 + v;
-            const int tcode = v == 0 ? p1[t0] : p2[v - 1];
-            const bool inw = j >= wa;
-            const int pe = inw ? 2 : 0, pn = inw ? -4 : 0;
-            const int ex = inw ? (j == wa ? -4 : -2) : 0;
-            const int fo = inw ? -4 : 0, fx = inw ? -2 : 0;
-            const int fo_prev = inw ? -4 : 0;
-            if (v > 0) Hup = dpp_shr1(fresh + fo1_last, Hq[R - 1]);
-            if (j == wa) {
-#pragma unroll
-                for (int i = 0; i < R; ++i) Hq[i] -= 4;
-                Hup -= 4;
-            }
-            const int fo1p = o1 + fo_prev;
-            const int s_eq = sA + pe - fo1p, s_ne = sB + pn - fo1p, n_eq = sN + pe - fo1p, n_ne = sN + pn - fo1p;
-            const int ex1 = x1 + ex, ex2 = x2 + ex;
-            const int fo1 = o1 + fo, fo2 = fo1 + o21, fx1 = x1 + fx, fx2 = x2 + fx;
-            int hn[R];
-            int run1 = 2 * JNEG, run2 = 2 * JNEG;
-            int c1[R], c2[R];
-            int d = Hup;
-#pragma unroll
-            for (int i = 0; i < R; ++i) {
-                const int qc_ = (int)((qcp[i >> 2] >> (8 * (i & 3))) & 0xffu);
-                const bool eq_ = qc_ == tcode;
-                int sc = eq_ ? s_eq : s_ne;
-                if (HAS_N) { if ((qc_ | tcode) & 4) sc = eq_ ? n_eq : n_ne; }
-                const int dd = d + sc;
-                d = Hq[i];
-                const int ein = imax(E[i] + ex1, Hq[i]);
-                const int e2in = imax(E2[i] + ex2, Hq[i] + o21);
-                E[i] = ein; E2[i] = e2in;
-                hn[i] = imax(imax(dd, ein), e2in);
-                c1[i] = run1; c2[i] = run2;
-                run1 = imax(run1, hn[i] + fo1 - fx1 * (g0 + i));
-                run2 = imax(run2, hn[i] + fo2 - fx2 * (g0 + i));
-            }
-            fo1_last = fo1;
-            const int above1 = scan_excl_max(run1), above2 = scan_excl_max(run2);
-#pragma unroll
-            for (int i = 0; i < R; ++i) {
-                const int g = g0 + i;
-                const int F = imax(fresh, imax(above1, c1[i]) + fx1 * (g - 1));
-                const int F2 = imax(above2, c2[i]) + fx2 * (g - 1);
-                const int h = imax(imax(hn[i], F), F2);
-                M = imax(M, h);
-                Hq[i] = h + fo1;
-            }
-        }
-        // B(k1): the best score inside L + u1^k1 + mid
-        int Bk = lane <= last_lane ? M : 2 * JNEG;
-#pragma unroll
-        for (int off = 32; off > 0; off >>= 1) Bk = imax(Bk, __shfl_xor(Bk, off, 64));
-        // the junction state row-striped: f*[t] = row 64 t + lane, with the combine's constants folded in (rows beyond the
-        // read's last pairing row, Q - 2, get "minus infinity": row Q - 1 has no partner on the R side)
-        int fH[R], fE[R], fE2[R];
-#pragma unroll
-        for (int pl = 0; pl < 3; ++pl) {
-#pragma unroll
-            for (int i = 0; i < R; ++i) tr[g0 + lane + i] = pl == 0 ? Hq[i] : pl == 1 ? E[i] : E2[i];      // row g0 + i at g0 + i + lane
-            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-#pragma unroll
-            for (int t = 0; t < R; ++t) {
-                const int r = 64 * t + lane;
-                const int v = tr[r + r / R];
-                const bool ok = r < Q - 1;
-                if (pl == 0) fH[t] = ok ? v + cH : JNEG; else if (pl == 1) fE[t] = ok ? v + cE : JNEG; else fE2[t] = ok ? v + cE2 : JNEG;
-            }
-            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-        }
-        const int cell0 = tk.out + (tk.i0 + s) * tk.n2;
-        for (int n = 0; n < tk.n2; ++n) {
-            const int sl = tk.rs_first + n * tk.rs_stride;
-            const int32_t* __restrict__ rs = rsnap + tk.rs + (size_t)sl * 3 * P;
-            int tS = JNEG;
-#pragma unroll
-            for (int t = 0; t < R; ++t) {
-                const int r = 64 * t + lane;
-                const int a = r < Q - 1 ? Q - 2 - r : 0;        // (a row without a partner adds "minus infinity" + anything)
-                tS = imax(imax(tS, fH[t] + rs[a]), imax(fE[t] + rs[P + a], fE2[t] + rs[2 * P + a]));
-            }
-#pragma unroll
-            for (int off = 32; off > 0; off >>= 1) tS = imax(tS, __shfl_xor(tS, off, 64));
-            if (lane == 0) {
-                const int V = imax(imax(tS, Bk), ra[tk.ra + sl]);
-                const int scv = V >> 16;
-                if (scv >= lo) { cell_score[cell0 + n] = scv; cell_wscore[cell0 + n] = (V & 0xffff) - JBIAS; }
-                else { cell_score[cell0 + n] = -1; cell_wscore[cell0 + n] = 0; }
-            }
-        }
-    }
-}
-
-extern "C" int nra_launch_joint_cells(int R, int has_n, hipStream_t st, int n_tasks, const NraJointCellsTask* tasks,
-                                      const NraDevRead* reads, const NraDevRegion* regions, const uint8_t* pool,
-                                      const uint32_t* q2bit, const uint32_t* qnmask, NraScoreParams sp,
-                                      const int32_t* k1list, const int32_t* state, const int32_t* rsnap, const int32_t* ra,
-                                      int32_t* cell_score, int32_t* cell_wscore, const NraGridRow* rows)
-{
-    if (n_tasks <= 0) return 0;
-#define CASE(r)                                                                                     \
-    case r:                                                                                         \
-        if (has_n) k_joint_cells<r, true><<<n_tasks, WAVE, 0, st>>>(n_tasks, tasks, reads, regions, pool, q2bit, qnmask, sp, k1list, state, rsnap, ra, cell_score, cell_wscore, rows); \
-        else k_joint_cells<r, false><<<n_tasks, WAVE, 0, st>>>(n_tasks, tasks, reads, regions, pool, q2bit, qnmask, sp, k1list, state, rsnap, ra, cell_score, cell_wscore, rows);       \
-        break;
-    switch (R) {
-        NRA_R_LIST(CASE)
-    default: return (int)hipErrorInvalidValue;
-    }
-#undef CASE
-    return (int)hipGetLastError();
-}
-#endif
 #if NRA_HAS_PART(20)
 extern "C" int nra_launch_joint_bwd_ext(int R, int has_n, hipStream_t st, int n_tasks, const NraJointTask* tasks,
                                         const NraDevRead* reads, const NraDevRegion* regions, const uint8_t* pool,

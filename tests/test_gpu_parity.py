@@ -513,6 +513,29 @@ def test_joint_refinement_routed_on_the_device(capi, oracle):
                 assert (cs[r, len(mine):] == -1).all()
             # a second refinement of the same run, or one after the run was waited for: not in this state
             assert not one.refine(s1, s2, lo1, hi1, lo2, hi2)
+            # a refinement behind a grid that itself ran from kept column states (every second value of the coarse grid: no
+            # sweep, the template pool still has to reach the last kept count)
+            sparse = capi.Grid((1, 2 * s1, 40 // (2 * s1)), lo1, hi1, (0, s2, 16 // s2 + 1), lo2, hi2)
+            crs, k1s, k2s = capi.joint_grid_cells(sparse)
+            osp = oracle.joint_2d(j["region"], junk, crs, k1s, k2s, read_strand=strands)
+            oks = (osp["status"] == 0) & (osp["n_ties"] > 0)
+            nts = np.maximum(osp["n_ties"], 1).astype(np.float64)
+            y1, y2 = osp["sum_k1"] / nts, osp["sum_k2"] / nts
+            fs_ = [np.where(oks, v, 0.0) for v in (np.maximum(y1 - s1, lo1), np.minimum(y1 + s1, hi1), np.maximum(y2 - s2, lo2), np.minimum(y2 + s2, hi2))]
+            crf, k1f, k2f = capi.joint_grid_cells(capi.Grid((0, 1, 60), fs_[0], fs_[1], (0, 1, 30), fs_[2], fs_[3]))
+            of = oracle.joint_2d(j["region"], junk, crf, k1f, k2f, read_strand=strands)
+            hasf = np.zeros(n, bool); hasf[crf] = True
+            assert one.set_grid(coarse, strands) == n2
+            one.run(); one.sync()
+            swept_cells = one.stats()["executed_cells"]
+            assert one.set_grid(sparse, strands) == len(crs)
+            one.run()
+            assert one.refine(s1, s2, lo1, hi1, lo2, hi2)
+            one.sync()
+            assert one.stats()["executed_cells"] < 0.5 * swept_cells          # no sweep ran
+            gf = one.fetch(per_candidate=False)
+            for key in ("best_wscore", "sum_k1", "sum_k2", "n_ties", "status"):
+                assert np.array_equal(np.asarray(gf[key])[hasf], np.asarray(of[key])[hasf]), (s1, s2, "after reuse", key)
             # the batch goes on: the next grid sweeps or reuses as before
             assert one.set_grid(fine, strands) == n3
             one.run(); one.sync()

@@ -216,9 +216,15 @@ def fuzz_2d_grid(rng):
     t1 = np.array([t[0] for t in truth], np.float64); t2 = np.array([t[1] for t in truth], np.float64)
     strand = np.array(strand, np.int8)
     region = (L, u1, mid, u2, R)
-    flags = [0, 0, A.F_JOINT_NO_CHAIN, A.F_JOINT_TAILS, A.F_JOINT_NO_KEEP][int(rng.integers(0, 5))]
+    flags = [0, 0, 0, A.F_JOINT_NO_CHAIN, A.F_JOINT_TAILS, A.F_JOINT_NO_KEEP][int(rng.integers(0, 6))]
     prev = None
+    hist = []                                        # what the batch went through, for the report of a mismatch
     with A.Batch.create_2d_reads(region, reads, flags=flags) as b:
+        if rng.random() < 0.4:                       # flank sweeps ahead of any cell list, some strands unknown
+            ahead = strand.copy()
+            if rng.random() < 0.4: ahead[rng.integers(0, n, size=max(1, n // 3))] = 0
+            b.sweep_flanks(ahead)
+            hist.append(("sweep_flanks", ahead.tolist()))
         for rnd in range(int(rng.integers(2, 5))):
             if prev is not None and rng.random() < 0.5:
                 # a finer grid inside the previous bounds, the way the reference's round 3 follows round 2: within one
@@ -237,20 +243,40 @@ def fuzz_2d_grid(rng):
                 if rng.random() < 0.3: hi2[int(rng.integers(0, n))] = -1.0          # a read without cells
             prev = (lo1, hi1, lo2, hi2, a1[1], a2[1])
             st = strand if rng.random() < 0.85 else None
-            if rng.random() < 0.1: b.invalidate()
+            if rng.random() < 0.1: b.invalidate(); hist.append(("invalidate",))
             grid = A.Grid(a1, lo1, hi1, a2, lo2, hi2)
+            hist.append(["grid", a1, a2, [x.tolist() for x in (lo1, hi1, lo2, hi2)], None if st is None else st.tolist(), False])
             cr, k1, k2 = A.joint_grid_cells(grid)
             if b.set_grid(grid, st) != len(cr):
                 return dict(kind="2d-grid", key="n_cells", got=[b.n_cand], want=[len(cr)])
             if len(cr) == 0:
                 continue
-            b.run(); b.sync(); g = b.fetch()
+            b.run()
             o = O.joint_2d(region, reads, cr, k1, k2, read_strand=st)
+            refined = False
+            if st is not None and a1[1] > 1 and a2[1] > 1 and rng.random() < 0.6:
+                # the reference's round 3 behind this grid, routed on the device (nra_batch2d_refine): the oracle on the finer
+                # grid the host would have routed from this grid's results
+                refined = b.refine(a1[1], a2[1], lo1, hi1, lo2, hi2)
+                hist[-1][-1] = bool(refined)
+                if refined:
+                    ok = (o["status"] == 0) & (o["n_ties"] > 0)
+                    nt = np.maximum(o["n_ties"], 1).astype(np.float64)
+                    z1, z2 = o["sum_k1"] / nt, o["sum_k2"] / nt
+                    f = [np.where(ok, v, 0.0) for v in (np.maximum(z1 - a1[1], lo1), np.minimum(z1 + a1[1], hi1),
+                                                        np.maximum(z2 - a2[1], lo2), np.minimum(z2 + a2[1], hi2))]
+                    cr, k1, k2 = A.joint_grid_cells(A.Grid((0, 1, 200), f[0], f[1], (0, 1, 100), f[2], f[3]))
+                    o = O.joint_2d(region, reads, cr, k1, k2, read_strand=st)
+                    o = {k: v for k, v in o.items() if len(v) == n}          # (the refinement's per-cell arrays are laid out per read)
+            b.sync(); g = b.fetch()
             has = np.zeros(n, bool); has[cr] = True
+            if refined and not (np.asarray(g["status"])[~has] == 2).all():
+                return dict(kind="2d-grid", key="refined status of reads without cells", flags=flags, got=np.asarray(g["status"]).tolist(), want=has.tolist())
             for k in K2:
+                if k not in o: continue
                 sel = has if len(o[k]) == n else slice(None)
                 if not np.array_equal(np.asarray(g[k])[sel], np.asarray(o[k])[sel]):
-                    return dict(kind="2d-grid", flags=flags, round=rnd, key=k, region=region, reads=reads, grid=(a1, a2), bounds=[x.tolist() for x in (lo1, hi1, lo2, hi2)],
+                    return dict(kind="2d-grid", flags=flags, round=rnd, key=k, region=region, reads=reads, hist=hist, grid=(a1, a2), bounds=[x.tolist() for x in (lo1, hi1, lo2, hi2)],
                                 strands=None if st is None else st.tolist(), got=np.asarray(g[k]).tolist(), want=np.asarray(o[k]).tolist())
     return None
 
