@@ -1,7 +1,7 @@
 #!/bin/bash
 # Profiles of the default bench.py command on the GPU box: kernel stats + PMC counter passes.
 #   tools/profile_bench.sh <tag> <kernel name substring> [extra bench.py flags]      (run from the repo root, via gpurun)
-#   e.g. tools/profile_bench.sh r03 k_sweep_      tools/profile_bench.sh r03_config3 k_joint --config 3
+#   e.g. tools/profile_bench.sh r04 k_sweep_      tools/profile_bench.sh r04_config3 k_joint --config 3
 # Writes raw rocprofv3 output under gpurun_out/prof_<tag>/ and the summaries the judge reads under
 # gpurun_out/profiles_<tag>/ (copy them into profiles/ and commit).
 set -o pipefail
