@@ -39,7 +39,8 @@ int fail(int code, const std::string& msg)
     do {                                                                                         \
         hipError_t e_ = (expr);                                                                  \
         if (e_ != hipSuccess)                                                                    \
-            return fail(NRA_E_DEVICE, std::string(#expr) + ": " + hipGetErrorString(e_));        \
+            return fail(e_ == hipErrorOutOfMemory ? NRA_E_NOMEM : NRA_E_DEVICE,                  \
+                        std::string(#expr) + ": " + hipGetErrorString(e_));                      \
     } while (0)
 
 // NRA_DEBUG=1 in the environment: synchronise after every launch and trace it on stderr
@@ -124,6 +125,8 @@ struct Arena {
     ~Arena() { for (Chunk& c : chunks) device_chunk_put(device, c.p, c.size); }
     void expect(size_t bytes) { next_chunk = std::max(next_chunk, bytes); }
     void reset() { for (Chunk& c : chunks) c.used = 0; }        // keep the memory, hand it out again
+    void release() { for (Chunk& c : chunks) device_chunk_put(device, c.p, c.size); chunks.clear(); }    // give it back
+    size_t capacity() const { size_t n = 0; for (const Chunk& c : chunks) n += c.size; return n; }
     hipError_t alloc(size_t bytes, void** out)
     {
         bytes = (bytes + 255) & ~(size_t)255;
@@ -484,7 +487,7 @@ struct nra_batch {
     int payload_strips = 0;                     // waves of a chained payload launch (strips in chain_payload)
     DevBuf<NraChainBlock> chain_blocks;         // k_sweep_ringmt: (task, row block) lists, launch group after launch group
     DevBuf<uint64_t> mt_strips;                 // ... the granule strips between consecutive blocks (zeroed at create)
-    DevBuf<int32_t> mt_words;                   // ... [0] ticket, [1] launch-wide give-up word
+    DevBuf<int32_t> mt_words;                   // ... [0] launch-wide give-up word (kMtGiveUp), [1] unused, [2 + bucket] that bucket's ticket
     DevBuf<NraTask> queue_tasks;
     DevBuf<int32_t> queue_count;   // per bucket: prebuilt queue length (constant)
     DevBuf<int32_t> tie_count;     // per bucket: tie queue length (device-written)
@@ -516,6 +519,7 @@ struct nra_batch {
     std::vector<int8_t> keep_strand;
     std::vector<uint64_t> keep_state_off, keep_rs_off;
     std::vector<int32_t> keep_ra_off;
+    bool keep_off = false;                      // set for one retry: this cell list keeps nothing (the kept states did not fit)
     int joint_keep = 0;                         // this cell list: 0 = nothing kept, 1 = sweeps that keep, 2 = no sweeps, kept states
     // 2D: the packed sweep of rev(R) up to the window is valid for this strand of the read (like lst_strand for L)
     std::vector<int8_t> rpk_strand;
@@ -1297,9 +1301,12 @@ int nra_batch1d_create(int device, const nra_region_t* regions, int32_t n_region
         HIP_TRY(b->chain_blocks.upload(chain_blocks));
         const size_t granules = std::max<size_t>(mt_strip_total, 1) * 5 * (size_t)b->chain_cap;
         HIP_TRY(b->mt_strips.alloc(granules));
-        HIP_TRY(hipMemset(b->mt_strips.p, 0, granules * 8));       // no granule carries an epoch yet (epochs are never 0)
+        // (on the batch's own stream: the bucket streams are ordered behind it by fork_ev; a null-stream memset is not
+        // ordered with these non-blocking streams at all)
+        HIP_TRY(hipMemsetAsync(b->mt_strips.p, 0, granules * 8, b->stream));       // no granule carries an epoch yet (epochs are never 0)
         HIP_TRY(b->mt_words.alloc(2 + b->buckets.size()));
-        HIP_TRY(hipMemset(b->mt_words.p, 0, (2 + b->buckets.size()) * 4));
+        HIP_TRY(hipMemsetAsync(b->mt_words.p, 0, (2 + b->buckets.size()) * 4, b->stream));
+        HIP_TRY(hipStreamSynchronize(b->stream));
     }
     if (strip_total || !chain_blocks.empty()) {
         if (strip_total) HIP_TRY(b->chain_sweep.alloc(strip_total));
@@ -1362,7 +1369,9 @@ static int run_1d(nra_batch* b)
     if (b->chain_blocks.n > 0) {
         // concurrent row blocks: every block adds its maximum to the read's A (atomicMax; A >= 0); the give-up word
         HIP_TRY(hipMemsetAsync(b->read_a1d.p, 0, std::max<size_t>((size_t)b->n_reads, 1) * 4, st));
-        HIP_TRY(hipMemsetAsync(b->mt_words.p, 0, 4, st));
+        // (NRA_TEST_MT_GIVEUP in the environment, tests only: the run starts with the give-up word set, as if a wave had
+        // timed out -- every waiting wave leaves at its next look and the fetch reports NRA_E_DEVICE)
+        HIP_TRY(hipMemsetAsync(b->mt_words.p, getenv("NRA_TEST_MT_GIVEUP") ? 1 : 0, 4, st));
         b->mt_checked = false;
     }
     int ev = 2;
@@ -1861,7 +1870,18 @@ int nra_batch2d_set_grid(nra_batch_t* b, const int8_t* read_strand,
     if (n_cells_out) *n_cells_out = n;
     const JointGrid grid{step1, step2, rows.data(), keep.data()};
     // no per-cell arrays at all: the tasks come from the rows, the selector gets the rows (16 bytes a read)
-    return set_cells_common(b, read_strand, n, nullptr, nullptr, nullptr, &grid);
+    rc = set_cells_common(b, read_strand, n, nullptr, nullptr, nullptr, &grid);
+    if (rc == NRA_E_NOMEM && b->joint_keep == 1) {
+        // The kept column states did not fit after all (the check against the free memory races with other batches, ranks
+        // and libraries on the device): give the arena back and set the grid again without keeping -- a later, finer grid
+        // then sweeps again, nra_batch2d_refine says NRA_E_STATE, the results are the same.
+        b->keep_arena.release();
+        b->keep_valid = false;
+        b->keep_off = true;
+        rc = set_cells_common(b, read_strand, n, nullptr, nullptr, nullptr, &grid);
+        b->keep_off = false;
+    }
+    return rc;
 }
 
 }  // extern "C"
@@ -1961,6 +1981,7 @@ int set_cells_common(nra_batch* b, const int8_t* read_strand, int64_t n_cells, c
     // the MID scans and the combine.  joint_keep: 0 = nothing kept, 1 = this list sweeps and keeps, 2 = no sweeps.
     int32_t k1max_pool = k1max, k2max_pool = k2max;
     int keep = 0;
+    uint64_t keep_bytes = 0;
     {
         const bool brute_now = (flags & NRA_F_BRUTE_FORCE) != 0 || left_len < 1 || right_len < 2;
         bool strands_all = read_strand != nullptr && n_reads > 0;
@@ -1998,7 +2019,11 @@ int set_cells_common(nra_batch* b, const int8_t* read_strand, int64_t n_cells, c
                 }
                 const int64_t tl_keep = (int64_t)left_len + (int64_t)unit1_len * k1hi + mid_len + (int64_t)unit2_len * k2hi + right_len;
                 // ... within the budget, and within half of what the device has left (what the arena holds already counts as free)
-                bool fits = bytes <= NRA_JOINT_KEEP_BUDGET && tl_keep <= NRA_MAX_TLEN;
+                // (NRA_JOINT_KEEP_BUDGET_GB in the environment overrides the built-in budget; 0 keeps nothing)
+                const char* budget_env = getenv("NRA_JOINT_KEEP_BUDGET_GB");
+                const uint64_t budget = budget_env ? (uint64_t)(atof(budget_env) * (double)(1ull << 30)) : (uint64_t)NRA_JOINT_KEEP_BUDGET;
+                bool fits = bytes <= budget && tl_keep <= NRA_MAX_TLEN && !b->keep_off;
+                keep_bytes = bytes;
                 if (fits) {
                     size_t held = 0, free_b = 0, total_b = 0;
                     for (const Arena::Chunk& c : b->keep_arena.chunks) held += c.size;
@@ -2011,7 +2036,10 @@ int set_cells_common(nra_batch* b, const int8_t* read_strand, int64_t n_cells, c
         b->keep_pending = keep == 1;
         b->joint_keep = keep;
         if (keep == 1) {
-            b->keep_arena.reset();
+            // what the arena holds is handed out again; if it is too small it goes back BEFORE the larger chunk is asked for
+            // (old and new together may not fit)
+            if (b->keep_arena.capacity() < keep_bytes + (2u << 20)) b->keep_arena.release();
+            else b->keep_arena.reset();
             b->keep_rows.assign(grid->keep, grid->keep + n_reads);
             b->keep_strand.assign(read_strand, read_strand + n_reads);
             b->keep_state_off.assign((size_t)n_reads, 0);

@@ -1115,7 +1115,13 @@ __global__ __launch_bounds__(WAVE) void k_sweep_ringchain(int n_tasks, const Nra
 typedef unsigned long long nra_u64;
 typedef __attribute__((address_space(1))) nra_u64 nra_gu64;
 typedef __attribute__((address_space(1))) int nra_gi32;
-#define NRA_MT_SPIN_LIMIT (1u << 24)        // polls of ~1 us each before a wave gives up (a hang guard, not a path)
+// Polls (2 - 3 us each: an s_sleep and 3 - 5 agent-scope loads) before a waiting wave gives up: ~2.5 s, three orders above
+// the longest legitimate wait (64 * (skew + 1) steps of the block above, a millisecond or two).  A hang guard, not a
+// path: the argument that no wave waits for ever (tickets: a producer holds a smaller ticket than its consumer, so it
+// is running or done) assumes that a wave, once started, stays resident until it ends -- true as long as nothing
+// preempts the queue (no CWSR / time-slicing against another process on the device); if that ever fails the guard
+// turns a hang into NRA_E_DEVICE from nra_batch_sync / nra_batch1d_fetch.
+#define NRA_MT_SPIN_LIMIT (1u << 20)
 
 template <int R, bool HAS_N, int DIR, bool W>
 __global__ __launch_bounds__(WAVE, 3) void k_sweep_ringmt(int n_blocks, const NraChainBlock* __restrict__ blocks,

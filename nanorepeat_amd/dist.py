@@ -45,7 +45,19 @@ def _rows_per_lane(need, min_reads=0, span=2):
     return _R_LIST[idx]
 
 
-_SIMDS = 1024              # MI355X: 256 compute units x 4
+_SIMDS_DEFAULT = 1024      # MI355X: 256 compute units x 4
+
+
+def _simds():
+    """SIMDs of the device the batch will run on (the library's device_simds(): 4 x its compute units); MI355X's 1024 where
+    no device is visible (planning on a CPU box)."""
+    try:
+        import torch
+        if torch.cuda.is_available():
+            return 4 * int(torch.cuda.get_device_properties(torch.cuda.current_device()).multi_processor_count)
+    except Exception:
+        pass
+    return _SIMDS_DEFAULT
 
 
 def _prefer_row_blocks(q, either):
@@ -62,10 +74,11 @@ def _prefer_row_blocks(q, either):
     rows_blocks = int(((cls + 64 * best - 1) // (64 * best) * (64 * best)).sum())
     rows_single = int((64 * _R_LIST[np.searchsorted(_R_LIST, (cls + 63) // 64)]).sum())
     n = len(cls)
+    simds = _simds()
     waves, nblk = (n + 1) // 2, rows_blocks / (64.0 * best) / n
-    r1 = waves / _SIMDS
+    r1 = waves / simds
     e1 = r1 / np.ceil(r1)
-    r2 = waves * nblk / (3.0 * _SIMDS)
+    r2 = waves * nblk / (3.0 * simds)
     cap = 3.7 + 0.1 * (best - _BLOCK_R[-1]) + (0.4 if nblk < 2.5 else 0.0)
     return rows_single / (4.3 * e1) > rows_blocks / min(cap, 1.9 + 1.2 * r2 - 0.25 * (nblk - 2.0))
 

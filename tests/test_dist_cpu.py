@@ -289,6 +289,71 @@ def test_joint_sharded_hip_path_two_ranks_one_gpu(capi, oracle):
             assert res[r][k] == want[k].tolist(), (r, k)
 
 
+def test_config4_regions_deal_evenly_over_2_4_8_ranks():
+    """The strong-scaling workload north_star names (BASELINE config 4: 1000 regions x 1000 reads, mixed 3-6 bp motifs):
+    the regions' costs -- executed cells, from the region descriptors alone, what bench.py --config 4 deals with -- go to
+    N = 2, 4, 8 ranks with at most 3 % between the heaviest rank and the mean, every region to exactly one rank."""
+    from nanorepeat_amd import dist as D, synth
+    cost = np.array([synth.config4_region_cost(synth.config4_region(g), 1000) for g in range(1000)], np.int64)
+    assert (cost > 0).all() and cost.max() < 8 * cost.min()          # (a region costs 0.6 - 2.7 G cells: 1000 of them deal finely)
+    for world in (2, 4, 8):
+        owner = D.lpt_assign(cost, world)
+        assert owner.shape == cost.shape and set(owner.tolist()) == set(range(world))
+        per_rank = np.bincount(owner, weights=cost, minlength=world)
+        assert per_rank.max() / per_rank.mean() <= 1.03, (world, per_rank.max() / per_rank.mean())
+        # reads stay with their region: a rank's shard is whole regions
+        assert np.bincount(owner, minlength=world).sum() == 1000
+
+
+def _nccl_worker(port, q):
+    sys.path.insert(0, ROOT)
+    import torch
+    import torch.distributed as dist
+    from nanorepeat_amd import dist as D, synth
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    try:
+        d = synth.make_1d(40, "TATTG", (9, 27), "ont", kwin=None, anchor=300, seed=14)
+        idx = np.arange(len(d["reads"]), dtype=np.int64)
+        sb = D.ShardedBatch1D(d["regions"], d["reads"], d["kmin"], d["kmax"], None, idx, len(idx), device=0)
+        try:
+            sb.run()
+            out = sb.gather()                 # fetch + the all_gather on the nccl (= RCCL) backend
+            sb.run()
+            again = sb.exchange(sb.fetch_local())
+        finally:
+            sb.close()
+        t = torch.ones(4, device="cuda")
+        dist.all_reduce(t)
+        q.put({k: np.asarray(v).tolist() for k, v in out.items()} | {"same": all(np.array_equal(out[k], again[k]) for k in out),
+                                                                     "backend": dist.get_backend(), "sum": float(t.sum().item())})
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+@pytest.mark.timeout(300)
+def test_sharded_batch_on_the_nccl_backend_world_size_1(capi, oracle):
+    """ShardedBatch1D with its exchange on the nccl backend (RCCL), as far as one GPU allows: world size 1, device tensors,
+    the same all_gather call every N takes.  (More than one rank on RCCL has not run anywhere yet: DESIGN.md 6.)"""
+    from nanorepeat_amd import synth
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    p = ctx.Process(target=_nccl_worker, args=(37500 + os.getpid() % 2000, q))
+    p.start()
+    res = q.get(timeout=240)
+    p.join(60)
+    assert p.exitcode == 0
+    d = synth.make_1d(40, "TATTG", (9, 27), "ont", kwin=None, anchor=300, seed=14)
+    want = oracle.round3_1d(d["regions"], d["reads"], d["kmin"], d["kmax"])
+    assert res["backend"] == "nccl" and res["same"] and res["sum"] == 4.0
+    for k in ("best_score", "sum_k", "n_ties", "status"):
+        assert res[k] == want[k].tolist(), k
+
+
 def test_row_block_choice_agrees_with_the_measured_cases():
     """dist._prefer_row_blocks mirrors nra_batch1d_create's choice between one register block and row blocks for the reads
     of 1537 - 3072 bases; profiles/r03_row_blocks_or_one_block_54_cases.txt holds what both forms cost on an MI355X for

@@ -191,6 +191,52 @@ def test_round3_estimation_golden_end_to_end(capi, golden_1d):
         assert R3.output_repeat_size_1d(rr) == c["repeat_size_txt"]
 
 
+def test_regions_of_a_bed_in_one_call_equal_region_by_region(capi, oracle):
+    """INTEGRATION.md's primary 1D stub: the regions a worker would take one after the other (nanoRepeat_bam.py:602-612) in
+    ONE round3_estimation_regions call -- 15 regions of mixed motifs x 50 reads, reference window rule, a read without a
+    round-2 size, a junk read -- against 15 single-region calls (the per-region drop-in, :446-450) and the oracle."""
+    rng = np.random.default_rng(15)
+    regions = []
+    for g in range(15):
+        unit = synth.rand_unit(rng, int(rng.integers(2, 7)))
+        left, right = synth.rand_seq(rng, 400), synth.rand_seq(rng, 400)
+        rr = R3.RepeatRegion()
+        rr.left_anchor_seq, rr.repeat_unit_seq, rr.right_anchor_seq = left, unit, right
+        rr.chrom, rr.start_pos, rr.end_pos = "chr1", 1000 * g, 1000 * g + 50
+        alleles = (int(rng.integers(5, 60)), int(rng.integers(5, 60)))
+        for i in range(50):
+            kt = alleles[i % 2]
+            core = synth.apply_errors(rng, left[-100:] + unit * kt + right[:100], "ont_q20")
+            r2 = max(0.0, kt + float(rng.normal(0, 1)))
+            if i == 7:
+                r2 = None                                  # no round-2 estimate: skipped (:460)
+            if i == 9:
+                core = synth.rand_seq(rng, 80)             # nothing reaches min_dp_score: no record (:421)
+            rr.read_dict[f"g{g}r{i}"] = R3.Read(f"g{g}r{i}", r2)
+            rr.read_core_seq_dict[f"g{g}r{i}"] = core
+        regions.append(rr)
+
+    def sizes():
+        return [[None if rd.round3_repeat_size is None else float(rd.round3_repeat_size) for rd in rr.read_dict.values()] for rr in regions]
+
+    def reset():
+        for rr in regions:
+            for rd in rr.read_dict.values():
+                rd.round3_repeat_size = None
+
+    R3.round3_estimation_regions("ont", False, regions, 4)                          # one call
+    one_call = sizes()
+    reset()
+    for rr in regions:
+        R3.round3_estimation("ont", False, rr, 4)                                   # region by region
+    by_region = sizes()
+    reset()
+    R3.round3_estimation_regions("ont", False, regions, 4, scorer=oracle.round3_1d)
+    want = sizes()
+    assert one_call == by_region == want
+    assert sum(v is None for reg in want for v in reg) >= 30                        # the skipped and the junk read of every region
+
+
 # ------------------------------------------------------------------ 2D
 def _cells(j, step=2):
     cr, k1, k2 = [], [], []
@@ -525,6 +571,7 @@ def test_joint_refinement_routed_on_the_device(capi, oracle):
             crf, k1f, k2f = capi.joint_grid_cells(capi.Grid((0, 1, 60), fs_[0], fs_[1], (0, 1, 30), fs_[2], fs_[3]))
             of = oracle.joint_2d(j["region"], junk, crf, k1f, k2f, read_strand=strands)
             hasf = np.zeros(n, bool); hasf[crf] = True
+            one.invalidate()                                  # (the coarse grid sweeps again and keeps)
             assert one.set_grid(coarse, strands) == n2
             one.run(); one.sync()
             swept_cells = one.stats()["executed_cells"]
@@ -552,6 +599,57 @@ def test_joint_refinement_routed_on_the_device(capi, oracle):
         b.run()
         assert not b.refine(s1, s2, lo1, hi1, lo2, hi2)
         b.sync()
+
+
+def test_kept_column_states_budget_and_the_give_up_word(capi, oracle, monkeypatch):
+    """Two guards that should never decide a result.  NRA_JOINT_KEEP_BUDGET_GB = 0: a routed grid keeps no column states,
+    a refinement is refused (NRA_E_STATE) and the finer grid sweeps again -- same results.  NRA_TEST_MT_GIVEUP: a run of
+    concurrent row blocks that starts with its give-up word set (as if a wave had timed out waiting for the block above
+    it) ends at once and the fetch reports NRA_E_DEVICE instead of results."""
+    j = synth.make_joint(12, alleles=((11, 6), (21, 4)), read_len=640, read_sd=60, anchor=330, seed=5)
+    t1, t2 = j["truth"][:, 0].astype(np.float64), j["truth"][:, 1].astype(np.float64)
+    strands = j["strand"].astype(np.int8)
+    lo1, hi1, lo2, hi2 = t1 - 9, t1 + 8, np.maximum(t2 - 5, 0), t2 + 5
+    coarse = capi.Grid((1, 4, 9), lo1, hi1, (0, 3, 5), lo2, hi2)
+    fine = capi.Grid((0, 1, 40), t1 - 2, t1 + 2, (0, 1, 16), np.maximum(t2 - 1, 0), t2 + 2)
+    cr, k1, k2 = capi.joint_grid_cells(fine)
+    o = oracle.joint_2d(j["region"], j["reads"], cr, k1, k2, read_strand=strands)
+    cells = {}
+    for budget in (None, "0"):
+        if budget is not None:
+            monkeypatch.setenv("NRA_JOINT_KEEP_BUDGET_GB", budget)
+        with capi.Batch.create_2d_reads(j["region"], j["reads"]) as b:
+            assert b.set_grid(coarse, strands) > 0
+            b.run()
+            assert b.refine(4, 3, lo1, hi1, lo2, hi2) == (budget is None)
+            b.sync()
+            assert b.set_grid(fine, strands) == len(cr)
+            b.run(); b.sync()
+            g = b.fetch()
+            cells[budget] = b.stats()["executed_cells"]
+            for key in o:
+                assert np.array_equal(np.asarray(g[key]), np.asarray(o[key])), (budget, key)
+    monkeypatch.delenv("NRA_JOINT_KEEP_BUDGET_GB")
+    assert cells[None] < 0.5 * cells["0"]
+    # 1D, reads beyond one register block: row blocks as concurrent waves
+    rng = np.random.default_rng(8)
+    left, right = synth.rand_seq(rng, 300), synth.rand_seq(rng, 300)
+    reads = [synth.apply_errors(rng, left[-100:] + "TATTG" * k + right[:100], "hifi") for k in (700, 720, 760, 800)]
+    kmin, kmax = np.array([690, 710, 750, 790], np.int32), np.array([710, 730, 770, 810], np.int32)
+    with capi.Batch.create_1d([(left, "TATTG", right)], reads, kmin, kmax) as b:
+        b.run(); b.sync()
+        good = b.fetch(per_candidate=False)
+        assert (good["status"] == 0).all()
+        monkeypatch.setenv("NRA_TEST_MT_GIVEUP", "1")
+        b.run()
+        with pytest.raises(capi.NraError) as e:
+            b.sync()
+        assert e.value.code == -2 and "timed out" in str(e.value)
+        monkeypatch.delenv("NRA_TEST_MT_GIVEUP")
+        b.run(); b.sync()                                     # the batch goes on
+        again = b.fetch(per_candidate=False)
+        for key in good:
+            assert np.array_equal(good[key], again[key]), key
 
 
 def test_joint_flank_sweeps_ahead_of_the_cell_list(capi, oracle):
