@@ -71,6 +71,9 @@ extern "C" {
 #define NRA_F_JOINT_NO_KEEP 1024 /* testing / comparison, 2D routed grids: every grid of a batch sweeps its reads again, instead of keeping
                                  the column states a coarse grid's sweeps leave at EVERY repeat count of a read's range, from which a
                                  finer grid inside those ranges (the reference's round 3 after round 2) needs no sweep at all */
+#define NRA_F_NO_QUANTA 2048  /* testing / comparison, 1D: a bucket's reverse sweeps and forward sweeps as two launches (k_sweep_ring /
+                                 k_sweep_ring32) instead of one launch of quanta taken by ticket -- reverse sweep, forward sweep up to
+                                 the first unit boundary, forward sweep from there on (k_sweep_ringq) */
 #define NRA_F_BRUTE_FORCE  4  /* score the K candidates of a read as K independent alignments
                                  (k_score_pk16) instead of the junction decomposition (k_sweep_pk16) */
 

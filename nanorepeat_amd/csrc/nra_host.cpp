@@ -326,6 +326,8 @@ struct Bucket {
     int n_sweep = 0;           // junction-decomposition tasks (pairs of reads)
     size_t sweep_off = 0;
     bool ring = false;         // k_sweep_ring (LDS hand-off) instead of k_sweep_pk16 (DPP hand-off)
+    bool quanta = false;       // ... and its reverse and forward sweeps as ONE launch of quanta taken by ticket (k_sweep_ringq)
+    size_t q_off = 0, q_task_off = 0, q_state_off = 0;      // into q_list (3 entries a task), q_words' arrivals, q_state (int32)
     int n_jbwd = 0;            // 2D decomposition: reverse sweeps (one per read)
     size_t jbwd_off = 0;
     int n_jlpk = 0, n_jrpk = 0;    // ... packed sweeps of the payload-free columns of L / rev(R) (one per pair of reads)
@@ -488,6 +490,12 @@ struct nra_batch {
     DevBuf<NraChainBlock> chain_blocks;         // k_sweep_ringmt: (task, row block) lists, launch group after launch group
     DevBuf<uint64_t> mt_strips;                 // ... the granule strips between consecutive blocks (zeroed at create)
     DevBuf<int32_t> mt_words;                   // ... [0] launch-wide give-up word (kMtGiveUp), [1] unused, [2 + bucket] that bucket's ticket
+    // the sweeps in quanta (k_sweep_ringq): ticket order, the words of a run ([0] give-up word, [1 + bucket] that bucket's
+    // ticket, then one arrival counter per task -- zeroed by one memset per run), the wave states at the cut
+    DevBuf<uint32_t> q_list;
+    DevBuf<int32_t> q_words, q_state;
+    size_t q_words_n = 0, q_arrivals_off = 0;
+    bool q_checked = true;
     DevBuf<NraTask> queue_tasks;
     DevBuf<int32_t> queue_count;   // per bucket: prebuilt queue length (constant)
     DevBuf<int32_t> tie_count;     // per bucket: tie queue length (device-written)
@@ -1295,6 +1303,33 @@ int nra_batch1d_create(int device, const nra_region_t* regions, int32_t n_region
     if (!brute) {
         HIP_TRY(b->snap.alloc((size_t)snap_total));
         HIP_TRY(b->read_a1d.alloc((size_t)n_reads));
+        // Quanta (k_sweep_ringq): for the unchained LDS-ring buckets of a batch whose tasks are few against the wave slots --
+        // kernel-length tasks then end a launch with SIMDs holding 3 or 4 of them while others hold 2 or 3; with tens of
+        // tasks per slot (BASELINE config 4) two launches already run at 0.98 of the issue ceiling and the states at the
+        // cut (NRA_QSTATE_INTS(R) x 256 B a task) would only be traffic.
+        std::vector<uint32_t> qlist;
+        size_t q_tasks = 0, q_state = 0, n_q_tasks_all = 0;
+        for (const Bucket& bk : b->buckets) if (bk.ring && !bk.chain && !bk.mt) n_q_tasks_all += (size_t)bk.n_sweep;
+        const bool want_quanta = (flags & (NRA_F_NO_QUANTA | NRA_F_DPP_SWEEP)) == 0 && n_q_tasks_all > 0 &&
+                                 n_q_tasks_all <= (size_t)8 * (size_t)device_simds(device);
+        for (Bucket& bk : b->buckets) {
+            if (!want_quanta || !bk.ring || bk.chain || bk.mt || bk.n_sweep <= 0) continue;
+            bk.quanta = true;
+            bk.q_off = qlist.size(); bk.q_task_off = q_tasks; bk.q_state_off = q_state;
+            // ticket order: every task's two producers (its reverse sweep, its forward sweep up to the cut), task by task,
+            // then every task's second part -- a consumer's producers always hold smaller tickets
+            for (int t = 0; t < bk.n_sweep; ++t) { qlist.push_back((uint32_t)t); qlist.push_back((1u << 30) | (uint32_t)t); }
+            for (int t = 0; t < bk.n_sweep; ++t) qlist.push_back((2u << 30) | (uint32_t)t);
+            q_tasks += (size_t)bk.n_sweep;
+            q_state += (size_t)bk.n_sweep * NRA_QSTATE_INTS(bk.R) * 64;
+        }
+        if (!qlist.empty()) {
+            HIP_TRY(b->q_list.upload(qlist));
+            b->q_arrivals_off = (1 + b->buckets.size() + 3) / 4 * 4;
+            b->q_words_n = b->q_arrivals_off + q_tasks;
+            HIP_TRY(b->q_words.alloc(b->q_words_n));
+            HIP_TRY(b->q_state.alloc(q_state));
+        }
     }
     HIP_TRY(b->cand_flag.alloc((size_t)total));
     if (!chain_blocks.empty()) {
@@ -1349,7 +1384,7 @@ int nra_batch1d_create(int device, const nra_region_t* regions, int32_t n_region
     for (const Bucket& bk : b->buckets) ex += bk.cells_pair + bk.cells_queue + bk.cells_sweep;
     b->stats.executed_cells = ex;
     b->stats.algorithmic_bytes = (int64_t)pr.q2bit.size() * 4 + (int64_t)pool.size() + total * 4 + (int64_t)n_reads * 17;
-    b->stats.intermediate_bytes = brute ? 0 : 2 * (int64_t)snap_total * 4;      // the junction snapshot: written, then read
+    b->stats.intermediate_bytes = brute ? 0 : 2 * ((int64_t)snap_total + (int64_t)b->q_state.n) * 4;   // the junction snapshot and the wave states at the cut: written, then read
     *out = guard.release();
     return NRA_OK;
 }
@@ -1374,6 +1409,12 @@ static int run_1d(nra_batch* b)
         HIP_TRY(hipMemsetAsync(b->mt_words.p, getenv("NRA_TEST_MT_GIVEUP") ? 1 : 0, 4, st));
         b->mt_checked = false;
     }
+    if (b->q_words_n > 0) {
+        // the sweeps in quanta: tickets and arrival counters start at 0; the give-up word too (NRA_TEST_MT_GIVEUP: set)
+        HIP_TRY(hipMemsetAsync(b->q_words.p, 0, b->q_words_n * 4, st));
+        if (getenv("NRA_TEST_MT_GIVEUP")) HIP_TRY(hipMemsetAsync(b->q_words.p, 1, 4, st));
+        b->q_checked = false;
+    }
     int ev = 2;
     b->n_score_ev = 0; b->n_ext_ev = 0;
     const int max_waves = 256 * 16;
@@ -1391,6 +1432,23 @@ static int run_1d(nra_batch* b)
             HIP_TRY(hipStreamWaitEvent(q, b->fork_ev, 0));
             HIP_TRY(hipEventRecord(b->ev[ev++], q));
             int32_t* strips = bk.chain ? b->chain_sweep.p + bk.strip_off : nullptr;
+            if (bk.quanta) {
+                // one launch: 3 quanta a task, taken by ticket (two timing pairs like the two launches it replaces: the
+                // second one is empty)
+                auto launch = bk.half ? nra_launch_sweep_ringq32 : nra_launch_sweep_ringq;
+                LAUNCH_TRY(launch(bk.R, b->has_n, q, 3 * bk.n_sweep, b->q_list.p + bk.q_off, b->q_words.p + 1 + i,
+                                  b->q_words.p + b->q_arrivals_off + bk.q_task_off, b->q_words.p, b->q_state.p + bk.q_state_off,
+                                  b->sweep_tasks.p + bk.sweep_off, b->reads.p, b->regions.p, b->pool.p, b->q2bit.p, b->qnmask.p,
+                                  b->sp, b->kmin.p, b->kmax.p, b->coff.p, b->snap.p, b->read_a1d.p, b->cand_score.p,
+                                  b->cand_flag.p));
+                HIP_TRY(hipEventRecord(b->ev[ev++], q));
+                HIP_TRY(hipEventRecord(b->ev[ev++], q));
+                HIP_TRY(hipEventRecord(b->ev[ev++], q));
+                b->n_score_ev += 2;
+                HIP_TRY(hipEventRecord(b->bdone[i], q));
+                HIP_TRY(hipStreamWaitEvent(st, b->bdone[i], 0));
+                continue;
+            }
             if (bk.mt) {
                 for (const auto& g : bk.mt_groups)
                     LAUNCH_TRY(nra_launch_sweep_ringmt_bwd(bk.R, b->has_n, bk.wide ? 1 : 0, q, g.second, b->chain_blocks.p + g.first,
@@ -1508,6 +1566,12 @@ static int run_1d(nra_batch* b)
 // should never fire; if it does the results of this run are not to be used.)
 static int check_mt(nra_batch* b)
 {
+    if (!b->q_checked && b->q_words_n > 0) {
+        int32_t gave_up = 0;
+        HIP_TRY(hipMemcpy(&gave_up, b->q_words.p, 4, hipMemcpyDeviceToHost));
+        b->q_checked = true;
+        if (gave_up) return fail(NRA_E_DEVICE, "sweep in quanta: a second part timed out waiting for its reverse sweep / first part");
+    }
     if (b->mt_checked || b->chain_blocks.n == 0) return NRA_OK;
     int32_t failed = 0;
     HIP_TRY(hipMemcpy(&failed, b->mt_words.p, 4, hipMemcpyDeviceToHost));

@@ -251,6 +251,23 @@ int nra_launch_sweep_ring32_fwd(int R, int has_n, hipStream_t st, int n_tasks, c
                                 const int32_t* kmin, const int32_t* kmax, const uint32_t* coff,
                                 int32_t* snap, int32_t* read_a, int32_t* cand_score, uint8_t* cand_flag);
 
+// a bucket's reverse and forward sweeps as one launch of quanta taken by ticket (k_sweep_ringq): n_quanta = 3 x tasks entries
+// in qlist (kind << 30 | task; kind 0 reverse sweep, 1 forward sweep to the cut, 2 from the cut on), `arrivals` one counter per
+// task and `ticket` zeroed before the launch, `giveup` the launch-wide give-up word, qstate NRA_QSTATE_INTS(R) x 64 int32 per task
+#define NRA_QSTATE_INTS(R) (((4 * (R) + 2 + 3) / 4 + NRA_SWEEP_RING_MAX_M) * 4)
+int nra_launch_sweep_ringq(int R, int has_n, hipStream_t st, int n_quanta, const uint32_t* qlist, int32_t* ticket,
+                           int32_t* arrivals, int32_t* giveup, int32_t* qstate, const NraSweepTask* tasks,
+                           const NraDevRead* reads, const NraDevRegion* regions, const uint8_t* pool,
+                           const uint32_t* q2bit, const uint32_t* qnmask, NraScoreParams sp,
+                           const int32_t* kmin, const int32_t* kmax, const uint32_t* coff,
+                           int32_t* snap, int32_t* read_a, int32_t* cand_score, uint8_t* cand_flag);
+int nra_launch_sweep_ringq32(int R, int has_n, hipStream_t st, int n_quanta, const uint32_t* qlist, int32_t* ticket,
+                             int32_t* arrivals, int32_t* giveup, int32_t* qstate, const NraSweepTask* tasks,
+                             const NraDevRead* reads, const NraDevRegion* regions, const uint8_t* pool,
+                             const uint32_t* q2bit, const uint32_t* qnmask, NraScoreParams sp,
+                             const int32_t* kmin, const int32_t* kmax, const uint32_t* coff,
+                             int32_t* snap, int32_t* read_a, int32_t* cand_score, uint8_t* cand_flag);
+
 // chained LDS-ring sweeps (k_sweep_ringchain): reads of more than NRA_RING_CHAIN_MIN_ROWS rows as row blocks of
 // 64 * NRA_RING_CHAIN_R; wide = 0: two reads per wave in packed int16, 1: one read per wave in int32 cells.
 // chain_buf: n_strips strips of 10 * chain_cap int32; the launch has min(n_tasks, n_strips) waves

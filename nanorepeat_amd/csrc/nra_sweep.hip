@@ -435,36 +435,80 @@ __global__ __launch_bounds__(WAVE) void k_sweep_pk16(int n_tasks, const NraSweep
 // hand-off's LDS read one step ahead (6.5 ms); a two- or three-column skew in the reverse sweep (6.6-6.7 ms);
 // two or four waves (= tasks) per workgroup (6.1-6.3 ms, SWEEP_RING_WPB below).
 #define SWEEP_RING_D NRA_SWEEP_RING_MAX_M
+#define NRA_Q_SPIN_LIMIT (1u << 20)         // polls (~2 us each) before a waiting second part gives up: a hang guard, not a path
 
 #ifndef SWEEP_RING_WPB
 #define SWEEP_RING_WPB 1
 #endif
-template <int R, bool HAS_N, int DIR>
-__global__ __launch_bounds__(WAVE * SWEEP_RING_WPB) void k_sweep_ring(int n_tasks, const NraSweepTask* __restrict__ tasks,
-                                                     const NraDevRead* __restrict__ reads,
-                                                     const NraDevRegion* __restrict__ regions,
-                                                     const uint8_t* __restrict__ pool,
-                                                     const uint32_t* __restrict__ q2bit,
-                                                     const uint32_t* __restrict__ qnmask,
-                                                     NraScoreParams sp,
-                                                     const int32_t* __restrict__ kmin_arr,
-                                                     const int32_t* __restrict__ kmax_arr,
-                                                     const uint32_t* __restrict__ coff,
-                                                     int32_t* __restrict__ snap,
-                                                     int32_t* __restrict__ read_a,
-                                                     int32_t* __restrict__ cand_score,
-                                                     uint8_t* __restrict__ cand_flag)
+// Q (the sweep in quanta, k_sweep_ringq): 0 = the whole sweep; 1 = a forward sweep's steps up to the cut -- the last multiple
+// of 64 at or before the first unit boundary, so no boundary, no junction input, nothing of the reverse sweep is needed -- and
+// then the wave's state to `qstate` (the lane's registers and its places of the ring, lane-major 16-byte pieces); 2 = from
+// that state on.  A resumed wave is the uninterrupted sweep bit for bit (the joint prefix / tail pair works the same way).
+// (piece by piece, straight between the registers and memory: an array of the whole state in between costs the
+// merged kernel 60 registers)
+template <int R>
+__device__ __forceinline__ int qstate_get(int i, const int (&Hq)[R], const int (&Hq2)[R], const int (&E)[R], const int (&E2)[R],
+                                          int Hup_prev, int M)
+{
+    return i < R ? Hq[i] : i < 2 * R ? Hq2[i - R] : i < 3 * R ? E[i - 2 * R] : i < 4 * R ? E2[i - 3 * R] : i == 4 * R ? Hup_prev : i == 4 * R + 1 ? M : 0;
+}
+template <int R>
+__device__ __forceinline__ void qstate_store(int32_t* __restrict__ q, const int (&Hq)[R], const int (&Hq2)[R], const int (&E)[R],
+                                             const int (&E2)[R], int Hup_prev, int M, const int4* ring, int lane)
+{
+    constexpr int NR = (4 * R + 2 + 3) / 4;            // 16-byte pieces of the registers; the ring's places follow
+    int4* __restrict__ q4 = reinterpret_cast<int4*>(q + (size_t)lane * NRA_QSTATE_INTS(R));
+#pragma unroll
+    for (int i = 0; i < NR; ++i)
+        q4[i] = make_int4(qstate_get<R>(4 * i, Hq, Hq2, E, E2, Hup_prev, M), qstate_get<R>(4 * i + 1, Hq, Hq2, E, E2, Hup_prev, M),
+                          qstate_get<R>(4 * i + 2, Hq, Hq2, E, E2, Hup_prev, M), qstate_get<R>(4 * i + 3, Hq, Hq2, E, E2, Hup_prev, M));
+#pragma unroll
+    for (int sl = 0; sl < SWEEP_RING_D; ++sl) q4[NR + sl] = ring[sl * 64 + lane];
+}
+template <int R>
+__device__ __forceinline__ void qstate_load(const int32_t* __restrict__ q, int (&Hq)[R], int (&Hq2)[R], int (&E)[R], int (&E2)[R],
+                                            int& Hup_prev, int& M, int4* ring, int lane)
+{
+    constexpr int NR = (4 * R + 2 + 3) / 4;
+    const int4* __restrict__ q4 = reinterpret_cast<const int4*>(q + (size_t)lane * NRA_QSTATE_INTS(R));
+#pragma unroll
+    for (int sl = 0; sl < SWEEP_RING_D; ++sl) ring[sl * 64 + lane] = q4[NR + sl];
+#pragma unroll
+    for (int i = 0; i < NR; ++i) {
+        const int4 x = q4[i];
+        const int v[4] = {x.x, x.y, x.z, x.w};
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const int k = 4 * i + c;
+            if (k < R) Hq[k] = v[c];
+            else if (k < 2 * R) Hq2[k - R] = v[c];
+            else if (k < 3 * R) E[k - 2 * R] = v[c];
+            else if (k < 4 * R) E2[k - 3 * R] = v[c];
+            else if (k == 4 * R) Hup_prev = v[c];
+            else if (k == 4 * R + 1) M = v[c];
+        }
+    }
+}
+
+template <int R, bool HAS_N, int DIR, int Q>
+__device__ __forceinline__ void sweep_ring_body(const int task, const int lane, int4* ring, int2* racc,
+                                                const NraSweepTask* __restrict__ tasks,
+                                                const NraDevRead* __restrict__ reads,
+                                                const NraDevRegion* __restrict__ regions,
+                                                const uint8_t* __restrict__ pool,
+                                                const uint32_t* __restrict__ q2bit,
+                                                const uint32_t* __restrict__ qnmask,
+                                                NraScoreParams sp,
+                                                const int32_t* __restrict__ kmin_arr,
+                                                const int32_t* __restrict__ kmax_arr,
+                                                const uint32_t* __restrict__ coff,
+                                                int32_t* __restrict__ snap,
+                                                int32_t* __restrict__ read_a,
+                                                int32_t* __restrict__ cand_score,
+                                                uint8_t* __restrict__ cand_flag,
+                                                int32_t* __restrict__ qstate)
 {
     constexpr int SC = 2;                 // origin-bit scheme: doubled scores
-    __shared__ int4 ring_all[SWEEP_RING_WPB * SWEEP_RING_D * 64];
-    __shared__ int2 racc_all[SWEEP_RING_WPB * 64];
-    // (with one wave per block everything below is a constant: LDS addresses stay immediates)
-    const int wave_in_block = SWEEP_RING_WPB > 1 ? (int)(threadIdx.x >> 6) : 0;
-    int4* ring = ring_all + wave_in_block * SWEEP_RING_D * 64;
-    int2* racc = racc_all + wave_in_block * 64;
-    const int task = blockIdx.x * SWEEP_RING_WPB + wave_in_block;
-    if (task >= n_tasks) return;
-    const int lane = SWEEP_RING_WPB > 1 ? (int)(threadIdx.x & 63) : (int)threadIdx.x;
     const NraSweepTask tk = tasks[task];
     const bool has_b = tk.read_b >= 0;
     const int ra = tk.read_a, rb = has_b ? tk.read_b : tk.read_a;
@@ -528,8 +572,9 @@ __global__ __launch_bounds__(WAVE * SWEEP_RING_WPB) void k_sweep_ring(int n_task
         qc[i] = ca | (0x0c << 8) | (cb << 16) | (0x0c << 24);
     }
     constexpr bool PARK = R >= 28;        // the R side of the junction in AGPRs
-    int Hbo[DIR ? R : 1], Ebo[DIR ? R : 1], E2bo[DIR ? R : 1];
-    if (DIR) {
+    constexpr bool COMB = DIR == 1 && Q != 1;      // this part of the sweep meets unit boundaries
+    int Hbo[COMB ? R : 1], Ebo[COMB ? R : 1], E2bo[COMB ? R : 1];
+    if (COMB) {
         const int q1 = SC * (sp.open1 - sp.ext1), q2 = SC * (sp.open2 - sp.ext2);
 #pragma unroll
         for (int i = 0; i < R; ++i) {
@@ -567,14 +612,21 @@ __global__ __launch_bounds__(WAVE * SWEEP_RING_WPB) void k_sweep_ring(int n_task
     int feed = tbl_mis4;
     const int nsteps = ncols + 63 * skew;                   // lane 63 finishes the last column at step ncols - 1 + 63*skew
     const int wr = (lane + 1) & 63;
-    int slot = 0;                                           // step mod skew
+    // the cut of a forward sweep in quanta: the last multiple of 64 steps at or before the first boundary step
+    const int s_cut = Q ? (jfirst < 0 ? 0 : jfirst / 64 * 64) : 0;
+    int32_t* __restrict__ qs = Q ? qstate + (size_t)task * (NRA_QSTATE_INTS(R) * 64) : nullptr;
+    if (Q == 2) {
+        qstate_load<R>(qs, Hq, Hq2, E, E2, Hup_prev, M, ring, lane);
+        ring_order();
+    }
+    int slot = Q == 2 ? s_cut % skew : 0;                   // step mod skew
     // A (best alignment inside R, doubled) of the two reads: written by the reverse sweep, constant here
-    const int a_of_a = DIR ? read_a[ra] : 0, a_of_b = DIR ? read_a[rb] : 0;
+    const int a_of_a = COMB ? read_a[ra] : 0, a_of_b = COMB ? read_a[rb] : 0;
     int phase = jfirst % m;                                 // boundary steps: step mod m == phase, step >= jfirst
-    int pcnt = 0;                                           // step mod m
+    int pcnt = Q == 2 ? s_cut % m : 0;                      // step mod m
     int bidx = 0;                                           // boundary steps so far
 #pragma unroll 1
-    for (int step = 0; step < nsteps; ++step) {
+    for (int step = Q == 2 ? s_cut : 0; step < (Q == 1 ? s_cut : nsteps); ++step) {
         if ((step & 63) == 0) feed = column_table(step + skew + wr);      // lane 63 hands out column step + skew
         const int4 in = ring[slot * 64 + lane];
         const int tt = in.w;
@@ -592,7 +644,7 @@ __global__ __launch_bounds__(WAVE * SWEEP_RING_WPB) void k_sweep_ring(int n_task
 
         if constexpr (DIR == 0) {
             if (tt & FLAG_SNAPSHOT) sweep_snapshot<0, R, R>(Hq, E, E2, snap_task, lane);
-        } else {
+        } else if constexpr (COMB) {
             if (pcnt == phase && step >= jfirst) {          // every lane is on a unit boundary: wave-uniform
                 const int tS = sweep_combine<0, R, R, false, PARK>(Hq, E, E2, Hbo, Ebo, E2bo, NEG2);
                 const int2 acc = racc[lane];
@@ -637,9 +689,40 @@ __global__ __launch_bounds__(WAVE * SWEEP_RING_WPB) void k_sweep_ring(int n_task
             read_a[ra] = half_lo(M) - BIAS;
             if (has_b) read_a[rb] = half_hi(M) - BIAS;
         }
+    } else if (Q == 1) {
+        qstate_store<R>(qs, Hq, Hq2, E, E2, Hup_prev, M, ring, lane);
     } else if (n_out > 0) {
         flush(n_out);
     }
+}
+
+template <int R, bool HAS_N, int DIR>
+__global__ __launch_bounds__(WAVE * SWEEP_RING_WPB) void k_sweep_ring(int n_tasks, const NraSweepTask* __restrict__ tasks,
+                                                     const NraDevRead* __restrict__ reads,
+                                                     const NraDevRegion* __restrict__ regions,
+                                                     const uint8_t* __restrict__ pool,
+                                                     const uint32_t* __restrict__ q2bit,
+                                                     const uint32_t* __restrict__ qnmask,
+                                                     NraScoreParams sp,
+                                                     const int32_t* __restrict__ kmin_arr,
+                                                     const int32_t* __restrict__ kmax_arr,
+                                                     const uint32_t* __restrict__ coff,
+                                                     int32_t* __restrict__ snap,
+                                                     int32_t* __restrict__ read_a,
+                                                     int32_t* __restrict__ cand_score,
+                                                     uint8_t* __restrict__ cand_flag)
+{
+    __shared__ int4 ring_all[SWEEP_RING_WPB * SWEEP_RING_D * 64];
+    __shared__ int2 racc_all[SWEEP_RING_WPB * 64];
+    // (with one wave per block everything below is a constant: LDS addresses stay immediates)
+    const int wave_in_block = SWEEP_RING_WPB > 1 ? (int)(threadIdx.x >> 6) : 0;
+    int4* ring = ring_all + wave_in_block * SWEEP_RING_D * 64;
+    int2* racc = racc_all + wave_in_block * 64;
+    const int task = blockIdx.x * SWEEP_RING_WPB + wave_in_block;
+    if (task >= n_tasks) return;
+    const int lane = SWEEP_RING_WPB > 1 ? (int)(threadIdx.x & 63) : (int)threadIdx.x;
+    sweep_ring_body<R, HAS_N, DIR, 0>(task, lane, ring, racc, tasks, reads, regions, pool, q2bit, qnmask, sp, kmin_arr, kmax_arr, coff,
+                                      snap, read_a, cand_score, cand_flag, nullptr);
 }
 
 // ------------------------------------------------------------------------------------
@@ -651,28 +734,25 @@ __global__ __launch_bounds__(WAVE * SWEEP_RING_WPB) void k_sweep_ring(int n_task
 // template (same region, the union of the four reads' windows) in lock step, each with its own ring
 // (lane 31 hands out what enters lane 0, lane 63 what enters lane 32), so the overhead is paid once for four
 // reads and the pipeline is 32*skew columns deep.
-template <int R, bool HAS_N, int DIR>
-__global__ __launch_bounds__(WAVE) void k_sweep_ring32(int n_tasks, const NraSweepTask* __restrict__ tasks,
-                                                       const NraDevRead* __restrict__ reads,
-                                                       const NraDevRegion* __restrict__ regions,
-                                                       const uint8_t* __restrict__ pool,
-                                                       const uint32_t* __restrict__ q2bit,
-                                                       const uint32_t* __restrict__ qnmask,
-                                                       NraScoreParams sp,
-                                                       const int32_t* __restrict__ kmin_arr,
-                                                       const int32_t* __restrict__ kmax_arr,
-                                                       const uint32_t* __restrict__ coff,
-                                                       int32_t* __restrict__ snap,
-                                                       int32_t* __restrict__ read_a,
-                                                       int32_t* __restrict__ cand_score,
-                                                       uint8_t* __restrict__ cand_flag)
+template <int R, bool HAS_N, int DIR, int Q>          // Q: the sweep in quanta, as in sweep_ring_body
+__device__ __forceinline__ void sweep_ring32_body(const int task, const int lane, int4* ring, int2* racc,
+                                                  const NraSweepTask* __restrict__ tasks,
+                                                  const NraDevRead* __restrict__ reads,
+                                                  const NraDevRegion* __restrict__ regions,
+                                                  const uint8_t* __restrict__ pool,
+                                                  const uint32_t* __restrict__ q2bit,
+                                                  const uint32_t* __restrict__ qnmask,
+                                                  NraScoreParams sp,
+                                                  const int32_t* __restrict__ kmin_arr,
+                                                  const int32_t* __restrict__ kmax_arr,
+                                                  const uint32_t* __restrict__ coff,
+                                                  int32_t* __restrict__ snap,
+                                                  int32_t* __restrict__ read_a,
+                                                  int32_t* __restrict__ cand_score,
+                                                  uint8_t* __restrict__ cand_flag,
+                                                  int32_t* __restrict__ qstate)
 {
     constexpr int SC = 2;
-    __shared__ int4 ring[SWEEP_RING_D * 64];
-    __shared__ int2 racc[64];
-    const int task = blockIdx.x;
-    if (task >= n_tasks) return;
-    const int lane = threadIdx.x;
     const int hoff = lane & 32;                           // first lane of this lane's half
     const int hl = lane & 31;                             // lane within the half
     const NraSweepTask tk = tasks[task];
@@ -743,8 +823,9 @@ __global__ __launch_bounds__(WAVE) void k_sweep_ring32(int n_tasks, const NraSwe
         const int cb = sweep_query_sel<HAS_N>(rdb, q2bit, qnmask, gi, DIR == 0);
         qc[i] = ca | (0x0c << 8) | (cb << 16) | (0x0c << 24);
     }
-    int Hbo[DIR ? R : 1], Ebo[DIR ? R : 1], E2bo[DIR ? R : 1];
-    if (DIR) {
+    constexpr bool COMB = DIR == 1 && Q != 1;      // this part of the sweep meets unit boundaries
+    int Hbo[COMB ? R : 1], Ebo[COMB ? R : 1], E2bo[COMB ? R : 1];
+    if (COMB) {
         const int q1 = SC * (sp.open1 - sp.ext1), q2 = SC * (sp.open2 - sp.ext2);
 #pragma unroll
         for (int i = 0; i < R; ++i) {
@@ -781,13 +862,19 @@ __global__ __launch_bounds__(WAVE) void k_sweep_ring32(int n_tasks, const NraSwe
     int feed = tbl_mis4;
     const int nsteps = ncols + 31 * skew;                   // lanes 31 / 63 finish the last column at step ncols - 1 + 31*skew
     const int wr = hoff | ((hl + 1) & 31);
-    int slot = 0;
-    const int a_of_a = DIR ? read_a[ra] : 0, a_of_b = DIR ? read_a[rb] : 0;
+    const int s_cut = Q ? (jfirst < 0 ? 0 : jfirst / 64 * 64) : 0;
+    int32_t* __restrict__ qs = Q ? qstate + (size_t)task * (NRA_QSTATE_INTS(R) * 64) : nullptr;
+    if (Q == 2) {
+        qstate_load<R>(qs, Hq, Hq2, E, E2, Hup_prev, M, ring, lane);
+        ring_order();
+    }
+    int slot = Q == 2 ? s_cut % skew : 0;
+    const int a_of_a = COMB ? read_a[ra] : 0, a_of_b = COMB ? read_a[rb] : 0;
     int phase = jfirst % m;
-    int pcnt = 0;
+    int pcnt = Q == 2 ? s_cut % m : 0;
     int bidx = 0;
 #pragma unroll 1
-    for (int step = 0; step < nsteps; ++step) {
+    for (int step = Q == 2 ? s_cut : 0; step < (Q == 1 ? s_cut : nsteps); ++step) {
         // both halves sweep the same template: the column tables repeat with period 32 across the wave, and a
         // full-wave rotation keeps them so
         if ((step & 31) == 0) feed = column_table(step + skew + ((hl + 1) & 31));
@@ -805,7 +892,7 @@ __global__ __launch_bounds__(WAVE) void k_sweep_ring32(int n_tasks, const NraSwe
 
         if constexpr (DIR == 0) {
             if (tt & FLAG_SNAPSHOT) sweep_snapshot_lane<R>(Hq, E, E2, snap_task + (size_t)lane * NRA_SNAP_LANE_STRIDE(R));
-        } else {
+        } else if constexpr (COMB) {
             if (pcnt == phase && step >= jfirst) {          // every lane is on a unit boundary: wave-uniform
                 const int tS = sweep_combine<0, R, R>(Hq, E, E2, Hbo, Ebo, E2bo, NEG2);
                 const int2 acc = racc[lane];
@@ -849,9 +936,140 @@ __global__ __launch_bounds__(WAVE) void k_sweep_ring32(int n_tasks, const NraSwe
             read_a[ra] = half_lo(M) - BIAS;
             if (has_b) read_a[rb] = half_hi(M) - BIAS;
         }
+    } else if (Q == 1) {
+        qstate_store<R>(qs, Hq, Hq2, E, E2, Hup_prev, M, ring, lane);
     } else if (n_out > 0) {
         flush(n_out);
     }
+}
+
+template <int R, bool HAS_N, int DIR>
+__global__ __launch_bounds__(WAVE) void k_sweep_ring32(int n_tasks, const NraSweepTask* __restrict__ tasks,
+                                                       const NraDevRead* __restrict__ reads,
+                                                       const NraDevRegion* __restrict__ regions,
+                                                       const uint8_t* __restrict__ pool,
+                                                       const uint32_t* __restrict__ q2bit,
+                                                       const uint32_t* __restrict__ qnmask,
+                                                       NraScoreParams sp,
+                                                       const int32_t* __restrict__ kmin_arr,
+                                                       const int32_t* __restrict__ kmax_arr,
+                                                       const uint32_t* __restrict__ coff,
+                                                       int32_t* __restrict__ snap,
+                                                       int32_t* __restrict__ read_a,
+                                                       int32_t* __restrict__ cand_score,
+                                                       uint8_t* __restrict__ cand_flag)
+{
+    __shared__ int4 ring[SWEEP_RING_D * 64];
+    __shared__ int2 racc[64];
+    const int task = blockIdx.x;
+    if (task >= n_tasks) return;
+    sweep_ring32_body<R, HAS_N, DIR, 0>(task, (int)threadIdx.x, ring, racc, tasks, reads, regions, pool, q2bit, qnmask, sp, kmin_arr,
+                                        kmax_arr, coff, snap, read_a, cand_score, cand_flag, nullptr);
+}
+
+// ------------------------------------------------------------------------------------
+// k_sweep_ringq: a bucket's reverse and forward sweeps as ONE launch of quanta taken by ticket.
+//
+// Two launches per bucket (all reverse sweeps, then all forward sweeps) made kernel-length tasks: 3750 waves of 1000 - 2300
+// steps on 1024 SIMDs ended with a tail of SIMDs holding 3 or 4 of them (12 - 14 % of a config-2 step), and no forward
+// sweep could start before the last reverse sweep of its bucket was over.  Here every task is three quanta of about a
+// thousand steps -- its reverse sweep, its forward sweep up to the cut (the columns of L: no boundary, no junction input,
+// nothing of the reverse sweep needed), its forward sweep from the cut on -- and a wave takes ONE by ticket (an atomic
+// add when it starts) from a list the host orders [every reverse sweep and first part, task by task | every second part]:
+//   * a second part waits for its two producers (a counter per task, two arrivals; bounded spin with s_sleep, a launch-wide
+//     give-up word like k_sweep_ringmt's); both hold smaller tickets, so they were taken by waves that have started: running
+//     or done, whatever order the workgroups are dispatched in -- no deadlock as long as started waves stay resident;
+//   * producers publish with an agent-scope release fence before the arrival, the consumer acquires after the poll
+//     (cdna_hip_programming.md Guideline 16: plain payload, atomic flag, fences on both sides);
+//   * the cut costs no step: the dumped state is the skewed wave state, the pipeline is not drained.
+// (as real function calls -- noinline -- the three quanta cost the calling convention's register reserve: 248 at R = 15)
+template <int R, bool HAS_N, bool HALF, int DIR, int Q>
+__device__ __forceinline__ void sweep_quantum(const int task, const int lane, int4* ring, int2* racc,
+                                                        const NraSweepTask* __restrict__ tasks,
+                                                        const NraDevRead* __restrict__ reads,
+                                                        const NraDevRegion* __restrict__ regions,
+                                                        const uint8_t* __restrict__ pool,
+                                                        const uint32_t* __restrict__ q2bit,
+                                                        const uint32_t* __restrict__ qnmask,
+                                                        NraScoreParams sp,
+                                                        const int32_t* __restrict__ kmin_arr,
+                                                        const int32_t* __restrict__ kmax_arr,
+                                                        const uint32_t* __restrict__ coff,
+                                                        int32_t* __restrict__ snap,
+                                                        int32_t* __restrict__ read_a,
+                                                        int32_t* __restrict__ cand_score,
+                                                        uint8_t* __restrict__ cand_flag,
+                                                        int32_t* __restrict__ qstate)
+{
+    if (HALF) sweep_ring32_body<R, HAS_N, DIR, Q>(task, lane, ring, racc, tasks, reads, regions, pool, q2bit, qnmask, sp, kmin_arr, kmax_arr,
+                                                  coff, snap, read_a, cand_score, cand_flag, qstate);
+    else sweep_ring_body<R, HAS_N, DIR, Q>(task, lane, ring, racc, tasks, reads, regions, pool, q2bit, qnmask, sp, kmin_arr, kmax_arr, coff,
+                                           snap, read_a, cand_score, cand_flag, qstate);
+}
+
+// (waves per SIMD as the forward sweep alone: without the hint the merged body takes 226 registers at R = 15 where
+// k_sweep_ring's forward sweep takes 156; with it 168 and 26 spilled values, all of them in the second part's prologue
+// -- the R side's constants while the state is loaded --, none in a step loop)
+constexpr int ringq_waves(int R)
+{
+    const int w = 512 / (9 * R + 30);
+    return w < 1 ? 1 : (w > 8 ? 8 : w);
+}
+
+template <int R, bool HAS_N, bool HALF>
+__global__ __launch_bounds__(WAVE, ringq_waves(R)) void k_sweep_ringq(int n_quanta, const uint32_t* __restrict__ qlist, int32_t* ticket,
+                                                      int32_t* arrivals, int32_t* giveup, int32_t* __restrict__ qstate,
+                                                      const NraSweepTask* __restrict__ tasks,
+                                                      const NraDevRead* __restrict__ reads,
+                                                      const NraDevRegion* __restrict__ regions,
+                                                      const uint8_t* __restrict__ pool,
+                                                      const uint32_t* __restrict__ q2bit,
+                                                      const uint32_t* __restrict__ qnmask,
+                                                      NraScoreParams sp,
+                                                      const int32_t* __restrict__ kmin_arr,
+                                                      const int32_t* __restrict__ kmax_arr,
+                                                      const uint32_t* __restrict__ coff,
+                                                      int32_t* __restrict__ snap,
+                                                      int32_t* __restrict__ read_a,
+                                                      int32_t* __restrict__ cand_score,
+                                                      uint8_t* __restrict__ cand_flag)
+{
+    __shared__ int4 ring[SWEEP_RING_D * 64];
+    __shared__ int2 racc[64];
+    const int lane = threadIdx.x;
+    int t = 0;
+    if (lane == 0) t = __hip_atomic_fetch_add(ticket, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    t = __builtin_amdgcn_readfirstlane(t);
+    if (t >= n_quanta) return;
+    const uint32_t q = qlist[t];
+    const int kind = (int)(q >> 30), task = (int)(q & 0x3fffffffu);
+#define NRA_Q_ARGS task, lane, ring, racc, tasks, reads, regions, pool, q2bit, qnmask, sp, kmin_arr, kmax_arr, coff, snap, read_a, cand_score, cand_flag, qstate
+    if (kind < 2) {
+        if (kind == 0) sweep_quantum<R, HAS_N, HALF, 0, 0>(NRA_Q_ARGS);
+        else sweep_quantum<R, HAS_N, HALF, 1, 1>(NRA_Q_ARGS);
+        // everything this wave stored -- the R side's snapshot and A, or the wave state at the cut -- before the arrival
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        if (lane == 0) __hip_atomic_fetch_add(arrivals + task, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        return;
+    }
+    for (unsigned spins = 0;; ++spins) {
+        int v = 0;
+        if (lane == 0) v = __hip_atomic_load(arrivals + task, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (__builtin_amdgcn_readfirstlane(v) >= 2) break;
+        __builtin_amdgcn_s_sleep(64);
+        if ((spins & 15) == 15) {
+            int failed = 0;
+            if (lane == 0) failed = __hip_atomic_load(giveup, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (__builtin_amdgcn_readfirstlane(failed) != 0) return;
+            if (spins >= NRA_Q_SPIN_LIMIT) {
+                if (lane == 0) __hip_atomic_store(giveup, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                return;
+            }
+        }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    sweep_quantum<R, HAS_N, HALF, 1, 2>(NRA_Q_ARGS);
+#undef NRA_Q_ARGS
 }
 
 // ------------------------------------------------------------------------------------
@@ -1527,6 +1745,55 @@ static int launch_sweep_ring32(int R, int has_n, hipStream_t st, int n_tasks, co
 #undef ARGS
     return (int)hipGetLastError();
 }
+
+// k_sweep_ringq launchers: `half` = the half-wave kernel's buckets (two read pairs per wave, R <= NRA_RING32_MAX_R)
+#define NRA_Q_LAUNCH_ARGS n_quanta, qlist, ticket, arrivals, giveup, qstate, tasks, reads, regions, pool, q2bit, qnmask, sp, kmin, kmax, coff, snap, read_a, cand_score, cand_flag
+#if NRA_HAS_PART(25)
+extern "C" int nra_launch_sweep_ringq(int R, int has_n, hipStream_t st, int n_quanta, const uint32_t* qlist, int32_t* ticket,
+                                      int32_t* arrivals, int32_t* giveup, int32_t* qstate, const NraSweepTask* tasks,
+                                      const NraDevRead* reads, const NraDevRegion* regions, const uint8_t* pool,
+                                      const uint32_t* q2bit, const uint32_t* qnmask, NraScoreParams sp,
+                                      const int32_t* kmin, const int32_t* kmax, const uint32_t* coff,
+                                      int32_t* snap, int32_t* read_a, int32_t* cand_score, uint8_t* cand_flag)
+{
+    if (n_quanta <= 0) return 0;
+#define CASE(r)                                                                                          \
+    case r:                                                                                              \
+        if (has_n) k_sweep_ringq<r, true, false><<<n_quanta, WAVE, 0, st>>>(NRA_Q_LAUNCH_ARGS);          \
+        else k_sweep_ringq<r, false, false><<<n_quanta, WAVE, 0, st>>>(NRA_Q_LAUNCH_ARGS);               \
+        break;
+    switch (R) {
+        NRA_R_LIST(CASE)
+    default: return (int)hipErrorInvalidValue;
+    }
+#undef CASE
+    return (int)hipGetLastError();
+}
+#endif
+#if NRA_HAS_PART(26)
+extern "C" int nra_launch_sweep_ringq32(int R, int has_n, hipStream_t st, int n_quanta, const uint32_t* qlist, int32_t* ticket,
+                                        int32_t* arrivals, int32_t* giveup, int32_t* qstate, const NraSweepTask* tasks,
+                                        const NraDevRead* reads, const NraDevRegion* regions, const uint8_t* pool,
+                                        const uint32_t* q2bit, const uint32_t* qnmask, NraScoreParams sp,
+                                        const int32_t* kmin, const int32_t* kmax, const uint32_t* coff,
+                                        int32_t* snap, int32_t* read_a, int32_t* cand_score, uint8_t* cand_flag)
+{
+    if (n_quanta <= 0) return 0;
+#define CASE(r)                                                                                          \
+    case r:                                                                                              \
+        if (has_n) k_sweep_ringq<r, true, true><<<n_quanta, WAVE, 0, st>>>(NRA_Q_LAUNCH_ARGS);           \
+        else k_sweep_ringq<r, false, true><<<n_quanta, WAVE, 0, st>>>(NRA_Q_LAUNCH_ARGS);                \
+        break;
+    switch (R) {
+        CASE(1) CASE(2) CASE(3) CASE(4) CASE(5) CASE(6) CASE(7) CASE(8) CASE(9) CASE(10) CASE(11) CASE(12) CASE(13)
+        CASE(14) CASE(15) CASE(16) CASE(18) CASE(20) CASE(22) CASE(24)
+    default: return (int)hipErrorInvalidValue;
+    }
+#undef CASE
+    return (int)hipGetLastError();
+}
+#endif
+#undef NRA_Q_LAUNCH_ARGS
 
 #if NRA_HAS_PART(15)
 extern "C" int nra_launch_sweep_ring32_bwd(int R, int has_n, hipStream_t st, int n_tasks, const NraSweepTask* tasks,
