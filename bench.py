@@ -153,6 +153,7 @@ def host_cores():
 def cpu_baseline_1d(data, n_sample, seconds):
     """Times the CPU oracle (oracle/, the restatement of the reference algorithm: K independent
     optimal alignments per read) on a bounded sample of the same workload, all host cores."""
+    import numpy as np
     from oracle import oracle as O
     cores = host_cores()
     n_total = len(data["reads"])
@@ -174,9 +175,30 @@ def cpu_baseline_1d(data, n_sample, seconds):
     out = O.round3_1d(data["regions"], reads, kmin, kmax, threads=cores, **sub(n_sample))
     dt = time.perf_counter() - t0
     n_align = int((kmax.astype("int64") - kmin + 1).sum())
-    return {"value": n_align / dt, "unit": "read-alignments/s", "cores": cores, "kind": "port",
-            "sample": f"first {n_sample} reads = {n_align} alignments in {dt:.1f} s; oracle/nr_oracle.c (optimal DP, K "
-                      f"independent alignments per read, OpenMP), not minimap2"}, out
+    rec = {"value": n_align / dt, "unit": "read-alignments/s", "cores": cores, "kind": "port",
+           "sample": f"first {n_sample} reads = {n_align} alignments in {dt:.1f} s; oracle/nr_oracle.c (optimal DP, K "
+                     f"independent alignments per read, OpenMP), not minimap2"}
+    # second leg: the SAME algorithm as the HIP sweeps (junction decomposition, oracle/nr_decomp.c, scalar C + OpenMP) on a
+    # larger sample -- separates what the decomposition buys from what the hardware buys
+    try:
+        if all(len(g[0]) >= 1 and len(g[2]) >= 1 for g in data["regions"]):
+            m = min(n_total, max(n_sample, 64 * cores))
+            t0 = time.perf_counter()
+            dec = O.round3_1d_decomposed(data["regions"], data["reads"][:m], data["kmin"][:m], data["kmax"][:m], threads=cores, **sub(m))
+            t1 = time.perf_counter() - t0
+            m2 = min(n_total, max(m, int(m * (seconds / 3.0) / max(t1, 1e-3)) // cores * cores))      # ~ a third of the oracle's time
+            if m2 > m:
+                t0 = time.perf_counter()
+                dec = O.round3_1d_decomposed(data["regions"], data["reads"][:m2], data["kmin"][:m2], data["kmax"][:m2], threads=cores, **sub(m2))
+                t1, m = time.perf_counter() - t0, m2
+            na = int(np.maximum(data["kmax"][:m].astype("int64") - data["kmin"][:m] + 1, 0).sum())
+            rec.update(same_algorithm_value=na / t1, same_algorithm_reads=m,
+                       same_algorithm_matches_oracle=bool(all(np.array_equal(dec[k][:n_sample], out[k]) for k in ("best_score", "sum_k", "n_ties", "status"))),
+                       same_algorithm_what="oracle/nr_decomp.c: the junction decomposition as scalar C, OpenMP")
+            rec["_decomposed"] = (m, dec)
+    except Exception as e:
+        rec["same_algorithm_error"] = f"{type(e).__name__}: {e}"
+    return rec, out
 
 
 def live_pmc(config, kernel_substr, steps=2, timeout_s=180, extra=()):
@@ -507,6 +529,11 @@ def bench_1d(args):
             n = len(ref["sum_k"])
             same = all(np.array_equal(out[k][index][:n], ref[k]) for k in ("sum_k", "n_ties", "status", "best_score"))
             base["gpu_matches_sample"] = bool(same)
+            if "_decomposed" in base:
+                m, dec = base.pop("_decomposed")
+                base["gpu_matches_same_algorithm_sample"] = bool(all(np.array_equal(out[k][index][:m], dec[k]) for k in ("sum_k", "n_ties", "status", "best_score")))
+                if line["value_scorer_call"]:
+                    base["gpu_over_cpu_same_algorithm"] = line["value_scorer_call"] / base["same_algorithm_value"]
             if line["value_scorer_call"]:
                 base["gpu_over_cpu"] = line["value_scorer_call"] / base["value"]
             line["cpu_baseline"] = base
@@ -686,6 +713,7 @@ def sub_record(args, config):
             rec["roofline"].pop(k, None)
         if "cpu_baseline" in rec:
             rec["cpu_baseline"]["sample"] = rec["cpu_baseline"]["sample"].split(";")[0]
+            rec["cpu_baseline"].pop("same_algorithm_what", None)
         if "scorer_call" in rec:
             rec["scorer_call"].pop("what", None)
     return rec

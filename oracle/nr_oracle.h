@@ -92,6 +92,16 @@ int nro_round3_1d(const nro_region_t* regions, int32_t n_regions,
                   int32_t* best_score, int64_t* sum_k, int32_t* n_ties, uint8_t* status,
                   int32_t* cand_score, int32_t* cand_tstart, int32_t* cand_tend);
 
+/* nr_decomp.c -- NOT the oracle: the junction decomposition of the HIP sweeps as scalar C (same inputs and per-read outputs
+ * as nro_round3_1d, no per-candidate arrays; regions need a base on either side of the repeat).  bench.py times it as the
+ * CPU baseline of the SAME algorithm; the tests hold it against nro_round3_1d.  executed_cells (optional): DP cells updated. */
+int nrd_round3_1d(const nro_region_t* regions, int32_t n_regions,
+                  int32_t n_reads, const char* seqs, const int64_t* seq_off,
+                  const int32_t* read_region, const int32_t* kmin, const int32_t* kmax,
+                  const nro_scoring_t* sc,
+                  int32_t* best_score, int64_t* sum_k, int32_t* n_ties, uint8_t* status,
+                  int64_t* executed_cells);
+
 /* Mirrors nra_align_pairs. */
 int nro_align_pairs(int32_t n_seqs, const char* seqs, const int64_t* seq_off,
                     int64_t n_pairs, const int32_t* pair_query, const int32_t* pair_target,

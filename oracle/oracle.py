@@ -40,7 +40,8 @@ class JointRegion(C.Structure):
 def build(force=False):
     so = os.path.join(_HERE, "libnr_oracle.so")
     src = os.path.join(_HERE, "nr_oracle.c")
-    if force or not os.path.exists(so) or os.path.getmtime(so) < os.path.getmtime(src):
+    srcs = [src, os.path.join(_HERE, "nr_decomp.c"), os.path.join(_HERE, "nr_oracle.h")]
+    if force or not os.path.exists(so) or os.path.getmtime(so) < max(os.path.getmtime(x) for x in srcs):
         subprocess.check_call(["make", "-C", _HERE, "-B", "libnr_oracle.so"],
                               stdout=subprocess.DEVNULL)
     return so
@@ -78,6 +79,9 @@ def load():
     lib.nro_round3_1d.argtypes = [C.POINTER(Region), C.c_int32, C.c_int32, C.c_char_p, pi64, pi32,
                                   pi32, pi32, C.POINTER(Scoring), C.c_int32,
                                   pi32, pi64, pi32, p8, pi32, pi32, pi32]
+    lib.nrd_round3_1d.restype = C.c_int
+    lib.nrd_round3_1d.argtypes = [C.POINTER(Region), C.c_int32, C.c_int32, C.c_char_p, pi64, pi32, pi32, pi32,
+                                  C.POINTER(Scoring), pi32, pi64, pi32, p8, pi64]
     lib.nro_align_pairs.restype = C.c_int
     lib.nro_align_pairs.argtypes = [C.c_int32, C.c_char_p, pi64, C.c_int64, pi32, pi32,
                                     C.POINTER(Scoring), C.c_int32, pi32, pi32, pi32]
@@ -206,6 +210,31 @@ def round3_1d(regions, reads, kmin, kmax, read_region=None, sc=None, flags=0, th
                            _ptr(out["cand_tend"], C.c_int32))
     if rc != 0:
         raise ValueError("nro_round3_1d: bad argument")
+    return out
+
+
+def round3_1d_decomposed(regions, reads, kmin, kmax, read_region=None, sc=None, threads=None, **_ignored):
+    """nrd_round3_1d: the junction decomposition (the HIP sweeps' algorithm) as scalar C -- NOT the oracle.  Per-read
+    outputs like round3_1d plus `executed_cells`."""
+    lib = load()
+    if threads is not None:
+        lib.nro_set_threads(int(threads))
+    sc = _scoring(sc)
+    n = len(reads)
+    seqs, off = _pack_reads(reads)
+    kmin = np.ascontiguousarray(kmin, np.int32)
+    kmax = np.ascontiguousarray(kmax, np.int32)
+    rr = None if read_region is None else np.ascontiguousarray(read_region, np.int32)
+    regs, keep = _regions(regions)
+    out = dict(best_score=np.zeros(n, np.int32), sum_k=np.zeros(n, np.int64), n_ties=np.zeros(n, np.int32),
+               status=np.zeros(n, np.uint8))
+    cells = C.c_int64(0)
+    rc = lib.nrd_round3_1d(regs, len(regions), n, seqs, _ptr(off, C.c_int64), _ptr(rr, C.c_int32), _ptr(kmin, C.c_int32),
+                           _ptr(kmax, C.c_int32), C.byref(sc), _ptr(out["best_score"], C.c_int32), _ptr(out["sum_k"], C.c_int64),
+                           _ptr(out["n_ties"], C.c_int32), _ptr(out["status"], C.c_uint8), C.byref(cells))
+    if rc != 0:
+        raise ValueError("nrd_round3_1d: bad argument")
+    out["executed_cells"] = int(cells.value)
     return out
 
 

@@ -46,7 +46,7 @@ def test_no_cpu_fallback_in_product(capi):
         for f in files:
             if f.endswith((".py", ".cpp", ".hip", ".h")):
                 src = open(os.path.join(dirpath, f)).read()
-                for bad in ("import oracle", "from oracle", "libnr_oracle", "nr_oracle.h", "nro_"):
+                for bad in ("import oracle", "from oracle", "libnr_oracle", "nr_oracle.h", "nr_decomp", "nro_", "nrd_"):
                     assert bad not in src, (f, bad)
 
 

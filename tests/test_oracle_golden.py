@@ -307,6 +307,36 @@ def test_window_payload_equals_rescored_traceback(oracle):
     assert n > 100
 
 
+def test_cpu_decomposition_equals_the_oracle(oracle):
+    """oracle/nr_decomp.c -- the junction decomposition of the HIP sweeps as scalar C (bench.py's same-algorithm CPU
+    baseline) -- against the oracle's K independent alignments per read: exact and noisy reads (ties and ambiguous flank
+    verdicts), N bases, one-base flanks, k = 0 windows, skipped and empty reads, several min_dp_score."""
+    from nanorepeat_amd import synth
+    rng = np.random.default_rng(11)
+    statuses = set()
+    for trial in range(600):
+        unit = synth.rand_unit(rng, int(rng.integers(1, 7)))
+        L = synth.rand_seq(rng, int(rng.choice([1, 2, 5, 12, 30, 80]))); R = synth.rand_seq(rng, int(rng.choice([1, 2, 5, 12, 30, 80])))
+        reads, kmin, kmax = [], [], []
+        for _ in range(int(rng.integers(1, 5))):
+            kt = int(rng.integers(0, 16)); fl = int(rng.integers(0, len(L) + 1)); fr = int(rng.integers(0, len(R) + 1))
+            s = L[len(L) - fl:] + unit * kt + R[:fr]
+            if rng.random() < 0.6: s = synth.apply_errors(rng, s, ["hifi", "ont"][int(rng.integers(0, 2))])
+            if rng.random() < 0.1 and len(s) > 2: s = s[:len(s) // 2] + "N" + s[len(s) // 2:]
+            if rng.random() < 0.03: s = ""
+            lo, hi = max(0, kt - int(rng.integers(0, 6))), kt + int(rng.integers(0, 6))
+            if rng.random() < 0.03: lo, hi = 3, 2
+            reads.append(s); kmin.append(lo); kmax.append(hi)
+        sc = oracle.default_scoring(min_dp_score=int(rng.choice([0, 1, 10, 40])))
+        a = oracle.round3_1d([(L, unit, R)], reads, kmin, kmax, sc=sc)
+        b = oracle.round3_1d_decomposed([(L, unit, R)], reads, kmin, kmax, sc=sc)
+        for k in ("best_score", "sum_k", "n_ties", "status"):
+            assert np.array_equal(a[k], b[k]), (trial, k, L, unit, R, reads, kmin, kmax)
+        statuses |= set(a["status"].tolist())
+        assert 0 < b["executed_cells"] or all(len(r) == 0 or lo > hi for r, lo, hi in zip(reads, kmin, kmax))
+    assert statuses == {0, 1, 2, 3}
+
+
 def test_known_small_alignments(oracle):
     sc = oracle.default_scoring(min_dp_score=0)
     assert oracle.align("ACGTACGTAC", "TTTACGTACGTACGGG", sc) == (20, 3, 13)
