@@ -1,7 +1,7 @@
 """Build nanorepeat_amd/libnanorepeat_amd.so (HIP kernels + C ABI) in-tree for gfx950.
 
 hipcc cross-compiles without a GPU.  The kernel file is split into parts
-(-DNRA_PART=1..26) that compile in parallel; the shared library carries only gfx950 code.
+(-DNRA_PART=1..27) that compile in parallel; the shared library carries only gfx950 code.
 """
 import os
 import subprocess
@@ -47,7 +47,7 @@ def build_library(force=False, jobs=None, verbose=False):
         o = os.path.join(OBJ, f"nra_kernels_p{part}.o")
         objs.append(o)
         cmds.append(common + [f"-DNRA_PART={part}", "-c", os.path.join(CSRC, "nra_kernels.hip"), "-o", o])
-    for part in (5, 6, 11, 12, 13, 14, 15, 16, 18, 19, 25, 26):
+    for part in (5, 6, 11, 12, 13, 14, 15, 16, 18, 19, 25, 26, 27):
         o = os.path.join(OBJ, f"nra_sweep_p{part}.o")
         objs.append(o)
         cmds.append(common + [f"-DNRA_PART={part}", "-c", os.path.join(CSRC, "nra_sweep.hip"), "-o", o])

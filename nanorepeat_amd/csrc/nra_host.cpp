@@ -1432,6 +1432,24 @@ static int run_1d(nra_batch* b)
             HIP_TRY(hipStreamWaitEvent(q, b->fork_ev, 0));
             HIP_TRY(hipEventRecord(b->ev[ev++], q));
             int32_t* strips = bk.chain ? b->chain_sweep.p + bk.strip_off : nullptr;
+            if (bk.quanta && (b->flags & NRA_F_QUANTA_2L)) {
+                // comparison form: the same quanta as two launches, no tickets, no waiting
+                LAUNCH_TRY(nra_launch_sweep_ring2l(bk.R, b->has_n, bk.half ? 1 : 0, 0, q, bk.n_sweep, b->q_state.p + bk.q_state_off,
+                                                   b->sweep_tasks.p + bk.sweep_off, b->reads.p, b->regions.p, b->pool.p, b->q2bit.p,
+                                                   b->qnmask.p, b->sp, b->kmin.p, b->kmax.p, b->coff.p, b->snap.p, b->read_a1d.p,
+                                                   b->cand_score.p, b->cand_flag.p));
+                HIP_TRY(hipEventRecord(b->ev[ev++], q));
+                HIP_TRY(hipEventRecord(b->ev[ev++], q));
+                LAUNCH_TRY(nra_launch_sweep_ring2l(bk.R, b->has_n, bk.half ? 1 : 0, 1, q, bk.n_sweep, b->q_state.p + bk.q_state_off,
+                                                   b->sweep_tasks.p + bk.sweep_off, b->reads.p, b->regions.p, b->pool.p, b->q2bit.p,
+                                                   b->qnmask.p, b->sp, b->kmin.p, b->kmax.p, b->coff.p, b->snap.p, b->read_a1d.p,
+                                                   b->cand_score.p, b->cand_flag.p));
+                HIP_TRY(hipEventRecord(b->ev[ev++], q));
+                b->n_score_ev += 2;
+                HIP_TRY(hipEventRecord(b->bdone[i], q));
+                HIP_TRY(hipStreamWaitEvent(st, b->bdone[i], 0));
+                continue;
+            }
             if (bk.quanta) {
                 // one launch: 3 quanta a task, taken by ticket (two timing pairs like the two launches it replaces: the
                 // second one is empty)

@@ -268,6 +268,13 @@ int nra_launch_sweep_ringq32(int R, int has_n, hipStream_t st, int n_quanta, con
                              const int32_t* kmin, const int32_t* kmax, const uint32_t* coff,
                              int32_t* snap, int32_t* read_a, int32_t* cand_score, uint8_t* cand_flag);
 
+// the quanta as two launches without tickets (comparison form): phase 0 = every task's reverse sweep and first part, 1 = second parts
+int nra_launch_sweep_ring2l(int R, int has_n, int half, int phase, hipStream_t st, int n_tasks, int32_t* qstate,
+                            const NraSweepTask* tasks, const NraDevRead* reads, const NraDevRegion* regions,
+                            const uint8_t* pool, const uint32_t* q2bit, const uint32_t* qnmask, NraScoreParams sp,
+                            const int32_t* kmin, const int32_t* kmax, const uint32_t* coff,
+                            int32_t* snap, int32_t* read_a, int32_t* cand_score, uint8_t* cand_flag);
+
 // chained LDS-ring sweeps (k_sweep_ringchain): reads of more than NRA_RING_CHAIN_MIN_ROWS rows as row blocks of
 // 64 * NRA_RING_CHAIN_R; wide = 0: two reads per wave in packed int16, 1: one read per wave in int32 cells.
 // chain_buf: n_strips strips of 10 * chain_cap int32; the launch has min(n_tasks, n_strips) waves

@@ -1746,6 +1746,43 @@ static int launch_sweep_ring32(int R, int has_n, hipStream_t st, int n_tasks, co
     return (int)hipGetLastError();
 }
 
+// The same quanta as two launches without tickets or waiting (the comparison form, NRA_F_QUANTA_2L): every task's reverse
+// sweep and first part in one launch (k_sweep_ringp, 2 quanta a task, nothing to wait for, the registers of the reverse
+// sweep: 4 waves per SIMD at R = 15), every second part in the next (k_sweep_ringc) behind it on the stream.
+constexpr int ringp_waves(int R)
+{
+    const int w = 512 / (7 * R + 22);
+    return w < 1 ? 1 : (w > 8 ? 8 : w);
+}
+#define NRA_QK_PARAMS const NraSweepTask* __restrict__ tasks, const NraDevRead* __restrict__ reads,                      \
+                      const NraDevRegion* __restrict__ regions, const uint8_t* __restrict__ pool,                           \
+                      const uint32_t* __restrict__ q2bit, const uint32_t* __restrict__ qnmask, NraScoreParams sp,          \
+                      const int32_t* __restrict__ kmin_arr, const int32_t* __restrict__ kmax_arr,                          \
+                      const uint32_t* __restrict__ coff, int32_t* __restrict__ snap, int32_t* __restrict__ read_a,         \
+                      int32_t* __restrict__ cand_score, uint8_t* __restrict__ cand_flag
+template <int R, bool HAS_N, bool HALF>
+__global__ __launch_bounds__(WAVE, ringp_waves(R)) void k_sweep_ringp(int n_tasks, int32_t* __restrict__ qstate, NRA_QK_PARAMS)
+{
+    __shared__ int4 ring[SWEEP_RING_D * 64];
+    __shared__ int2 racc[64];
+    const int task = blockIdx.x >> 1, lane = threadIdx.x;
+    if (task >= n_tasks) return;
+#define NRA_Q_ARGS task, lane, ring, racc, tasks, reads, regions, pool, q2bit, qnmask, sp, kmin_arr, kmax_arr, coff, snap, read_a, cand_score, cand_flag, qstate
+    if ((blockIdx.x & 1) == 0) sweep_quantum<R, HAS_N, HALF, 0, 0>(NRA_Q_ARGS);
+    else sweep_quantum<R, HAS_N, HALF, 1, 1>(NRA_Q_ARGS);
+}
+template <int R, bool HAS_N, bool HALF>
+__global__ __launch_bounds__(WAVE, ringq_waves(R)) void k_sweep_ringc(int n_tasks, int32_t* __restrict__ qstate, NRA_QK_PARAMS)
+{
+    __shared__ int4 ring[SWEEP_RING_D * 64];
+    __shared__ int2 racc[64];
+    const int task = blockIdx.x, lane = threadIdx.x;
+    if (task >= n_tasks) return;
+    sweep_quantum<R, HAS_N, HALF, 1, 2>(NRA_Q_ARGS);
+#undef NRA_Q_ARGS
+}
+#undef NRA_QK_PARAMS
+
 // k_sweep_ringq launchers: `half` = the half-wave kernel's buckets (two read pairs per wave, R <= NRA_RING32_MAX_R)
 #define NRA_Q_LAUNCH_ARGS n_quanta, qlist, ticket, arrivals, giveup, qstate, tasks, reads, regions, pool, q2bit, qnmask, sp, kmin, kmax, coff, snap, read_a, cand_score, cand_flag
 #if NRA_HAS_PART(25)
@@ -1767,6 +1804,30 @@ extern "C" int nra_launch_sweep_ringq(int R, int has_n, hipStream_t st, int n_qu
     default: return (int)hipErrorInvalidValue;
     }
 #undef CASE
+    return (int)hipGetLastError();
+}
+#endif
+#if NRA_HAS_PART(27)
+// phase 0: producers (2 n blocks), phase 1: consumers (n blocks)
+extern "C" int nra_launch_sweep_ring2l(int R, int has_n, int half, int phase, hipStream_t st, int n_tasks, int32_t* qstate,
+                                       const NraSweepTask* tasks, const NraDevRead* reads, const NraDevRegion* regions,
+                                       const uint8_t* pool, const uint32_t* q2bit, const uint32_t* qnmask, NraScoreParams sp,
+                                       const int32_t* kmin, const int32_t* kmax, const uint32_t* coff,
+                                       int32_t* snap, int32_t* read_a, int32_t* cand_score, uint8_t* cand_flag)
+{
+    if (n_tasks <= 0) return 0;
+#define A2L n_tasks, qstate, tasks, reads, regions, pool, q2bit, qnmask, sp, kmin, kmax, coff, snap, read_a, cand_score, cand_flag
+#define CASE_H(r, H)                                                                                                  \
+        if (phase == 0) { if (has_n) k_sweep_ringp<r, true, H><<<2 * n_tasks, WAVE, 0, st>>>(A2L); else k_sweep_ringp<r, false, H><<<2 * n_tasks, WAVE, 0, st>>>(A2L); } \
+        else { if (has_n) k_sweep_ringc<r, true, H><<<n_tasks, WAVE, 0, st>>>(A2L); else k_sweep_ringc<r, false, H><<<n_tasks, WAVE, 0, st>>>(A2L); }
+#define CASE(r) case r: if (half) { if (r <= NRA_RING32_MAX_R) { CASE_H(r, true) } } else { CASE_H(r, false) } break;
+    switch (R) {
+        NRA_R_LIST(CASE)
+    default: return (int)hipErrorInvalidValue;
+    }
+#undef CASE
+#undef CASE_H
+#undef A2L
     return (int)hipGetLastError();
 }
 #endif

@@ -191,6 +191,35 @@ def test_round3_estimation_golden_end_to_end(capi, golden_1d):
         assert R3.output_repeat_size_1d(rr) == c["repeat_size_txt"]
 
 
+def test_the_three_forms_of_the_ring_sweeps_agree(capi, oracle):
+    """One launch of quanta taken by ticket (k_sweep_ringq, the default), the same quanta as two launches without tickets
+    (NRA_F_QUANTA_2L) and the reverse / forward launches of round 3 (NRA_F_NO_QUANTA): the same per-read and per-candidate
+    results, equal to the oracle on a sample -- templates whose first boundary lies before the first cut (short L, kmin 0),
+    reads of both kernels (half-wave and full-wave), N bases."""
+    rng = np.random.default_rng(33)
+    cases = [synth.config2(n_reads=600)]
+    left, right = synth.rand_seq(rng, 40), synth.rand_seq(rng, 70)                 # first boundary at column 39: no first part
+    reads = [synth.apply_errors(rng, left[-30:] + "CAG" * k + right[:50], "ont") for k in rng.integers(0, 40, size=64)]
+    reads[5] = reads[5][:20] + "N" + reads[5][20:]
+    cases.append(dict(regions=[(left, "CAG", right)], reads=reads, kmin=np.zeros(64, np.int32), kmax=np.full(64, 45, np.int32)))
+    for d in cases:
+        res = {}
+        for name, fl in (("tickets", 0), ("two launches", capi.F_QUANTA_2L), ("reverse / forward", capi.F_NO_QUANTA)):
+            with capi.Batch.create_1d(d["regions"], d["reads"], d["kmin"], d["kmax"], flags=fl) as b:
+                b.run(); b.sync()
+                res[name] = b.fetch()
+                b.run(); b.sync()
+                again = b.fetch()
+                for k in again:
+                    assert np.array_equal(again[k], res[name][k]), (name, "second run", k)
+        for name in res:
+            for k in res["tickets"]:
+                assert np.array_equal(res[name][k], res["tickets"][k]), (name, k)
+        o = oracle.round3_1d(d["regions"], d["reads"][:48], d["kmin"][:48], d["kmax"][:48])
+        for k in ("best_score", "sum_k", "n_ties", "status"):
+            assert np.array_equal(res["tickets"][k][:48], o[k]), k
+
+
 def test_regions_of_a_bed_in_one_call_equal_region_by_region(capi, oracle):
     """INTEGRATION.md's primary 1D stub: the regions a worker would take one after the other (nanoRepeat_bam.py:602-612) in
     ONE round3_estimation_regions call -- 15 regions of mixed motifs x 50 reads, reference window rule, a read without a
