@@ -701,6 +701,8 @@ def sub_record(args, config):
     try:
         rec = bench_joint(sub) if config == 3 else bench_1d(sub)
     except Exception as e:          # a sub-record must not take the headline down with it
+        if int(os.environ.get("WORLD_SIZE", "1")) > 1:
+            raise                   # (N > 1: a rank that went on alone would hang the others in their next collective)
         return {"error": f"{type(e).__name__}: {e}"}
     if rec is not None:
         rec["wall_s_of_this_record"] = round(time.perf_counter() - t0, 1)

@@ -323,8 +323,9 @@ int  nra_batch2d_sweep_flanks(nra_batch_t* b, const int8_t* read_strand);
  * and nra_stats_t.n_alignments counts the cells of both grids.  What the host saves: a fetch, a second routing and task
  * list, and the idle device between the two rounds.  NRA_E_STATE when the batch kept no column states for its current
  * grid (strands not all given, explicit cell list, NRA_F_JOINT_NO_KEEP / _TAILS / _NO_CHAIN, reads beyond 3072 bases,
- * kept states over budget) or the run was already waited for: the caller then fetches and calls nra_batch2d_set_grid
- * for the finer grid itself -- same results.  NRA_E_RANGE from the fetch if a row falls outside the kept counts. */
+ * kept states over budget), when some read's refinement could reach a count no column state was kept at (other buffers or
+ * bounds than the grid's; a grid that itself ran from the states an earlier grid kept), or when the run was already waited
+ * for: the caller then fetches and calls nra_batch2d_set_grid for the finer grid itself -- same results. */
 int  nra_batch2d_refine(nra_batch_t* b, int32_t buf1, int32_t buf2,
                         const double* lo1, const double* hi1, const double* lo2, const double* hi2);
 int  nra_batch_run(nra_batch_t* b);      /* enqueue every kernel of the path; returns at once */

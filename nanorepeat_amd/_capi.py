@@ -458,7 +458,7 @@ class Batch:
         st = None if read_strand is None else np.ascontiguousarray(read_strand, np.int8)
         _check(load().nra_batch2d_set_cells(self._h, _ptr(st, C.c_int8), len(cr), _ptr(cr, C.c_int32),
                                             _ptr(k1, C.c_int32), _ptr(k2, C.c_int32)))
-        self.n_cand = len(cr)
+        self.n_cand = self._n_cells = len(cr)
 
     def set_grid(self, grid, read_strand=None):
         """A whole routed grid round (Grid): the library lists the cells itself.  Returns the number of cells."""
@@ -467,7 +467,7 @@ class Batch:
         st = None if read_strand is None else np.ascontiguousarray(read_strand, np.int8)
         n = C.c_int64(0)
         _check(load().nra_batch2d_set_grid(self._h, _ptr(st, C.c_int8), *grid.c_args(), C.byref(n)))
-        self.n_cand = int(n.value)
+        self.n_cand = self._n_cells = int(n.value)
         return self.n_cand
 
     def sweep_flanks(self, read_strand):
@@ -496,6 +496,8 @@ class Batch:
 
     def run(self):
         _check(load().nra_batch_run(self._h))
+        if self.kind == 2 and getattr(self, "_n_cells", None) is not None:
+            self.n_cand = self._n_cells          # (a refinement of the previous run had its own per-cell layout)
 
     def sync(self):
         _check(load().nra_batch_sync(self._h))

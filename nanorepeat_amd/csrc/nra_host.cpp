@@ -524,6 +524,8 @@ struct nra_batch {
     // every k2) left, kept for a later grid whose cells lie inside (nra_batch2d_invalidate / other strands drop them)
     bool keep_valid = false, keep_pending = false;
     std::vector<NraGridRow> keep_rows;
+    std::vector<NraGridRow> cur_rows;           // the current routed grid's rows (nra_batch2d_refine checks what a refinement can ask for)
+    int32_t cur_step1 = 0, cur_step2 = 0;
     std::vector<int8_t> keep_strand;
     std::vector<uint64_t> keep_state_off, keep_rs_off;
     std::vector<int32_t> keep_ra_off;
@@ -552,6 +554,8 @@ struct nra_batch {
     DevBuf<NraJointTask> rf_mid_tasks;
     DevBuf<NraJointCombineTask> rf_comb_tasks;
     DevBuf<int32_t> rf_fs, rf_fb;
+    DevBuf<int32_t> rf_cell_score, rf_cell_wscore;   // the refinement's cells (the grid's own stay where they are: the grid may run again)
+    int64_t rf_n_cands = 0;
     bool refined = false, refine_read = false;  // this run carries a refinement; its counters have been read back
     int64_t refine_bad_rows = 0;
     bool cells_need_clear = true;               // 2D: some cells are written by no kernel unless found
@@ -1608,7 +1612,10 @@ int nra_batch1d_fetch(nra_batch_t* b, int32_t* best_score, int64_t* sum_k, int32
         const int rcm = check_mt(b);
         if (rcm) return rcm;
     }
-    const size_t n = (size_t)b->n_reads, nc = (size_t)b->n_cands;
+    // (after a refinement the per-cell arrays are the refinement's: (2 buf1)(2 buf2) entries a read)
+    const size_t n = (size_t)b->n_reads, nc = (size_t)(b->refined ? b->rf_n_cands : b->n_cands);
+    const int32_t* src_score = b->refined ? b->rf_cell_score.p : b->cand_score.p;
+    const int32_t* src_wscore = b->refined ? b->rf_cell_wscore.p : b->cand_tstart.p;
     if (n) {
         int rc = fetch_results(b);
         if (rc) return rc;
@@ -2559,6 +2566,8 @@ int set_cells_common(nra_batch* b, const int8_t* read_strand, int64_t n_cells, c
             HIP_TRY(b->jcomb_tasks.upload(jcomb));
         }
     }
+    b->cur_rows.clear();
+    if (grid) { b->cur_rows.assign(grid->rows, grid->rows + n_reads); b->cur_step1 = grid->step1; b->cur_step2 = grid->step2; }
     b->grid_step1 = b->grid_step2 = 0;
     if (grid) {                                        // the selector computes k1 / k2 of a cell from the read's row
         std::vector<GridRow> rows(grid->rows, grid->rows + n_reads);
@@ -2971,6 +2980,27 @@ int nra_batch2d_refine(nra_batch_t* b, int32_t buf1, int32_t buf2, const double*
                                  "given) whose column states are kept, before anything waits for that run");
     for (const Bucket& bk : b->buckets)
         if (bk.chain) return fail(NRA_E_STATE, "no refinement: reads beyond one register block are scored cell by cell");
+    // Every count a read's refinement can ask for -- within buf of a size between its first and last grid value, inside
+    // [lo, hi) -- has to be among the counts column states were kept at.  True by construction behind the grid that kept
+    // them when buf = its steps and [lo, hi) = its bounds; not necessarily behind a grid that itself ran from states an
+    // EARLIER grid kept, or with other buffers / bounds: then the caller takes the two-call path.
+    if (b->cur_rows.size() != (size_t)n_reads) return fail(NRA_E_STATE, "no refinement: the current cell list is not a routed grid");
+    for (int32_t r = 0; r < n_reads; ++r) {
+        const NraGridRow& g = b->cur_rows[(size_t)r];
+        const NraGridRow& k = b->keep_rows[(size_t)r];
+        if (g.n1 <= 0 || g.n2 <= 0 || k.n1 <= 0 || k.n2 <= 0) continue;
+        auto fits = [](int32_t first, int32_t n, int32_t step, int32_t buf, double lo, double hi, int32_t klo, int32_t kn) {
+            if (!(lo < hi)) return true;
+            const int64_t last = (int64_t)first + (int64_t)(n - 1) * step;
+            const double cl = std::ceil(lo), ch = std::ceil(hi);
+            const int64_t need_lo = std::max<int64_t>({cl < 0 ? 0 : (cl > 1e9 ? (int64_t)1e9 : (int64_t)cl), (int64_t)first - buf, 0});
+            const int64_t need_hi = std::min<int64_t>(ch > 1e9 ? (int64_t)1e9 : (int64_t)ch - 1, last + buf - 1);
+            return need_hi < need_lo || (need_lo >= klo && need_hi <= (int64_t)klo + kn - 1);
+        };
+        if (!fits(g.k1lo, g.n1, b->cur_step1, buf1, lo1[r], hi1[r], k.k1lo, k.n1) ||
+            !fits(g.k2lo, g.n2, b->cur_step2, buf2, lo2[r], hi2[r], k.k2lo, k.n2))
+            return fail(NRA_E_STATE, "no refinement: a read's refinement could ask for repeat counts no column state was kept at");
+    }
     HIP_TRY(hipSetDevice(b->device));
     ArenaScope arena_scope(&b->cell_arena);
     const int cap1 = 2 * buf1, cap2 = 2 * buf2;
@@ -3033,9 +3063,9 @@ int nra_batch2d_refine(nra_batch_t* b, int32_t buf1, int32_t buf2, const double*
     HIP_TRY(b->rf_fs.alloc((size_t)fs_total));
     HIP_TRY(b->rf_fb.alloc((size_t)fb_total));
     // the refinement's cells: read-major, `cap` entries a read (its n1 x n2 cells first, k1-major)
-    HIP_TRY(b->cand_score.alloc((size_t)(cap * n_reads)));
-    HIP_TRY(b->cand_tstart.alloc((size_t)(cap * n_reads)));
-    b->n_cands = cap * n_reads;
+    HIP_TRY(b->rf_cell_score.alloc((size_t)(cap * n_reads)));
+    HIP_TRY(b->rf_cell_wscore.alloc((size_t)(cap * n_reads)));
+    b->rf_n_cands = cap * n_reads;
     {
         const size_t need = (size_t)b->ev_next + 4 * nb + 4;
         while (b->ev.size() < need) { hipEvent_t e; HIP_TRY(g_handles.event(b->device, true, &e)); b->ev.push_back(e); }
@@ -3045,8 +3075,8 @@ int nra_batch2d_refine(nra_batch_t* b, int32_t buf1, int32_t buf2, const double*
     int ev = b->ev_next;
     const size_t nc = (size_t)std::max<int64_t>(cap * n_reads, 1);
     HIP_TRY(hipMemsetAsync(b->rf_words.p, 0, 4 * sizeof(int64_t), st));
-    HIP_TRY(hipMemsetAsync(b->cand_score.p, 0xff, nc * 4, st));
-    HIP_TRY(hipMemsetAsync(b->cand_tstart.p, 0, nc * 4, st));
+    HIP_TRY(hipMemsetAsync(b->rf_cell_score.p, 0xff, nc * 4, st));
+    HIP_TRY(hipMemsetAsync(b->rf_cell_wscore.p, 0, nc * 4, st));
     const double* bd = b->rf_bounds.p;
     LAUNCH_TRY(nra_launch_joint_refine_route(st, n_reads, b->status.p, b->n_ties.p, b->sum_k.p, b->sum_k2.p, bd, bd + n_reads,
                                              bd + 2 * (size_t)n_reads, bd + 3 * (size_t)n_reads, buf1, buf2, b->rf_keep.p,
@@ -3067,7 +3097,7 @@ int nra_batch2d_refine(nra_batch_t* b, int32_t buf1, int32_t buf2, const double*
         b->n_score_ev++;
         HIP_TRY(hipEventRecord(b->ev[ev++], qb));
         LAUNCH_TRY(nra_launch_joint_combine(qb, n_comb, b->rf_comb_tasks.p + comb_off[i], b->reads.p, b->sp, b->rf_fs.p, b->jrs.p,
-                                            b->rf_fb.p, b->jra.p, b->cand_score.p, b->cand_tstart.p, b->rf_rows.p));
+                                            b->rf_fb.p, b->jra.p, b->rf_cell_score.p, b->rf_cell_wscore.p, b->rf_rows.p));
         HIP_TRY(hipEventRecord(b->ev[ev++], qb));
         b->n_score_ev++;
         HIP_TRY(hipEventRecord(b->bdone[3 * i + 1], qb));
@@ -3075,12 +3105,11 @@ int nra_batch2d_refine(nra_batch_t* b, int32_t buf1, int32_t buf2, const double*
     }
     HIP_TRY(hipEventRecord(b->phase_ev[1], st));
     LAUNCH_TRY(nra_launch_select_2d(st, n_reads, b->rf_first.p, b->rf_cnt.p, nullptr, nullptr, b->rf_rows.p, 1, 1,
-                                    b->cand_score.p, b->cand_tstart.p, b->best_score.p, b->sum_k.p, b->sum_k2.p, b->n_ties.p,
+                                    b->rf_cell_score.p, b->rf_cell_wscore.p, b->best_score.p, b->sum_k.p, b->sum_k2.p, b->n_ties.p,
                                     b->status.p));
     HIP_TRY(hipEventRecord(b->ev[1], st));
     b->ev_next = ev;
     b->refined = true; b->refine_read = false;
-    b->grid_step1 = b->grid_step2 = 1;
     return NRA_OK;
 }
 
@@ -3097,7 +3126,10 @@ int nra_batch2d_fetch(nra_batch_t* b, int8_t* read_strand, int32_t* cell_score, 
             return fail(NRA_E_RANGE, std::to_string(b->refine_bad_rows) + " reads of the refinement ask for repeat counts outside the "
                                      "kept column states (bounds other than the grid's?)");
     }
-    const size_t n = (size_t)b->n_reads, nc = (size_t)b->n_cands;
+    // (after a refinement the per-cell arrays are the refinement's: (2 buf1)(2 buf2) entries a read)
+    const size_t n = (size_t)b->n_reads, nc = (size_t)(b->refined ? b->rf_n_cands : b->n_cands);
+    const int32_t* src_score = b->refined ? b->rf_cell_score.p : b->cand_score.p;
+    const int32_t* src_wscore = b->refined ? b->rf_cell_wscore.p : b->cand_tstart.p;
     if (n) {
         int rc = fetch_results(b);
         if (rc) return rc;
@@ -3109,8 +3141,8 @@ int nra_batch2d_fetch(nra_batch_t* b, int8_t* read_strand, int32_t* cell_score, 
         if (status) memcpy(status, staged(b, b->status), n);
     }
     if (nc) {
-        if (cell_score) HIP_TRY(hipMemcpy(cell_score, b->cand_score.p, nc * 4, hipMemcpyDeviceToHost));
-        if (cell_wscore) HIP_TRY(hipMemcpy(cell_wscore, b->cand_tstart.p, nc * 4, hipMemcpyDeviceToHost));
+        if (cell_score) HIP_TRY(hipMemcpy(cell_score, src_score, nc * 4, hipMemcpyDeviceToHost));
+        if (cell_wscore) HIP_TRY(hipMemcpy(cell_wscore, src_wscore, nc * 4, hipMemcpyDeviceToHost));
     }
     return NRA_OK;
 }

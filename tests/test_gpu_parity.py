@@ -588,6 +588,12 @@ def test_joint_refinement_routed_on_the_device(capi, oracle):
                 assert (cs[r, len(mine):] == -1).all()
             # a second refinement of the same run, or one after the run was waited for: not in this state
             assert not one.refine(s1, s2, lo1, hi1, lo2, hi2)
+            # the grid itself runs again on the same batch: its own cells and results (the refinement kept arrays of its own)
+            one.run(); one.sync()
+            rerun = one.fetch()
+            assert len(rerun["cell_score"]) == n2
+            for key in ("best_wscore", "sum_k1", "sum_k2", "n_ties", "status"):
+                assert np.array_equal(rerun[key], r2[key]), (s1, s2, "grid again", key)
             # a refinement behind a grid that itself ran from kept column states (every second value of the coarse grid: no
             # sweep, the template pool still has to reach the last kept count)
             sparse = capi.Grid((1, 2 * s1, 40 // (2 * s1)), lo1, hi1, (0, s2, 16 // s2 + 1), lo2, hi2)
