@@ -116,6 +116,10 @@ inline uint8_t encode_base(char c)
 // chunks come from / go back to a small per-device cache (HandlePool below)
 hipError_t device_chunk_get(int device, size_t bytes, char** out, size_t* got);
 void device_chunk_put(int device, char* p, size_t bytes);
+// Copies between pageable host memory and the device (defined behind HandlePool): from kStagedFrom bytes on they go
+// through a pinned buffer of the calling thread instead of straight into hipMemcpy.
+hipError_t copy_h2d(void* dst, const void* src, size_t bytes);
+hipError_t copy_d2h(void* dst, const void* src, size_t bytes);
 
 struct Arena {
     struct Chunk { char* p; size_t size, used; };
@@ -166,7 +170,7 @@ struct DevBuf {
     {
         hipError_t e = alloc(v.size());
         if (e != hipSuccess || v.empty()) return e;
-        return hipMemcpy(p, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice);
+        return copy_h2d(p, v.data(), v.size() * sizeof(T));
     }
 };
 
@@ -298,6 +302,52 @@ HandlePool g_handles;
 // process: the library does not touch it; see nanorepeat_amd.apply_recommended_env and INTEGRATION.md.)
 hipError_t device_chunk_get(int device, size_t bytes, char** out, size_t* got) { return g_handles.chunk_get(device, bytes, out, got); }
 void device_chunk_put(int device, char* p, size_t bytes) { g_handles.chunk_put(device, p, bytes); }
+
+// hipMemcpy on pageable memory of 1 MB or more pins the caller's pages for the transfer and unpins them after it
+// (the runtime's GPU_PINNED_MIN_XFER_SIZE).  With kernels of the same process running meanwhile that is not harmless on
+// this platform: measured on the joint path with >= 29 000 reads (the first task array to reach 1 MB), the device drops
+// into a state in which every running kernel takes 2-3 x as long (GPU busy 95 -> 55 %, 32 -> 60 ms per step, for
+// seconds; 5 of 9 runs against 1 of 9 with the runtime's threshold lifted -- DESIGN.md 9(2b), profiles/r04_keep_cliff*).
+// So the library never hands the runtime a large pageable buffer: it copies through a pinned stage of its own, in
+// pieces, synchronously as before.
+constexpr size_t kStagedFrom = 256u << 10, kStageBytes = 4u << 20;
+struct CopyStage {
+    void* p = nullptr;
+    size_t cap = 0;
+    ~CopyStage() { if (p) g_handles.pinned_put(p, cap); }
+    hipError_t ensure()
+    {
+        if (p) return hipSuccess;
+        return g_handles.pinned_get(kStageBytes, &p, &cap);
+    }
+};
+thread_local CopyStage g_copy_stage;
+hipError_t copy_h2d(void* dst, const void* src, size_t bytes)
+{
+    if (bytes < kStagedFrom) return hipMemcpy(dst, src, bytes, hipMemcpyHostToDevice);
+    hipError_t e = g_copy_stage.ensure();
+    if (e != hipSuccess) return e;
+    for (size_t off = 0; off < bytes; off += g_copy_stage.cap) {
+        const size_t n = std::min(g_copy_stage.cap, bytes - off);
+        memcpy(g_copy_stage.p, (const char*)src + off, n);
+        e = hipMemcpy((char*)dst + off, g_copy_stage.p, n, hipMemcpyHostToDevice);
+        if (e != hipSuccess) return e;
+    }
+    return hipSuccess;
+}
+hipError_t copy_d2h(void* dst, const void* src, size_t bytes)
+{
+    if (bytes < kStagedFrom) return hipMemcpy(dst, src, bytes, hipMemcpyDeviceToHost);
+    hipError_t e = g_copy_stage.ensure();
+    if (e != hipSuccess) return e;
+    for (size_t off = 0; off < bytes; off += g_copy_stage.cap) {
+        const size_t n = std::min(g_copy_stage.cap, bytes - off);
+        e = hipMemcpy(g_copy_stage.p, (const char*)src + off, n, hipMemcpyDeviceToHost);
+        if (e != hipSuccess) return e;
+        memcpy((char*)dst + off, g_copy_stage.p, n);
+    }
+    return hipSuccess;
+}
 
 // 2D decomposition: reads of one bucket whose wave states fit the state buffer together; the
 // prefix sweeps of a group run, then its tail sweeps, then the next group reuses the buffer.
@@ -1627,9 +1677,9 @@ int nra_batch1d_fetch(nra_batch_t* b, int32_t* best_score, int64_t* sum_k, int32
             for (size_t i = 0; i < n; ++i) if (best_score[i] < 0) best_score[i] = 0;
     }
     if (nc) {
-        if (cand_score) HIP_TRY(hipMemcpy(cand_score, b->cand_score.p, nc * 4, hipMemcpyDeviceToHost));
-        if (cand_tstart) HIP_TRY(hipMemcpy(cand_tstart, b->cand_tstart.p, nc * 4, hipMemcpyDeviceToHost));
-        if (cand_tend) HIP_TRY(hipMemcpy(cand_tend, b->cand_tend.p, nc * 4, hipMemcpyDeviceToHost));
+        if (cand_score) HIP_TRY(copy_d2h(cand_score, b->cand_score.p, nc * 4));
+        if (cand_tstart) HIP_TRY(copy_d2h(cand_tstart, b->cand_tstart.p, nc * 4));
+        if (cand_tend) HIP_TRY(copy_d2h(cand_tend, b->cand_tend.p, nc * 4));
     }
     return NRA_OK;
 }
@@ -2127,6 +2177,10 @@ int set_cells_common(nra_batch* b, const int8_t* read_strand, int64_t n_cells, c
         if (keep == 1) {
             // what the arena holds is handed out again; if it is too small it goes back BEFORE the larger chunk is asked for
             // (old and new together may not fit)
+            if (g_debug_phases)
+                fprintf(stderr, "[nra] kept column states: %.3f GB wanted, the arena holds %.3f GB in %zu chunks -> %s\n", (double)keep_bytes / 1073741824.0,
+                        (double)b->keep_arena.capacity() / 1073741824.0, b->keep_arena.chunks.size(),
+                        b->keep_arena.capacity() < keep_bytes + (2u << 20) ? "given back, asked for again" : "handed out again");
             if (b->keep_arena.capacity() < keep_bytes + (2u << 20)) b->keep_arena.release();
             else b->keep_arena.reset();
             b->keep_rows.assign(grid->keep, grid->keep + n_reads);
@@ -2676,8 +2730,8 @@ int nra_batch2d_sweep_flanks(nra_batch_t* b, const int8_t* read_strand)
     }
     if (parts.empty()) return NRA_OK;
     std::reverse(parts.begin(), parts.end());                  // the longest reads first, like the cell lists' buckets
-    HIP_TRY(hipMemcpy(b->warm_reads.p, reads.data(), reads.size() * sizeof(NraDevRead), hipMemcpyHostToDevice));
-    HIP_TRY(hipMemcpy(b->warm_tasks.p, mt.data(), mt.size() * sizeof(NraJointPairTask), hipMemcpyHostToDevice));
+    HIP_TRY(copy_h2d(b->warm_reads.p, reads.data(), reads.size() * sizeof(NraDevRead)));
+    HIP_TRY(copy_h2d(b->warm_tasks.p, mt.data(), mt.size() * sizeof(NraJointPairTask)));
     const size_t np = parts.size();
     while (b->bstreams.size() < 2 * np) { hipStream_t q; HIP_TRY(g_handles.stream(b->device, &q)); b->bstreams.push_back(q); }
     while (b->warm_ev.size() < 2 * np) { hipEvent_t e; HIP_TRY(g_handles.event(b->device, false, &e)); b->warm_ev.push_back(e); }
@@ -3141,8 +3195,8 @@ int nra_batch2d_fetch(nra_batch_t* b, int8_t* read_strand, int32_t* cell_score, 
         if (status) memcpy(status, staged(b, b->status), n);
     }
     if (nc) {
-        if (cell_score) HIP_TRY(hipMemcpy(cell_score, src_score, nc * 4, hipMemcpyDeviceToHost));
-        if (cell_wscore) HIP_TRY(hipMemcpy(cell_wscore, src_wscore, nc * 4, hipMemcpyDeviceToHost));
+        if (cell_score) HIP_TRY(copy_d2h(cell_score, src_score, nc * 4));
+        if (cell_wscore) HIP_TRY(copy_d2h(cell_wscore, src_wscore, nc * 4));
     }
     return NRA_OK;
 }
@@ -3319,9 +3373,9 @@ int nra_align_pairs(int device, int32_t n_seqs, const char* seqs, const int64_t*
                                              g.chain ? d_chain.p : nullptr, g.chain ? chain_cap : 0, g.wide ? 1 : 0));
     }
     HIP_TRY(hipDeviceSynchronize());
-    HIP_TRY(hipMemcpy(score, d_score.p, (size_t)n_pairs * 4, hipMemcpyDeviceToHost));
-    HIP_TRY(hipMemcpy(tstart, d_ts.p, (size_t)n_pairs * 4, hipMemcpyDeviceToHost));
-    HIP_TRY(hipMemcpy(tend, d_te.p, (size_t)n_pairs * 4, hipMemcpyDeviceToHost));
+    HIP_TRY(copy_d2h(score, d_score.p, (size_t)n_pairs * 4));
+    HIP_TRY(copy_d2h(tstart, d_ts.p, (size_t)n_pairs * 4));
+    HIP_TRY(copy_d2h(tend, d_te.p, (size_t)n_pairs * 4));
     return NRA_OK;
 }
 
@@ -3391,9 +3445,9 @@ int nra_align_pairs_cigar(int device, int32_t n_seqs, const char* seqs, const in
     std::vector<int32_t> fill(nt * 5), back(nt * 3);
     std::vector<uint8_t> ops((size_t)ops_bytes);
     if (nt) {
-        HIP_TRY(hipMemcpy(fill.data(), d_fill.p, nt * 5 * 4, hipMemcpyDeviceToHost));
-        HIP_TRY(hipMemcpy(back.data(), d_back.p, nt * 3 * 4, hipMemcpyDeviceToHost));
-        HIP_TRY(hipMemcpy(ops.data(), d_ops.p, (size_t)ops_bytes, hipMemcpyDeviceToHost));
+        HIP_TRY(copy_d2h(fill.data(), d_fill.p, nt * 5 * 4));
+        HIP_TRY(copy_d2h(back.data(), d_back.p, nt * 3 * 4));
+        HIP_TRY(copy_d2h(ops.data(), d_ops.p, (size_t)ops_bytes));
     }
     // per pair: extents + run-length encoded CIGAR
     std::vector<std::string> cg((size_t)n_pairs);

@@ -167,8 +167,10 @@ struct NraScoreParams {
 #define NRA_JOINT_COLSTATE(R) ((3 * (R) + 2 + 3) / 4 * 4)
 // wave states of one group of 2D prefix sweeps: at most this many int32 (16 GiB)
 #define NRA_JOINT_STATE_CAP_INTS (4ull << 30)
-#define NRA_JOINT_KEEP_BUDGET (20ull << 30)    // bytes of column states kept from one routed grid for the next (else: not kept).  Config 3's
-                                               // reads x 4: 16 GB kept, 30.1 -> 28.1 ms per step; x 6: 24 GB, 45.2 -> 42.6; x 8: 32 GB, 59.6 -> 90 ms
+#define NRA_JOINT_KEEP_BUDGET (96ull << 30)    // bytes of column states kept from one routed grid for the next (else: not kept): a third of the
+                                               // device, and never more than half of what is free.  Kept states pay at every size measured (config 3's
+                                               // reads x 12 / x 16: 33 / 45 GiB kept, 76.6 -> 64.0 / 101.8 -> 88.1 ms per run); the loss round 3 saw
+                                               // at 32 GB was the runtime pinning pageable task arrays of >= 1 MB under running kernels (copy_h2d)
 #define NRA_MAX_TLEN 65000     // int32 payload cells: tstart is 16 bits; + 64 pipeline columns
 #define NRA_MAX_TLEN_WIDE 4000000   // int64 payload cells (score << 32 | payload)
 // rows per lane of the int64 payload kernels' unchained instantiations (a rare path: three sizes suffice)

@@ -726,17 +726,22 @@ def test_joint_flank_sweeps_ahead_of_the_cell_list(capi, oracle):
             assert cells[True] >= cells[False], cells             # pairs swept ahead for a strand the list then does not use
 
 
-def test_joint_beyond_the_keep_budget_sweeps_again(capi):
-    """30 000 amplicon reads would keep 24 GB of column states, more than NRA_JOINT_KEEP_BUDGET: the batch keeps nothing,
-    round 3 sweeps again -- cell for cell what a NRA_F_JOINT_NO_KEEP batch computes and executes -- while 2000 reads of the
-    same kind do keep (fewer cells in round 3)."""
+def test_joint_beyond_the_keep_budget_sweeps_again(capi, monkeypatch):
+    """30 000 amplicon reads keep 17 GiB of column states.  With the budget set below that (NRA_JOINT_KEEP_BUDGET_GB = 16) the
+    batch keeps nothing and round 3 sweeps again -- cell for cell what a NRA_F_JOINT_NO_KEEP batch computes and executes;
+    with the built-in budget (a third of the device) they are kept, as for 2000 reads of the same kind: the same results
+    from fewer cells in round 3."""
     j = synth.make_joint(30000, seed=3)
     t1, t2 = j["truth"][:, 0].astype(np.float64), j["truth"][:, 1].astype(np.float64)
     strands = j["strand"].astype(np.int8)
     coarse = capi.Grid((0, 4, 25), t1 - 20, t1 + 13, (0, 3, 8), np.zeros(len(t2)), t2 + 8)       # 33 + 15..18 counts kept per read: 0.8 MB
     fine = capi.Grid((0, 1, 90), t1 - 2, t1 + 3, (0, 1, 24), np.maximum(t2 - 2, 0), t2 + 2)
-    for n, keeps in ((30000, False), (2000, True)):
+    for n, budget, keeps in ((30000, "16", False), (30000, None, True), (2000, None, True)):
         sub = lambda g: capi.Grid(g.axes[0], g.bounds[0][:n], g.bounds[1][:n], g.axes[1], g.bounds[2][:n], g.bounds[3][:n])
+        if budget is None:
+            monkeypatch.delenv("NRA_JOINT_KEEP_BUDGET_GB", raising=False)
+        else:
+            monkeypatch.setenv("NRA_JOINT_KEEP_BUDGET_GB", budget)
         got = {}
         for name, flags in (("default", 0), ("no keep", capi.F_JOINT_NO_KEEP)):
             with capi.Batch.create_2d_reads(j["region"], j["reads"][:n], flags=flags) as b:
@@ -753,6 +758,7 @@ def test_joint_beyond_the_keep_budget_sweeps_again(capi):
             assert r2_default >= r2_nokeep and r3_default < 0.5 * r3_nokeep, (n, got["default"][1][1], r3_nokeep)
         else:
             assert (r2_default, r3_default) == (r2_nokeep, r3_nokeep), n
+    monkeypatch.delenv("NRA_JOINT_KEEP_BUDGET_GB", raising=False)
 
 
 def test_joint_packed_flank_sweeps(capi, oracle):

@@ -10,7 +10,13 @@ parts = int(sys.argv[1]) if len(sys.argv) > 1 else 1
 if len(sys.argv) > 2 and sys.argv[2] == "torch":      # like bench.py: torch's HIP context first
     import torch
     torch.cuda.synchronize()
-n = 5000
+ballast = float(os.environ.get("NRA_TIMELINE_BALLAST_GB", "0"))     # device memory held but never touched by the kernels
+if ballast > 0:
+    import torch
+    hold = [torch.empty(int(min(ballast - g, 8.0) * (1 << 30)), dtype=torch.uint8, device="cuda").zero_() for g in range(0, int(ballast + 7.999), 8) if ballast - g > 0]
+    torch.cuda.synchronize()
+n = int(os.environ.get("NRA_TIMELINE_READS", "5000"))
+n_runs = int(os.environ.get("NRA_TIMELINE_RUNS", "14"))
 j = synth.config3(n)
 init = J.Round1Estimation(); fq = {}
 for i, s in enumerate(j["reads"]):
@@ -45,16 +51,19 @@ def score_grid(self, grid, read_strand, refine=None):
 
 
 J.GridSession.score_grid = score_grid
-session = J.GridSession(J._joint_region(chrom, a, b), fq, parts=parts)
+session = J.GridSession(J._joint_region(chrom, a, b), fq, parts=parts, flags=int(os.environ.get("NRA_TIMELINE_FLAGS", "0")))
 runs = []
-for it in range(14):
+stamps = []
+for it in range(n_runs):
     session.new_run()
     log.clear()
     t0 = time.perf_counter()
     J.fine_tune_read_count(init, fq, chrom, copy.copy(a), copy.copy(b), session=session)
     t1 = time.perf_counter()
     runs.append(round(1e3 * (t1 - t0), 1))
+    stamps.append(round(time.time(), 3))
 print("runs (ms):", runs)
+print("run ends (unix s):", stamps)
 print(f"parts {parts}: last run {1e3 * (t1 - t0):.2f} ms")
 for me, t in sorted(log, key=lambda x: x[1][0]):
     print(f"{me:12s} set_grid {1e3 * (t[0] - t0):7.2f} -> {1e3 * (t[1] - t0):7.2f}  run -> {1e3 * (t[2] - t0):7.2f}  "
