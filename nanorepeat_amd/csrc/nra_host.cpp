@@ -314,9 +314,24 @@ constexpr size_t kStagedFrom = 256u << 10, kStageBytes = 4u << 20;
 struct CopyStage {
     void* p = nullptr;
     size_t cap = 0;
-    ~CopyStage() { if (p) g_handles.pinned_put(p, cap); }
+    int device = -1;
+    hipStream_t q = nullptr;            // the stage's own stream: the pieces' transfers overlap the host's memcpy of the next piece
+    hipEvent_t ev[2] = {nullptr, nullptr};
+    void drop_handles()
+    {
+        if (q) g_handles.put_stream(device, q);
+        for (hipEvent_t& e : ev) if (e) { g_handles.put_event(device, false, e); e = nullptr; }
+        q = nullptr;
+    }
+    ~CopyStage() { drop_handles(); if (p) g_handles.pinned_put(p, cap); }
     hipError_t ensure()
     {
+        int dev = 0;
+        hipError_t e = hipGetDevice(&dev);
+        if (e != hipSuccess) return e;
+        if (dev != device) { drop_handles(); device = dev; }
+        if (!q && (e = g_handles.stream(device, &q)) != hipSuccess) return e;
+        for (hipEvent_t& v : ev) if (!v && (e = g_handles.event(device, false, &v)) != hipSuccess) return e;
         if (p) return hipSuccess;
         return g_handles.pinned_get(kStageBytes, &p, &cap);
     }
@@ -325,26 +340,40 @@ thread_local CopyStage g_copy_stage;
 hipError_t copy_h2d(void* dst, const void* src, size_t bytes)
 {
     if (bytes < kStagedFrom) return hipMemcpy(dst, src, bytes, hipMemcpyHostToDevice);
-    hipError_t e = g_copy_stage.ensure();
+    CopyStage& st = g_copy_stage;
+    hipError_t e = st.ensure();
     if (e != hipSuccess) return e;
-    for (size_t off = 0; off < bytes; off += g_copy_stage.cap) {
-        const size_t n = std::min(g_copy_stage.cap, bytes - off);
-        memcpy(g_copy_stage.p, (const char*)src + off, n);
-        e = hipMemcpy((char*)dst + off, g_copy_stage.p, n, hipMemcpyHostToDevice);
-        if (e != hipSuccess) return e;
+    const size_t piece = st.cap / 2;
+    size_t i = 0;
+    for (size_t off = 0; off < bytes; off += piece, ++i) {
+        const size_t n = std::min(piece, bytes - off);
+        char* half = (char*)st.p + (i & 1) * piece;
+        if (i >= 2 && (e = hipEventSynchronize(st.ev[i & 1])) != hipSuccess) return e;      // this half's last transfer is over
+        memcpy(half, (const char*)src + off, n);
+        if ((e = hipMemcpyAsync((char*)dst + off, half, n, hipMemcpyHostToDevice, st.q)) != hipSuccess) return e;
+        if ((e = hipEventRecord(st.ev[i & 1], st.q)) != hipSuccess) return e;
     }
-    return hipSuccess;
+    return hipStreamSynchronize(st.q);          // synchronous, like the hipMemcpy it stands for
 }
 hipError_t copy_d2h(void* dst, const void* src, size_t bytes)
 {
     if (bytes < kStagedFrom) return hipMemcpy(dst, src, bytes, hipMemcpyDeviceToHost);
-    hipError_t e = g_copy_stage.ensure();
+    CopyStage& st = g_copy_stage;
+    hipError_t e = st.ensure();
     if (e != hipSuccess) return e;
-    for (size_t off = 0; off < bytes; off += g_copy_stage.cap) {
-        const size_t n = std::min(g_copy_stage.cap, bytes - off);
-        e = hipMemcpy(g_copy_stage.p, (const char*)src + off, n, hipMemcpyDeviceToHost);
-        if (e != hipSuccess) return e;
-        memcpy((char*)dst + off, g_copy_stage.p, n);
+    const size_t piece = st.cap / 2;
+    const size_t n_pieces = (bytes + piece - 1) / piece;
+    auto start = [&](size_t i) -> hipError_t {
+        const size_t off = i * piece, n = std::min(piece, bytes - off);
+        hipError_t e2 = hipMemcpyAsync((char*)st.p + (i & 1) * piece, (const char*)src + off, n, hipMemcpyDeviceToHost, st.q);
+        return e2 != hipSuccess ? e2 : hipEventRecord(st.ev[i & 1], st.q);
+    };
+    if ((e = start(0)) != hipSuccess) return e;
+    for (size_t i = 0; i < n_pieces; ++i) {
+        if (i + 1 < n_pieces && (e = start(i + 1)) != hipSuccess) return e;       // the next piece travels while this one is copied out
+        if ((e = hipEventSynchronize(st.ev[i & 1])) != hipSuccess) return e;
+        const size_t off = i * piece;
+        memcpy((char*)dst + off, (const char*)st.p + (i & 1) * piece, std::min(piece, bytes - off));
     }
     return hipSuccess;
 }
