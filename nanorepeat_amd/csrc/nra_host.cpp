@@ -1714,7 +1714,7 @@ int nra_batch1d_fetch(nra_batch_t* b, int32_t* best_score, int64_t* sum_k, int32
 }
 
 // A large many-region call in region blocks: block i + 1 is packed, bucketed and uploaded (host work + H2D) while
-// the kernels of block i run, so that the host's share of the call (config 4: ~110 of ~380 ms) hides behind the
+// the kernels of block i run, so that the host's share of the call (config 4: ~90 of ~345 ms) hides behind the
 // device's.  Reads of a region stay in one block (the sweeps pair two or four reads of a region per wave); needs
 // the reads grouped by region (read_region non-decreasing), which is how the host mirror lists them.
 #define NRA_STREAM_MIN_READS 131072
@@ -1724,7 +1724,11 @@ static int round3_1d_streamed(int device, const nra_region_t* regions, int32_t n
                               int32_t* best_score, int64_t* sum_k, int32_t* n_ties, uint8_t* status,
                               int32_t* cand_score, int32_t* cand_tstart, int32_t* cand_tend)
 {
-    const int n_blocks = (int)std::min<int64_t>(16, std::max<int64_t>(2, n_reads / 65536));
+    // Up to 8 blocks of equal size.  Measured on config 4 (1 M reads, one box, ms per call): 16 blocks 350 -- every launch a
+    // sixteenth of its bucket --, 8 blocks 304-314, 4 blocks 300-312, 2 blocks 330-337 (the first block's host work is not
+    // hidden), blocks of doubling size 353-359 (the last block's device chunk is too large for the chunk cache: a
+    // hipMalloc / hipFree of several GB per call); the resident batch's step is 281.
+    const int n_blocks = (int)std::min<int64_t>(8, std::max<int64_t>(2, n_reads / 120000));
     struct Block { int32_t r0, r1, g0, g1; int64_t c0; };
     std::vector<Block> blocks;
     {
