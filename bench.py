@@ -96,7 +96,6 @@ def parse():
                     help="score K independent alignments per read (k_score_pk16) instead of the decomposition")
     ap.add_argument("--no-quanta", action="store_true",
                     help="1D, comparison: reverse and forward sweeps as two launches per bucket (NRA_F_NO_QUANTA) instead of one launch of quanta taken by ticket")
-    ap.add_argument("--quanta-2l", action="store_true", help="1D, comparison: the quanta as two launches without tickets (NRA_F_QUANTA_2L)")
     ap.add_argument("--joint-tails", action="store_true",
                     help="config 3, comparison: tail sweeps with the junction at R[0] (NRA_F_JOINT_TAILS) instead of the junction at the end of mid")
     ap.add_argument("--joint-no-chain", action="store_true",
@@ -416,7 +415,7 @@ def bench_1d(args):
 
     n_align_local = int(np.maximum(data["kmax"].astype(np.int64) - data["kmin"] + 1, 0).sum())
     sb = D.ShardedBatch1D(data["regions"], data["reads"], data["kmin"], data["kmax"], data.get("read_region"),
-                          index, n_total, flags=(A.F_BRUTE_FORCE if args.brute else 0) | (A.F_NO_QUANTA if args.no_quanta else 0) | (A.F_QUANTA_2L if args.quanta_2l else 0),
+                          index, n_total, flags=(A.F_BRUTE_FORCE if args.brute else 0) | (A.F_NO_QUANTA if args.no_quanta else 0),
                           device=local_rank)
     last = {}
 

@@ -74,8 +74,8 @@ extern "C" {
 #define NRA_F_NO_QUANTA 2048  /* testing / comparison, 1D: a bucket's reverse sweeps and forward sweeps as two launches (k_sweep_ring /
                                  k_sweep_ring32) instead of one launch of quanta taken by ticket -- reverse sweep, forward sweep up to
                                  the first unit boundary, forward sweep from there on (k_sweep_ringq) */
-#define NRA_F_QUANTA_2L 4096  /* testing / comparison, 1D: the same quanta as two launches without tickets -- every reverse sweep and
-                                 first part, then every second part -- instead of one launch (k_sweep_ringq) */
+#define NRA_F_QUANTA_2L 4096  /* accepted and ignored since the sweeps' quanta became parts of a few hundred steps (it ran the three
+                                 quanta of round 4's first form as two launches without tickets: measured no better than no quanta) */
 #define NRA_F_BRUTE_FORCE  4  /* score the K candidates of a read as K independent alignments
                                  (k_score_pk16) instead of the junction decomposition (k_sweep_pk16) */
 

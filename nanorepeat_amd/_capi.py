@@ -24,7 +24,7 @@ F_JOINT_TAILS = 256   # testing / comparison, 2D routed grids: tail sweeps (junc
 F_JOINT_NO_KEEP = 1024  # testing / comparison, 2D routed grids: a finer grid sweeps its reads again instead of using the column states kept from the coarse one
 F_JOINT_NO_CHAIN = 512  # testing / comparison, 2D routed grids: the MID part as one systolic sweep per (read, k1) instead of column-parallel scans
 F_NO_QUANTA = 2048    # testing / comparison, 1D: reverse and forward sweeps as two launches instead of one launch of quanta taken by ticket
-F_QUANTA_2L = 4096    # testing / comparison, 1D: the quanta as two launches without tickets
+F_QUANTA_2L = 4096    # accepted and ignored (round 4's first form of the quanta as two launches)
 F_SERIAL_CHAIN = 128  # testing / comparison, 1D: a long read's row blocks one after the other in one wave
 
 # every symbol include/nanorepeat_amd.h declares

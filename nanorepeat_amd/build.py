@@ -47,7 +47,7 @@ def build_library(force=False, jobs=None, verbose=False):
         o = os.path.join(OBJ, f"nra_kernels_p{part}.o")
         objs.append(o)
         cmds.append(common + [f"-DNRA_PART={part}", "-c", os.path.join(CSRC, "nra_kernels.hip"), "-o", o])
-    for part in (5, 6, 11, 12, 13, 14, 15, 16, 18, 19, 25, 26, 27):
+    for part in (5, 6, 11, 12, 13, 14, 15, 16, 18, 19, 25, 26):
         o = os.path.join(OBJ, f"nra_sweep_p{part}.o")
         objs.append(o)
         cmds.append(common + [f"-DNRA_PART={part}", "-c", os.path.join(CSRC, "nra_sweep.hip"), "-o", o])

@@ -406,7 +406,8 @@ struct Bucket {
     size_t sweep_off = 0;
     bool ring = false;         // k_sweep_ring (LDS hand-off) instead of k_sweep_pk16 (DPP hand-off)
     bool quanta = false;       // ... and its reverse and forward sweeps as ONE launch of quanta taken by ticket (k_sweep_ringq)
-    size_t q_off = 0, q_task_off = 0, q_state_off = 0;      // into q_list (3 entries a task), q_words' arrivals, q_state (int32)
+    size_t q_off = 0, q_task_off = 0, q_state_off = 0;      // into q_list, q_words' arrivals (2 a task), q_state (int32, 2 slots a task)
+    int n_quanta = 0, q_steps = 0;                            // entries of q_list; steps of a part
     int n_jbwd = 0;            // 2D decomposition: reverse sweeps (one per read)
     size_t jbwd_off = 0;
     int n_jlpk = 0, n_jrpk = 0;    // ... packed sweeps of the payload-free columns of L / rev(R) (one per pair of reads)
@@ -1393,18 +1394,56 @@ int nra_batch1d_create(int device, const nra_region_t* regions, int32_t n_region
         std::vector<uint32_t> qlist;
         size_t q_tasks = 0, q_state = 0, n_q_tasks_all = 0;
         for (const Bucket& bk : b->buckets) if (bk.ring && !bk.chain && !bk.mt) n_q_tasks_all += (size_t)bk.n_sweep;
+        // Parts of NRA_Q_STEPS = 384 steps.  Measured on one box, ms per step (config 2 | 5000 reads | 20 000 reads of it):
+        // no quanta 5.76 | 4.21 | 10.74; parts of 2048 (whole sweeps) 6.03; 1024 5.72; 768 5.32 | 3.39 | 9.93; 512 5.35 | 3.35 |
+        // 9.95; 448 5.25; 384 5.22 | 3.20 | 9.93; 320 5.33; 256 5.46 | 3.58 | 10.43; 192 5.55; 128 5.54.  With more than
+        // 8 tasks per SIMD the parts lose to two launches (40 000 reads 19.9 -> 20.2 ms, config 4 279 -> 285): the rule above.
+        // (NRA_TEST_QSTEPS overrides the part size for such measurements and for the tests.)
+        // Fewer tasks than SIMDs: a call's time is one task's chain of parts, every cut ~20 us of it (1000 reads: 1.99 -> 2.19 ms
+        // per step with parts of 384): a reverse sweep, a forward sweep to its first cut and the rest then, as in this round's
+        // first form.
+        int q_steps_wanted = n_q_tasks_all < (size_t)device_simds(device) ? NRA_Q_WHOLE : NRA_Q_STEPS;
+        if (const char* e = getenv("NRA_TEST_QSTEPS")) q_steps_wanted = std::max(64, atoi(e) / 64 * 64);
         const bool want_quanta = (flags & (NRA_F_NO_QUANTA | NRA_F_DPP_SWEEP)) == 0 && n_q_tasks_all > 0 &&
                                  n_q_tasks_all <= (size_t)8 * (size_t)device_simds(device);
         for (Bucket& bk : b->buckets) {
             if (!want_quanta || !bk.ring || bk.chain || bk.mt || bk.n_sweep <= 0) continue;
             bk.quanta = true;
             bk.q_off = qlist.size(); bk.q_task_off = q_tasks; bk.q_state_off = q_state;
-            // ticket order: every task's two producers (its reverse sweep, its forward sweep up to the cut), task by task,
-            // then every task's second part -- a consumer's producers always hold smaller tickets
-            for (int t = 0; t < bk.n_sweep; ++t) { qlist.push_back((uint32_t)t); qlist.push_back((1u << 30) | (uint32_t)t); }
-            for (int t = 0; t < bk.n_sweep; ++t) qlist.push_back((2u << 30) | (uint32_t)t);
-            q_tasks += (size_t)bk.n_sweep;
-            q_state += (size_t)bk.n_sweep * NRA_QSTATE_INTS(bk.R) * 64;
+            // Parts of `q_steps` steps (a multiple of 64; longer for sweeps that would make more than NRA_Q_MAX_PARTS of them).
+            // Ticket order: every reverse sweep's part 0, task by task, then every part 1, ..., then the forward sweeps' parts
+            // the same way -- a part's producers (the part before it; for a forward part at or behind the first boundary step
+            // the task's whole reverse sweep) always hold smaller tickets.
+            const NraSweepTask* bt = sweep_tasks.data() + bk.sweep_off;
+            int max_steps = 0;
+            std::vector<int> steps_rev((size_t)bk.n_sweep), steps_fwd((size_t)bk.n_sweep), cut_fwd((size_t)bk.n_sweep);
+            for (int t = 0; t < bk.n_sweep; ++t) {
+                const NraDevRegion& d = dregs[pr.reads[bt[t].read_a].region];
+                steps_rev[(size_t)t] = NRA_Q_STEPS_REV(d.l3, bk.half);
+                steps_fwd[(size_t)t] = NRA_Q_STEPS_FWD(d.l1, d.m1, bt[t].kmax, bk.half);
+                cut_fwd[(size_t)t] = NRA_Q_CUT(d.l1 + d.m1 * bt[t].kmin - 1);
+                max_steps = std::max(max_steps, std::max(steps_rev[(size_t)t], steps_fwd[(size_t)t]));
+            }
+            bk.q_steps = std::max(q_steps_wanted, ((max_steps + NRA_Q_MAX_PARTS - 2) / (NRA_Q_MAX_PARTS - 1) + 63) / 64 * 64);
+            for (int dir = 0; dir < 2; ++dir)
+                for (int part = 0; part < NRA_Q_MAX_PARTS; ++part) {
+                    bool any = false;
+                    for (int t = 0; t < bk.n_sweep; ++t) {
+                        // parts of this sweep: before the first cut (forward only), and from it on
+                        const int cut = dir ? cut_fwd[(size_t)t] : 0, steps = dir ? steps_fwd[(size_t)t] : steps_rev[(size_t)t];
+                        const int n_parts = (cut + bk.q_steps - 1) / bk.q_steps + std::max(1, (steps - cut + bk.q_steps - 1) / bk.q_steps);
+                        if (part < n_parts) {
+                            qlist.push_back(((uint32_t)dir << 31) | ((uint32_t)part << NRA_Q_PART_SHIFT) | (uint32_t)t);
+                            any = true;
+                        }
+                    }
+                    if (!any) break;
+                }
+            bk.n_quanta = (int)(qlist.size() - bk.q_off);
+            q_tasks += 2 * (size_t)bk.n_sweep;
+            int max_rev = 0;
+            for (int v : steps_rev) max_rev = std::max(max_rev, v);
+            q_state += (max_rev > bk.q_steps ? 2 : 1) * (size_t)bk.n_sweep * NRA_QSTATE_INTS(bk.R) * 64;
         }
         if (!qlist.empty()) {
             HIP_TRY(b->q_list.upload(qlist));
@@ -1515,29 +1554,11 @@ static int run_1d(nra_batch* b)
             HIP_TRY(hipStreamWaitEvent(q, b->fork_ev, 0));
             HIP_TRY(hipEventRecord(b->ev[ev++], q));
             int32_t* strips = bk.chain ? b->chain_sweep.p + bk.strip_off : nullptr;
-            if (bk.quanta && (b->flags & NRA_F_QUANTA_2L)) {
-                // comparison form: the same quanta as two launches, no tickets, no waiting
-                LAUNCH_TRY(nra_launch_sweep_ring2l(bk.R, b->has_n, bk.half ? 1 : 0, 0, q, bk.n_sweep, b->q_state.p + bk.q_state_off,
-                                                   b->sweep_tasks.p + bk.sweep_off, b->reads.p, b->regions.p, b->pool.p, b->q2bit.p,
-                                                   b->qnmask.p, b->sp, b->kmin.p, b->kmax.p, b->coff.p, b->snap.p, b->read_a1d.p,
-                                                   b->cand_score.p, b->cand_flag.p));
-                HIP_TRY(hipEventRecord(b->ev[ev++], q));
-                HIP_TRY(hipEventRecord(b->ev[ev++], q));
-                LAUNCH_TRY(nra_launch_sweep_ring2l(bk.R, b->has_n, bk.half ? 1 : 0, 1, q, bk.n_sweep, b->q_state.p + bk.q_state_off,
-                                                   b->sweep_tasks.p + bk.sweep_off, b->reads.p, b->regions.p, b->pool.p, b->q2bit.p,
-                                                   b->qnmask.p, b->sp, b->kmin.p, b->kmax.p, b->coff.p, b->snap.p, b->read_a1d.p,
-                                                   b->cand_score.p, b->cand_flag.p));
-                HIP_TRY(hipEventRecord(b->ev[ev++], q));
-                b->n_score_ev += 2;
-                HIP_TRY(hipEventRecord(b->bdone[i], q));
-                HIP_TRY(hipStreamWaitEvent(st, b->bdone[i], 0));
-                continue;
-            }
             if (bk.quanta) {
-                // one launch: 3 quanta a task, taken by ticket (two timing pairs like the two launches it replaces: the
+                // one launch: the sweeps' parts, taken by ticket (two timing pairs like the two launches it replaces: the
                 // second one is empty)
                 auto launch = bk.half ? nra_launch_sweep_ringq32 : nra_launch_sweep_ringq;
-                LAUNCH_TRY(launch(bk.R, b->has_n, q, 3 * bk.n_sweep, b->q_list.p + bk.q_off, b->q_words.p + 1 + i,
+                LAUNCH_TRY(launch(bk.R, b->has_n, q, bk.n_quanta, b->q_list.p + bk.q_off, bk.q_steps, bk.n_sweep, b->q_words.p + 1 + i,
                                   b->q_words.p + b->q_arrivals_off + bk.q_task_off, b->q_words.p, b->q_state.p + bk.q_state_off,
                                   b->sweep_tasks.p + bk.sweep_off, b->reads.p, b->regions.p, b->pool.p, b->q2bit.p, b->qnmask.p,
                                   b->sp, b->kmin.p, b->kmax.p, b->coff.p, b->snap.p, b->read_a1d.p, b->cand_score.p,

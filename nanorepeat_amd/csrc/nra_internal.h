@@ -253,29 +253,35 @@ int nra_launch_sweep_ring32_fwd(int R, int has_n, hipStream_t st, int n_tasks, c
                                 const int32_t* kmin, const int32_t* kmax, const uint32_t* coff,
                                 int32_t* snap, int32_t* read_a, int32_t* cand_score, uint8_t* cand_flag);
 
-// a bucket's reverse and forward sweeps as one launch of quanta taken by ticket (k_sweep_ringq): n_quanta = 3 x tasks entries
-// in qlist (kind << 30 | task; kind 0 reverse sweep, 1 forward sweep to the cut, 2 from the cut on), `arrivals` one counter per
-// task and `ticket` zeroed before the launch, `giveup` the launch-wide give-up word, qstate NRA_QSTATE_INTS(R) x 64 int32 per task
-#define NRA_QSTATE_INTS(R) (((4 * (R) + 2 + 3) / 4 + NRA_SWEEP_RING_MAX_M) * 4)
-int nra_launch_sweep_ringq(int R, int has_n, hipStream_t st, int n_quanta, const uint32_t* qlist, int32_t* ticket,
+// a bucket's reverse and forward sweeps as one launch of quanta taken by ticket (k_sweep_ringq).  A sweep is cut every
+// `qsteps` steps (a multiple of 64; a forward sweep also at NRA_Q_CUT of its first boundary step) into parts; qlist holds one entry per part, direction << 31 | part << NRA_Q_PART_SHIFT |
+// task, ordered [reverse parts 0 of every task | reverse parts 1 | ... | forward parts 0 | ...]; the host and the kernel
+// count a sweep's steps with the same macros.  `arrivals`: two counters per task (finished reverse / forward parts) and
+// `ticket`, zeroed before the launch; `giveup` the launch-wide give-up word; qstate: slots of NRA_QSTATE_INTS(R) x 64 int32
+// (the registers, the ring's places, then the pending outputs and boundary accumulators), one per forward sweep and then,
+// where a reverse sweep has more than one part, one per reverse sweep
+#define NRA_QSTATE_INTS(R) (((4 * (R) + 2 + 3) / 4 + NRA_SWEEP_RING_MAX_M + 1) * 4)
+#define NRA_Q_PART_SHIFT 27
+#define NRA_Q_PART_MASK 15u
+#define NRA_Q_TASK_MASK ((1u << NRA_Q_PART_SHIFT) - 1u)
+#define NRA_Q_MAX_PARTS 16
+#define NRA_Q_STEPS 384          // steps of a part (config 2: a reverse sweep in 3 parts, a forward sweep in 7)
+#define NRA_Q_CUT(jfirst) ((jfirst) < 0 ? 0 : (jfirst) / 64 * 64)      /* a forward sweep's first cut: before its first boundary step */
+#define NRA_Q_WHOLE (1 << 20)   // "steps of a part" of a batch too small for more cuts: a reverse sweep, a forward sweep to its first cut, the rest
+#define NRA_Q_STEPS_REV(l3, half) ((l3) + ((half) ? 31 : 63))
+#define NRA_Q_STEPS_FWD(l1, m, kmax, half) ((l1) + (m) * (kmax) + ((half) ? 31 : 63) * (m))
+int nra_launch_sweep_ringq(int R, int has_n, hipStream_t st, int n_quanta, const uint32_t* qlist, int qsteps, int n_tasks, int32_t* ticket,
                            int32_t* arrivals, int32_t* giveup, int32_t* qstate, const NraSweepTask* tasks,
                            const NraDevRead* reads, const NraDevRegion* regions, const uint8_t* pool,
                            const uint32_t* q2bit, const uint32_t* qnmask, NraScoreParams sp,
                            const int32_t* kmin, const int32_t* kmax, const uint32_t* coff,
                            int32_t* snap, int32_t* read_a, int32_t* cand_score, uint8_t* cand_flag);
-int nra_launch_sweep_ringq32(int R, int has_n, hipStream_t st, int n_quanta, const uint32_t* qlist, int32_t* ticket,
+int nra_launch_sweep_ringq32(int R, int has_n, hipStream_t st, int n_quanta, const uint32_t* qlist, int qsteps, int n_tasks, int32_t* ticket,
                              int32_t* arrivals, int32_t* giveup, int32_t* qstate, const NraSweepTask* tasks,
                              const NraDevRead* reads, const NraDevRegion* regions, const uint8_t* pool,
                              const uint32_t* q2bit, const uint32_t* qnmask, NraScoreParams sp,
                              const int32_t* kmin, const int32_t* kmax, const uint32_t* coff,
                              int32_t* snap, int32_t* read_a, int32_t* cand_score, uint8_t* cand_flag);
-
-// the quanta as two launches without tickets (comparison form): phase 0 = every task's reverse sweep and first part, 1 = second parts
-int nra_launch_sweep_ring2l(int R, int has_n, int half, int phase, hipStream_t st, int n_tasks, int32_t* qstate,
-                            const NraSweepTask* tasks, const NraDevRead* reads, const NraDevRegion* regions,
-                            const uint8_t* pool, const uint32_t* q2bit, const uint32_t* qnmask, NraScoreParams sp,
-                            const int32_t* kmin, const int32_t* kmax, const uint32_t* coff,
-                            int32_t* snap, int32_t* read_a, int32_t* cand_score, uint8_t* cand_flag);
 
 // chained LDS-ring sweeps (k_sweep_ringchain): reads of more than NRA_RING_CHAIN_MIN_ROWS rows as row blocks of
 // 64 * NRA_RING_CHAIN_R; wide = 0: two reads per wave in packed int16, 1: one read per wave in int32 cells.

@@ -440,10 +440,14 @@ __global__ __launch_bounds__(WAVE) void k_sweep_pk16(int n_tasks, const NraSweep
 #ifndef SWEEP_RING_WPB
 #define SWEEP_RING_WPB 1
 #endif
-// Q (the sweep in quanta, k_sweep_ringq): 0 = the whole sweep; 1 = a forward sweep's steps up to the cut -- the last multiple
-// of 64 at or before the first unit boundary, so no boundary, no junction input, nothing of the reverse sweep is needed -- and
-// then the wave's state to `qstate` (the lane's registers and its places of the ring, lane-major 16-byte pieces); 2 = from
-// that state on.  A resumed wave is the uninterrupted sweep bit for bit (the joint prefix / tail pair works the same way).
+// QUANTA (the sweeps in quanta, k_sweep_ringq): the body runs the steps [s_begin, s_end) of the sweep only.  `load`: it
+// starts from the wave state another wave left in `qs` -- the lane's registers, its places of the ring and of the boundary
+// accumulators, its pending outputs (lane-major 16-byte pieces) -- instead of the initial state; `store`: it leaves that state
+// instead of finishing the sweep.  Cuts are multiples of 64 steps (the column tables are reloaded every 64 / 32 steps), the
+// wave-uniform counters of the forward sweep follow from the step number, and a resumed wave is the uninterrupted sweep bit
+// for bit (the joint prefix / tail pair works the same way).  COMB: this part of a forward sweep meets unit boundaries --
+// it needs the R side's junction rows (the reverse sweep finished) and carries the combine; a part that ends before the
+// first boundary step needs neither.  Without QUANTA the arguments are constants and the body is the whole sweep.
 // (piece by piece, straight between the registers and memory: an array of the whole state in between costs the
 // merged kernel 60 registers)
 template <int R>
@@ -454,9 +458,10 @@ __device__ __forceinline__ int qstate_get(int i, const int (&Hq)[R], const int (
 }
 template <int R>
 __device__ __forceinline__ void qstate_store(int32_t* __restrict__ q, const int (&Hq)[R], const int (&Hq2)[R], const int (&E)[R],
-                                             const int (&E2)[R], int Hup_prev, int M, const int4* ring, int lane)
+                                             const int (&E2)[R], int Hup_prev, int M, const int4* ring, const int2* racc,
+                                             int out_a, int out_b, int lane)
 {
-    constexpr int NR = (4 * R + 2 + 3) / 4;            // 16-byte pieces of the registers; the ring's places follow
+    constexpr int NR = (4 * R + 2 + 3) / 4;            // 16-byte pieces of the registers; the ring's places follow, then the outputs
     int4* __restrict__ q4 = reinterpret_cast<int4*>(q + (size_t)lane * NRA_QSTATE_INTS(R));
 #pragma unroll
     for (int i = 0; i < NR; ++i)
@@ -464,15 +469,20 @@ __device__ __forceinline__ void qstate_store(int32_t* __restrict__ q, const int 
                           qstate_get<R>(4 * i + 2, Hq, Hq2, E, E2, Hup_prev, M), qstate_get<R>(4 * i + 3, Hq, Hq2, E, E2, Hup_prev, M));
 #pragma unroll
     for (int sl = 0; sl < SWEEP_RING_D; ++sl) q4[NR + sl] = ring[sl * 64 + lane];
+    const int2 acc = racc[lane];
+    q4[NR + SWEEP_RING_D] = make_int4(out_a, out_b, acc.x, acc.y);
 }
 template <int R>
 __device__ __forceinline__ void qstate_load(const int32_t* __restrict__ q, int (&Hq)[R], int (&Hq2)[R], int (&E)[R], int (&E2)[R],
-                                            int& Hup_prev, int& M, int4* ring, int lane)
+                                            int& Hup_prev, int& M, int4* ring, int2* racc, int& out_a, int& out_b, int lane)
 {
     constexpr int NR = (4 * R + 2 + 3) / 4;
     const int4* __restrict__ q4 = reinterpret_cast<const int4*>(q + (size_t)lane * NRA_QSTATE_INTS(R));
 #pragma unroll
     for (int sl = 0; sl < SWEEP_RING_D; ++sl) ring[sl * 64 + lane] = q4[NR + sl];
+    const int4 o = q4[NR + SWEEP_RING_D];
+    out_a = o.x; out_b = o.y;
+    racc[lane] = make_int2(o.z, o.w);
 #pragma unroll
     for (int i = 0; i < NR; ++i) {
         const int4 x = q4[i];
@@ -489,8 +499,22 @@ __device__ __forceinline__ void qstate_load(const int32_t* __restrict__ q, int (
         }
     }
 }
+// the forward sweep's wave-uniform counters at step s (what the loop below would have counted up to there): boundary steps
+// so far, the next repeat count lane LAG + 1 puts out, outputs waiting for their flush of W
+struct SweepCounters { int bidx, kcur, n_out; };
+__device__ __forceinline__ SweepCounters sweep_counters_at(int s, int jfirst, int m, int kmin, int kmax, int lag, int w)
+{
+    SweepCounters c;
+    c.bidx = (jfirst >= 0 && s > jfirst) ? (s - 1 - jfirst) / m + 1 : 0;
+    int outs = c.bidx - lag;
+    if (outs < 0) outs = 0;
+    if (outs > kmax - kmin + 1) outs = kmax - kmin + 1 > 0 ? kmax - kmin + 1 : 0;
+    c.kcur = kmin + outs;
+    c.n_out = outs % w;
+    return c;
+}
 
-template <int R, bool HAS_N, int DIR, int Q>
+template <int R, bool HAS_N, int DIR, bool COMB, bool QUANTA>
 __device__ __forceinline__ void sweep_ring_body(const int task, const int lane, int4* ring, int2* racc,
                                                 const NraSweepTask* __restrict__ tasks,
                                                 const NraDevRead* __restrict__ reads,
@@ -506,8 +530,10 @@ __device__ __forceinline__ void sweep_ring_body(const int task, const int lane, 
                                                 int32_t* __restrict__ read_a,
                                                 int32_t* __restrict__ cand_score,
                                                 uint8_t* __restrict__ cand_flag,
-                                                int32_t* __restrict__ qstate)
+                                                int32_t* __restrict__ qs, const int s_begin, const int s_end,
+                                                const bool load, const bool store)
 {
+    static_assert(DIR == 1 || !COMB, "only a forward sweep meets unit boundaries");
     constexpr int SC = 2;                 // origin-bit scheme: doubled scores
     const NraSweepTask tk = tasks[task];
     const bool has_b = tk.read_b >= 0;
@@ -572,7 +598,6 @@ __device__ __forceinline__ void sweep_ring_body(const int task, const int lane, 
         qc[i] = ca | (0x0c << 8) | (cb << 16) | (0x0c << 24);
     }
     constexpr bool PARK = R >= 28;        // the R side of the junction in AGPRs
-    constexpr bool COMB = DIR == 1 && Q != 1;      // this part of the sweep meets unit boundaries
     int Hbo[COMB ? R : 1], Ebo[COMB ? R : 1], E2bo[COMB ? R : 1];
     if (COMB) {
         const int q1 = SC * (sp.open1 - sp.ext1), q2 = SC * (sp.open2 - sp.ext2);
@@ -612,21 +637,21 @@ __device__ __forceinline__ void sweep_ring_body(const int task, const int lane, 
     int feed = tbl_mis4;
     const int nsteps = ncols + 63 * skew;                   // lane 63 finishes the last column at step ncols - 1 + 63*skew
     const int wr = (lane + 1) & 63;
-    // the cut of a forward sweep in quanta: the last multiple of 64 steps at or before the first boundary step
-    const int s_cut = Q ? (jfirst < 0 ? 0 : jfirst / 64 * 64) : 0;
-    int32_t* __restrict__ qs = Q ? qstate + (size_t)task * (NRA_QSTATE_INTS(R) * 64) : nullptr;
-    if (Q == 2) {
-        qstate_load<R>(qs, Hq, Hq2, E, E2, Hup_prev, M, ring, lane);
+    const int s0 = QUANTA ? s_begin : 0, s1 = QUANTA ? (s_end < nsteps ? s_end : nsteps) : nsteps;
+    if (QUANTA && load) {
+        qstate_load<R>(qs, Hq, Hq2, E, E2, Hup_prev, M, ring, racc, out_a, out_b, lane);
         ring_order();
+        const SweepCounters c = sweep_counters_at(s0, jfirst, m, tk.kmin, tk.kmax, 63, 64);
+        kcur = c.kcur; n_out = c.n_out;
     }
-    int slot = Q == 2 ? s_cut % skew : 0;                   // step mod skew
+    int slot = QUANTA ? s0 % skew : 0;                      // step mod skew
     // A (best alignment inside R, doubled) of the two reads: written by the reverse sweep, constant here
     const int a_of_a = COMB ? read_a[ra] : 0, a_of_b = COMB ? read_a[rb] : 0;
     int phase = jfirst % m;                                 // boundary steps: step mod m == phase, step >= jfirst
-    int pcnt = Q == 2 ? s_cut % m : 0;                      // step mod m
-    int bidx = 0;                                           // boundary steps so far
+    int pcnt = QUANTA ? s0 % m : 0;                         // step mod m
+    int bidx = QUANTA ? sweep_counters_at(s0, jfirst, m, tk.kmin, tk.kmax, 63, 64).bidx : 0;      // boundary steps so far
 #pragma unroll 1
-    for (int step = Q == 2 ? s_cut : 0; step < (Q == 1 ? s_cut : nsteps); ++step) {
+    for (int step = s0; step < s1; ++step) {
         if ((step & 63) == 0) feed = column_table(step + skew + wr);      // lane 63 hands out column step + skew
         const int4 in = ring[slot * 64 + lane];
         const int tt = in.w;
@@ -680,7 +705,9 @@ __device__ __forceinline__ void sweep_ring_body(const int task, const int lane, 
             if (++pcnt == m) pcnt = 0;
         }
     }
-    if (DIR == 0) {
+    if (QUANTA && store) {
+        qstate_store<R>(qs, Hq, Hq2, E, E2, Hup_prev, M, ring, racc, out_a, out_b, lane);
+    } else if (DIR == 0) {
         // the short reverse sweep ends on its one boundary, R[0]: A = best alignment inside R (doubled)
         // = the maximum over every cell of the sweep
 #pragma unroll
@@ -689,9 +716,7 @@ __device__ __forceinline__ void sweep_ring_body(const int task, const int lane, 
             read_a[ra] = half_lo(M) - BIAS;
             if (has_b) read_a[rb] = half_hi(M) - BIAS;
         }
-    } else if (Q == 1) {
-        qstate_store<R>(qs, Hq, Hq2, E, E2, Hup_prev, M, ring, lane);
-    } else if (n_out > 0) {
+    } else if (COMB && n_out > 0) {
         flush(n_out);
     }
 }
@@ -721,8 +746,8 @@ __global__ __launch_bounds__(WAVE * SWEEP_RING_WPB) void k_sweep_ring(int n_task
     const int task = blockIdx.x * SWEEP_RING_WPB + wave_in_block;
     if (task >= n_tasks) return;
     const int lane = SWEEP_RING_WPB > 1 ? (int)(threadIdx.x & 63) : (int)threadIdx.x;
-    sweep_ring_body<R, HAS_N, DIR, 0>(task, lane, ring, racc, tasks, reads, regions, pool, q2bit, qnmask, sp, kmin_arr, kmax_arr, coff,
-                                      snap, read_a, cand_score, cand_flag, nullptr);
+    sweep_ring_body<R, HAS_N, DIR, DIR == 1, false>(task, lane, ring, racc, tasks, reads, regions, pool, q2bit, qnmask, sp, kmin_arr, kmax_arr,
+                                                    coff, snap, read_a, cand_score, cand_flag, nullptr, 0, 0, false, false);
 }
 
 // ------------------------------------------------------------------------------------
@@ -734,7 +759,7 @@ __global__ __launch_bounds__(WAVE * SWEEP_RING_WPB) void k_sweep_ring(int n_task
 // template (same region, the union of the four reads' windows) in lock step, each with its own ring
 // (lane 31 hands out what enters lane 0, lane 63 what enters lane 32), so the overhead is paid once for four
 // reads and the pipeline is 32*skew columns deep.
-template <int R, bool HAS_N, int DIR, int Q>          // Q: the sweep in quanta, as in sweep_ring_body
+template <int R, bool HAS_N, int DIR, bool COMB, bool QUANTA>          // COMB, QUANTA and the last four arguments as in sweep_ring_body
 __device__ __forceinline__ void sweep_ring32_body(const int task, const int lane, int4* ring, int2* racc,
                                                   const NraSweepTask* __restrict__ tasks,
                                                   const NraDevRead* __restrict__ reads,
@@ -750,8 +775,10 @@ __device__ __forceinline__ void sweep_ring32_body(const int task, const int lane
                                                   int32_t* __restrict__ read_a,
                                                   int32_t* __restrict__ cand_score,
                                                   uint8_t* __restrict__ cand_flag,
-                                                  int32_t* __restrict__ qstate)
+                                                  int32_t* __restrict__ qs, const int s_begin, const int s_end,
+                                                  const bool load, const bool store)
 {
+    static_assert(DIR == 1 || !COMB, "only a forward sweep meets unit boundaries");
     constexpr int SC = 2;
     const int hoff = lane & 32;                           // first lane of this lane's half
     const int hl = lane & 31;                             // lane within the half
@@ -823,7 +850,6 @@ __device__ __forceinline__ void sweep_ring32_body(const int task, const int lane
         const int cb = sweep_query_sel<HAS_N>(rdb, q2bit, qnmask, gi, DIR == 0);
         qc[i] = ca | (0x0c << 8) | (cb << 16) | (0x0c << 24);
     }
-    constexpr bool COMB = DIR == 1 && Q != 1;      // this part of the sweep meets unit boundaries
     int Hbo[COMB ? R : 1], Ebo[COMB ? R : 1], E2bo[COMB ? R : 1];
     if (COMB) {
         const int q1 = SC * (sp.open1 - sp.ext1), q2 = SC * (sp.open2 - sp.ext2);
@@ -862,19 +888,20 @@ __device__ __forceinline__ void sweep_ring32_body(const int task, const int lane
     int feed = tbl_mis4;
     const int nsteps = ncols + 31 * skew;                   // lanes 31 / 63 finish the last column at step ncols - 1 + 31*skew
     const int wr = hoff | ((hl + 1) & 31);
-    const int s_cut = Q ? (jfirst < 0 ? 0 : jfirst / 64 * 64) : 0;
-    int32_t* __restrict__ qs = Q ? qstate + (size_t)task * (NRA_QSTATE_INTS(R) * 64) : nullptr;
-    if (Q == 2) {
-        qstate_load<R>(qs, Hq, Hq2, E, E2, Hup_prev, M, ring, lane);
+    const int s0 = QUANTA ? s_begin : 0, s1 = QUANTA ? (s_end < nsteps ? s_end : nsteps) : nsteps;
+    if (QUANTA && load) {
+        qstate_load<R>(qs, Hq, Hq2, E, E2, Hup_prev, M, ring, racc, out_a, out_b, lane);
         ring_order();
+        const SweepCounters c = sweep_counters_at(s0, jfirst, m, tk.kmin, tk.kmax, 31, 32);
+        kcur = c.kcur; n_out = c.n_out;
     }
-    int slot = Q == 2 ? s_cut % skew : 0;
+    int slot = QUANTA ? s0 % skew : 0;
     const int a_of_a = COMB ? read_a[ra] : 0, a_of_b = COMB ? read_a[rb] : 0;
     int phase = jfirst % m;
-    int pcnt = Q == 2 ? s_cut % m : 0;
-    int bidx = 0;
+    int pcnt = QUANTA ? s0 % m : 0;
+    int bidx = QUANTA ? sweep_counters_at(s0, jfirst, m, tk.kmin, tk.kmax, 31, 32).bidx : 0;
 #pragma unroll 1
-    for (int step = Q == 2 ? s_cut : 0; step < (Q == 1 ? s_cut : nsteps); ++step) {
+    for (int step = s0; step < s1; ++step) {
         // both halves sweep the same template: the column tables repeat with period 32 across the wave, and a
         // full-wave rotation keeps them so
         if ((step & 31) == 0) feed = column_table(step + skew + ((hl + 1) & 31));
@@ -928,7 +955,9 @@ __device__ __forceinline__ void sweep_ring32_body(const int task, const int lane
             if (++pcnt == m) pcnt = 0;
         }
     }
-    if (DIR == 0) {
+    if (QUANTA && store) {
+        qstate_store<R>(qs, Hq, Hq2, E, E2, Hup_prev, M, ring, racc, out_a, out_b, lane);
+    } else if (DIR == 0) {
         // A = best alignment inside R (doubled) = the maximum over every cell of the half's sweep
 #pragma unroll
         for (int off = 16; off > 0; off >>= 1) M = pmaxi(M, __shfl_xor(M, off, 64));
@@ -936,9 +965,7 @@ __device__ __forceinline__ void sweep_ring32_body(const int task, const int lane
             read_a[ra] = half_lo(M) - BIAS;
             if (has_b) read_a[rb] = half_hi(M) - BIAS;
         }
-    } else if (Q == 1) {
-        qstate_store<R>(qs, Hq, Hq2, E, E2, Hup_prev, M, ring, lane);
-    } else if (n_out > 0) {
+    } else if (COMB && n_out > 0) {
         flush(n_out);
     }
 }
@@ -963,8 +990,8 @@ __global__ __launch_bounds__(WAVE) void k_sweep_ring32(int n_tasks, const NraSwe
     __shared__ int2 racc[64];
     const int task = blockIdx.x;
     if (task >= n_tasks) return;
-    sweep_ring32_body<R, HAS_N, DIR, 0>(task, (int)threadIdx.x, ring, racc, tasks, reads, regions, pool, q2bit, qnmask, sp, kmin_arr,
-                                        kmax_arr, coff, snap, read_a, cand_score, cand_flag, nullptr);
+    sweep_ring32_body<R, HAS_N, DIR, DIR == 1, false>(task, (int)threadIdx.x, ring, racc, tasks, reads, regions, pool, q2bit, qnmask, sp,
+                                                      kmin_arr, kmax_arr, coff, snap, read_a, cand_score, cand_flag, nullptr, 0, 0, false, false);
 }
 
 // ------------------------------------------------------------------------------------
@@ -972,18 +999,22 @@ __global__ __launch_bounds__(WAVE) void k_sweep_ring32(int n_tasks, const NraSwe
 //
 // Two launches per bucket (all reverse sweeps, then all forward sweeps) made kernel-length tasks: 3750 waves of 1000 - 2300
 // steps on 1024 SIMDs ended with a tail of SIMDs holding 3 or 4 of them (12 - 14 % of a config-2 step), and no forward
-// sweep could start before the last reverse sweep of its bucket was over.  Here every task is three quanta of about a
-// thousand steps -- its reverse sweep, its forward sweep up to the cut (the columns of L: no boundary, no junction input,
-// nothing of the reverse sweep needed), its forward sweep from the cut on -- and a wave takes ONE by ticket (an atomic
-// add when it starts) from a list the host orders [every reverse sweep and first part, task by task | every second part]:
-//   * a second part waits for its two producers (a counter per task, two arrivals; bounded spin with s_sleep, a launch-wide
-//     give-up word like k_sweep_ringmt's); both hold smaller tickets, so they were taken by waves that have started: running
-//     or done, whatever order the workgroups are dispatched in -- no deadlock as long as started waves stay resident;
+// sweep could start before the last reverse sweep of its bucket was over.  Here a sweep is cut every `qsteps` steps (a
+// multiple of 64; the host picks it; a forward sweep also at the last multiple of 64 at or before its first boundary
+// step) into parts -- quanta of a few hundred steps -- and a wave takes ONE by ticket (an
+// atomic add when it starts) from a list the host orders [reverse parts 0 of every task | reverse parts 1 | ... | forward
+// parts 0 | forward parts 1 | ...]:
+//   * part p of a sweep waits for part p - 1 (it resumes from the state that one left), and a forward part that reaches
+//     the first boundary step also for the task's whole reverse sweep (the junction rows, A): two counters per task count
+//     the finished parts of either direction; bounded spin with s_sleep, a launch-wide give-up word like k_sweep_ringmt's.
+//     Every producer holds a smaller ticket, so it was taken by a wave that has started: running or done, whatever order
+//     the workgroups are dispatched in -- no deadlock as long as started waves stay resident;
 //   * producers publish with an agent-scope release fence before the arrival, the consumer acquires after the poll
 //     (cdna_hip_programming.md Guideline 16: plain payload, atomic flag, fences on both sides);
-//   * the cut costs no step: the dumped state is the skewed wave state, the pipeline is not drained.
-// (as real function calls -- noinline -- the three quanta cost the calling convention's register reserve: 248 at R = 15)
-template <int R, bool HAS_N, bool HALF, int DIR, int Q>
+//   * a cut costs no step: the dumped state is the skewed wave state, the pipeline is not drained.
+// A forward part that ends before the first boundary step (the columns of L) runs the plain body: no junction input, no combine.
+// (as real function calls -- noinline -- the bodies cost the calling convention's register reserve: 248 at R = 15)
+template <int R, bool HAS_N, bool HALF, int DIR, bool COMB>
 __device__ __forceinline__ void sweep_quantum(const int task, const int lane, int4* ring, int2* racc,
                                                         const NraSweepTask* __restrict__ tasks,
                                                         const NraDevRead* __restrict__ reads,
@@ -999,17 +1030,18 @@ __device__ __forceinline__ void sweep_quantum(const int task, const int lane, in
                                                         int32_t* __restrict__ read_a,
                                                         int32_t* __restrict__ cand_score,
                                                         uint8_t* __restrict__ cand_flag,
-                                                        int32_t* __restrict__ qstate)
+                                                        int32_t* __restrict__ qs, const int s_begin, const int s_end,
+                                                        const bool load, const bool store)
 {
-    if (HALF) sweep_ring32_body<R, HAS_N, DIR, Q>(task, lane, ring, racc, tasks, reads, regions, pool, q2bit, qnmask, sp, kmin_arr, kmax_arr,
-                                                  coff, snap, read_a, cand_score, cand_flag, qstate);
-    else sweep_ring_body<R, HAS_N, DIR, Q>(task, lane, ring, racc, tasks, reads, regions, pool, q2bit, qnmask, sp, kmin_arr, kmax_arr, coff,
-                                           snap, read_a, cand_score, cand_flag, qstate);
+    if (HALF) sweep_ring32_body<R, HAS_N, DIR, COMB, true>(task, lane, ring, racc, tasks, reads, regions, pool, q2bit, qnmask, sp, kmin_arr,
+                                                           kmax_arr, coff, snap, read_a, cand_score, cand_flag, qs, s_begin, s_end, load, store);
+    else sweep_ring_body<R, HAS_N, DIR, COMB, true>(task, lane, ring, racc, tasks, reads, regions, pool, q2bit, qnmask, sp, kmin_arr, kmax_arr,
+                                                    coff, snap, read_a, cand_score, cand_flag, qs, s_begin, s_end, load, store);
 }
 
 // (waves per SIMD as the forward sweep alone: without the hint the merged body takes 226 registers at R = 15 where
-// k_sweep_ring's forward sweep takes 156; with it 168 and 26 spilled values, all of them in the second part's prologue
-// -- the R side's constants while the state is loaded --, none in a step loop)
+// k_sweep_ring's forward sweep takes 156; with it 168 and a few spilled values in the prologues -- the R side's
+// constants while the state is loaded --, none in a step loop)
 constexpr int ringq_waves(int R)
 {
     const int w = 512 / (9 * R + 30);
@@ -1017,8 +1049,9 @@ constexpr int ringq_waves(int R)
 }
 
 template <int R, bool HAS_N, bool HALF>
-__global__ __launch_bounds__(WAVE, ringq_waves(R)) void k_sweep_ringq(int n_quanta, const uint32_t* __restrict__ qlist, int32_t* ticket,
-                                                      int32_t* arrivals, int32_t* giveup, int32_t* __restrict__ qstate,
+__global__ __launch_bounds__(WAVE, ringq_waves(R)) void k_sweep_ringq(int n_quanta, const uint32_t* __restrict__ qlist, int qsteps, int n_tasks,
+                                                      int32_t* ticket, int32_t* arrivals, int32_t* giveup,
+                                                      int32_t* __restrict__ qstate,
                                                       const NraSweepTask* __restrict__ tasks,
                                                       const NraDevRead* __restrict__ reads,
                                                       const NraDevRegion* __restrict__ regions,
@@ -1041,35 +1074,55 @@ __global__ __launch_bounds__(WAVE, ringq_waves(R)) void k_sweep_ringq(int n_quan
     if (lane == 0) t = __hip_atomic_fetch_add(ticket, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     t = __builtin_amdgcn_readfirstlane(t);
     if (t >= n_quanta) return;
+    // a quantum: direction << 31 | part << NRA_Q_PART_SHIFT | task (NRA_Q_* in nra_internal.h, with the step counts the host
+    // lists the parts by)
     const uint32_t q = qlist[t];
-    const int kind = (int)(q >> 30), task = (int)(q & 0x3fffffffu);
-#define NRA_Q_ARGS task, lane, ring, racc, tasks, reads, regions, pool, q2bit, qnmask, sp, kmin_arr, kmax_arr, coff, snap, read_a, cand_score, cand_flag, qstate
-    if (kind < 2) {
-        if (kind == 0) sweep_quantum<R, HAS_N, HALF, 0, 0>(NRA_Q_ARGS);
-        else sweep_quantum<R, HAS_N, HALF, 1, 1>(NRA_Q_ARGS);
-        // everything this wave stored -- the R side's snapshot and A, or the wave state at the cut -- before the arrival
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-        if (lane == 0) __hip_atomic_fetch_add(arrivals + task, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        return;
-    }
-    for (unsigned spins = 0;; ++spins) {
-        int v = 0;
-        if (lane == 0) v = __hip_atomic_load(arrivals + task, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (__builtin_amdgcn_readfirstlane(v) >= 2) break;
-        __builtin_amdgcn_s_sleep(64);
-        if ((spins & 15) == 15) {
-            int failed = 0;
-            if (lane == 0) failed = __hip_atomic_load(giveup, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if (__builtin_amdgcn_readfirstlane(failed) != 0) return;
-            if (spins >= NRA_Q_SPIN_LIMIT) {
-                if (lane == 0) __hip_atomic_store(giveup, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                return;
+    const int dir = (int)(q >> 31), part = (int)((q >> NRA_Q_PART_SHIFT) & NRA_Q_PART_MASK), task = (int)(q & NRA_Q_TASK_MASK);
+    const NraSweepTask tk = tasks[task];
+    const NraDevRegion rg = regions[reads[tk.read_a].region];
+    const int nsteps_rev = NRA_Q_STEPS_REV(rg.l3, HALF), nsteps_fwd = NRA_Q_STEPS_FWD(rg.l1, rg.m1, tk.kmax, HALF);
+    const int jfirst = rg.l1 + rg.m1 * tk.kmin - 1;                 // the first boundary step of the forward sweep
+    // a forward sweep is cut at NRA_Q_CUT(jfirst) first -- the last multiple of 64 steps at or before the first boundary
+    // step: the parts before it are plain -- and every `qsteps` steps on either side of that cut; a reverse sweep every `qsteps`
+    const int s_cut = dir ? NRA_Q_CUT(jfirst) : 0;
+    const int n_plain = (s_cut + qsteps - 1) / qsteps;
+    const bool comb = dir && part >= n_plain;
+    const int s_begin = comb ? s_cut + (part - n_plain) * qsteps : part * qsteps;
+    const int s_end = (!comb && dir && s_begin + qsteps > s_cut) ? s_cut : s_begin + qsteps;
+    const bool load = part > 0, store = s_end < (dir ? nsteps_fwd : nsteps_rev);
+    const int need_rev = comb ? (nsteps_rev + qsteps - 1) / qsteps : 0;
+    int32_t* mine = arrivals + 2 * (size_t)task + dir;
+    const int32_t* rev = arrivals + 2 * (size_t)task;
+    if (load || comb) {
+        for (unsigned spins = 0;; ++spins) {
+            int ok = 0;
+            if (lane == 0)
+                ok = (!load || __hip_atomic_load(mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= part) &&
+                     (!comb || __hip_atomic_load(rev, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= need_rev);
+            if (__builtin_amdgcn_readfirstlane(ok)) break;
+            __builtin_amdgcn_s_sleep(64);
+            if ((spins & 15) == 15) {
+                int failed = 0;
+                if (lane == 0) failed = __hip_atomic_load(giveup, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (__builtin_amdgcn_readfirstlane(failed) != 0) return;
+                if (spins >= NRA_Q_SPIN_LIMIT) {
+                    if (lane == 0) __hip_atomic_store(giveup, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    return;
+                }
             }
         }
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
     }
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-    sweep_quantum<R, HAS_N, HALF, 1, 2>(NRA_Q_ARGS);
+    // a slot per forward sweep, then -- where a reverse sweep has more than one part -- one per reverse sweep
+    int32_t* __restrict__ qs = qstate + ((size_t)(dir ? 0 : n_tasks) + (size_t)task) * (NRA_QSTATE_INTS(R) * 64);
+#define NRA_Q_ARGS task, lane, ring, racc, tasks, reads, regions, pool, q2bit, qnmask, sp, kmin_arr, kmax_arr, coff, snap, read_a, cand_score, cand_flag, qs, s_begin, s_end, load, store
+    if (!dir) sweep_quantum<R, HAS_N, HALF, 0, false>(NRA_Q_ARGS);
+    else if (!comb) sweep_quantum<R, HAS_N, HALF, 1, false>(NRA_Q_ARGS);
+    else sweep_quantum<R, HAS_N, HALF, 1, true>(NRA_Q_ARGS);
 #undef NRA_Q_ARGS
+    // everything this wave stored -- the wave state at the cut, or the R side's snapshot and A -- before the arrival
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    if (lane == 0) __hip_atomic_fetch_add(mine, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 // ------------------------------------------------------------------------------------
@@ -1746,47 +1799,10 @@ static int launch_sweep_ring32(int R, int has_n, hipStream_t st, int n_tasks, co
     return (int)hipGetLastError();
 }
 
-// The same quanta as two launches without tickets or waiting (the comparison form, NRA_F_QUANTA_2L): every task's reverse
-// sweep and first part in one launch (k_sweep_ringp, 2 quanta a task, nothing to wait for, the registers of the reverse
-// sweep: 4 waves per SIMD at R = 15), every second part in the next (k_sweep_ringc) behind it on the stream.
-constexpr int ringp_waves(int R)
-{
-    const int w = 512 / (7 * R + 22);
-    return w < 1 ? 1 : (w > 8 ? 8 : w);
-}
-#define NRA_QK_PARAMS const NraSweepTask* __restrict__ tasks, const NraDevRead* __restrict__ reads,                      \
-                      const NraDevRegion* __restrict__ regions, const uint8_t* __restrict__ pool,                           \
-                      const uint32_t* __restrict__ q2bit, const uint32_t* __restrict__ qnmask, NraScoreParams sp,          \
-                      const int32_t* __restrict__ kmin_arr, const int32_t* __restrict__ kmax_arr,                          \
-                      const uint32_t* __restrict__ coff, int32_t* __restrict__ snap, int32_t* __restrict__ read_a,         \
-                      int32_t* __restrict__ cand_score, uint8_t* __restrict__ cand_flag
-template <int R, bool HAS_N, bool HALF>
-__global__ __launch_bounds__(WAVE, ringp_waves(R)) void k_sweep_ringp(int n_tasks, int32_t* __restrict__ qstate, NRA_QK_PARAMS)
-{
-    __shared__ int4 ring[SWEEP_RING_D * 64];
-    __shared__ int2 racc[64];
-    const int task = blockIdx.x >> 1, lane = threadIdx.x;
-    if (task >= n_tasks) return;
-#define NRA_Q_ARGS task, lane, ring, racc, tasks, reads, regions, pool, q2bit, qnmask, sp, kmin_arr, kmax_arr, coff, snap, read_a, cand_score, cand_flag, qstate
-    if ((blockIdx.x & 1) == 0) sweep_quantum<R, HAS_N, HALF, 0, 0>(NRA_Q_ARGS);
-    else sweep_quantum<R, HAS_N, HALF, 1, 1>(NRA_Q_ARGS);
-}
-template <int R, bool HAS_N, bool HALF>
-__global__ __launch_bounds__(WAVE, ringq_waves(R)) void k_sweep_ringc(int n_tasks, int32_t* __restrict__ qstate, NRA_QK_PARAMS)
-{
-    __shared__ int4 ring[SWEEP_RING_D * 64];
-    __shared__ int2 racc[64];
-    const int task = blockIdx.x, lane = threadIdx.x;
-    if (task >= n_tasks) return;
-    sweep_quantum<R, HAS_N, HALF, 1, 2>(NRA_Q_ARGS);
-#undef NRA_Q_ARGS
-}
-#undef NRA_QK_PARAMS
-
 // k_sweep_ringq launchers: `half` = the half-wave kernel's buckets (two read pairs per wave, R <= NRA_RING32_MAX_R)
-#define NRA_Q_LAUNCH_ARGS n_quanta, qlist, ticket, arrivals, giveup, qstate, tasks, reads, regions, pool, q2bit, qnmask, sp, kmin, kmax, coff, snap, read_a, cand_score, cand_flag
+#define NRA_Q_LAUNCH_ARGS n_quanta, qlist, qsteps, n_tasks, ticket, arrivals, giveup, qstate, tasks, reads, regions, pool, q2bit, qnmask, sp, kmin, kmax, coff, snap, read_a, cand_score, cand_flag
 #if NRA_HAS_PART(25)
-extern "C" int nra_launch_sweep_ringq(int R, int has_n, hipStream_t st, int n_quanta, const uint32_t* qlist, int32_t* ticket,
+extern "C" int nra_launch_sweep_ringq(int R, int has_n, hipStream_t st, int n_quanta, const uint32_t* qlist, int qsteps, int n_tasks, int32_t* ticket,
                                       int32_t* arrivals, int32_t* giveup, int32_t* qstate, const NraSweepTask* tasks,
                                       const NraDevRead* reads, const NraDevRegion* regions, const uint8_t* pool,
                                       const uint32_t* q2bit, const uint32_t* qnmask, NraScoreParams sp,
@@ -1807,32 +1823,8 @@ extern "C" int nra_launch_sweep_ringq(int R, int has_n, hipStream_t st, int n_qu
     return (int)hipGetLastError();
 }
 #endif
-#if NRA_HAS_PART(27)
-// phase 0: producers (2 n blocks), phase 1: consumers (n blocks)
-extern "C" int nra_launch_sweep_ring2l(int R, int has_n, int half, int phase, hipStream_t st, int n_tasks, int32_t* qstate,
-                                       const NraSweepTask* tasks, const NraDevRead* reads, const NraDevRegion* regions,
-                                       const uint8_t* pool, const uint32_t* q2bit, const uint32_t* qnmask, NraScoreParams sp,
-                                       const int32_t* kmin, const int32_t* kmax, const uint32_t* coff,
-                                       int32_t* snap, int32_t* read_a, int32_t* cand_score, uint8_t* cand_flag)
-{
-    if (n_tasks <= 0) return 0;
-#define A2L n_tasks, qstate, tasks, reads, regions, pool, q2bit, qnmask, sp, kmin, kmax, coff, snap, read_a, cand_score, cand_flag
-#define CASE_H(r, H)                                                                                                  \
-        if (phase == 0) { if (has_n) k_sweep_ringp<r, true, H><<<2 * n_tasks, WAVE, 0, st>>>(A2L); else k_sweep_ringp<r, false, H><<<2 * n_tasks, WAVE, 0, st>>>(A2L); } \
-        else { if (has_n) k_sweep_ringc<r, true, H><<<n_tasks, WAVE, 0, st>>>(A2L); else k_sweep_ringc<r, false, H><<<n_tasks, WAVE, 0, st>>>(A2L); }
-#define CASE(r) case r: if (half) { if (r <= NRA_RING32_MAX_R) { CASE_H(r, true) } } else { CASE_H(r, false) } break;
-    switch (R) {
-        NRA_R_LIST(CASE)
-    default: return (int)hipErrorInvalidValue;
-    }
-#undef CASE
-#undef CASE_H
-#undef A2L
-    return (int)hipGetLastError();
-}
-#endif
 #if NRA_HAS_PART(26)
-extern "C" int nra_launch_sweep_ringq32(int R, int has_n, hipStream_t st, int n_quanta, const uint32_t* qlist, int32_t* ticket,
+extern "C" int nra_launch_sweep_ringq32(int R, int has_n, hipStream_t st, int n_quanta, const uint32_t* qlist, int qsteps, int n_tasks, int32_t* ticket,
                                         int32_t* arrivals, int32_t* giveup, int32_t* qstate, const NraSweepTask* tasks,
                                         const NraDevRead* reads, const NraDevRegion* regions, const uint8_t* pool,
                                         const uint32_t* q2bit, const uint32_t* qnmask, NraScoreParams sp,

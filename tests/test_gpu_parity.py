@@ -191,20 +191,26 @@ def test_round3_estimation_golden_end_to_end(capi, golden_1d):
         assert R3.output_repeat_size_1d(rr) == c["repeat_size_txt"]
 
 
-def test_the_three_forms_of_the_ring_sweeps_agree(capi, oracle):
-    """One launch of quanta taken by ticket (k_sweep_ringq, the default), the same quanta as two launches without tickets
-    (NRA_F_QUANTA_2L) and the reverse / forward launches of round 3 (NRA_F_NO_QUANTA): the same per-read and per-candidate
-    results, equal to the oracle on a sample -- templates whose first boundary lies before the first cut (short L, kmin 0),
-    reads of both kernels (half-wave and full-wave), N bases."""
+def test_the_forms_of_the_ring_sweeps_agree(capi, oracle, monkeypatch):
+    """One launch of quanta taken by ticket (k_sweep_ringq, the default: parts of 512 steps), the same with parts of 64, 128
+    and 320 -> 256 steps (NRA_TEST_QSTEPS: cuts inside the repeat, inside the snapshot steps of the reverse sweep, between
+    two flushes of the outputs, parts that hold no boundary step at all) and the reverse / forward launches of round 3
+    (NRA_F_NO_QUANTA): the same per-read and per-candidate results, equal to the oracle on a sample -- templates whose
+    first boundary lies before the first cut (short L, kmin 0), reads of both kernels (half-wave and full-wave), N bases."""
     rng = np.random.default_rng(33)
     cases = [synth.config2(n_reads=600)]
-    left, right = synth.rand_seq(rng, 40), synth.rand_seq(rng, 70)                 # first boundary at column 39: no first part
+    left, right = synth.rand_seq(rng, 40), synth.rand_seq(rng, 70)                 # first boundary at column 39: no plain part
     reads = [synth.apply_errors(rng, left[-30:] + "CAG" * k + right[:50], "ont") for k in rng.integers(0, 40, size=64)]
     reads[5] = reads[5][:20] + "N" + reads[5][20:]
     cases.append(dict(regions=[(left, "CAG", right)], reads=reads, kmin=np.zeros(64, np.int32), kmax=np.full(64, 45, np.int32)))
     for d in cases:
         res = {}
-        for name, fl in (("tickets", 0), ("two launches", capi.F_QUANTA_2L), ("reverse / forward", capi.F_NO_QUANTA)):
+        for name, fl, qsteps in (("tickets", 0, None), ("parts of 64", 0, "64"), ("parts of 128", 0, "128"), ("parts of 256", 0, "320"),
+                                 ("reverse / forward", capi.F_NO_QUANTA, None)):
+            if qsteps is None:
+                monkeypatch.delenv("NRA_TEST_QSTEPS", raising=False)
+            else:
+                monkeypatch.setenv("NRA_TEST_QSTEPS", qsteps)
             with capi.Batch.create_1d(d["regions"], d["reads"], d["kmin"], d["kmax"], flags=fl) as b:
                 b.run(); b.sync()
                 res[name] = b.fetch()
@@ -212,6 +218,7 @@ def test_the_three_forms_of_the_ring_sweeps_agree(capi, oracle):
                 again = b.fetch()
                 for k in again:
                     assert np.array_equal(again[k], res[name][k]), (name, "second run", k)
+        monkeypatch.delenv("NRA_TEST_QSTEPS", raising=False)
         for name in res:
             for k in res["tickets"]:
                 assert np.array_equal(res[name][k], res["tickets"][k]), (name, k)

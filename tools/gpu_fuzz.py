@@ -286,7 +286,14 @@ if __name__ == "__main__":
     seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
     rng = np.random.default_rng(seed)
     t0 = time.time(); bad = 0
+    hist_q = {}
     for i in range(rounds):
+        # the 1D sweeps' quanta (k_sweep_ringq): the library's part size, or short parts so that these small templates are cut
+        # several times -- inside the repeat, inside the reverse sweep's snapshot steps, between two flushes of the outputs
+        qsteps = [None, "64", "128", "192"][int(rng.integers(0, 4))]
+        hist_q[qsteps] = hist_q.get(qsteps, 0) + 1
+        if qsteps is None: os.environ.pop("NRA_TEST_QSTEPS", None)
+        else: os.environ["NRA_TEST_QSTEPS"] = qsteps
         for f in (fuzz_1d, fuzz_1d_multi, fuzz_1d_blocks, fuzz_2d, fuzz_2d_grid, fuzz_pairs):
             r = f(rng)
             if r is not None:
@@ -296,5 +303,5 @@ if __name__ == "__main__":
                     sys.exit(1)
         if i % 20 == 19:
             print(f"round {i + 1}/{rounds} ok, {time.time() - t0:.0f} s", flush=True)
-    print("fuzz done", rounds, "rounds, mismatches:", bad, flush=True)
+    print("fuzz done", rounds, "rounds, mismatches:", bad, "part sizes of the 1D quanta (rounds):", hist_q, flush=True)
     sys.exit(1 if bad else 0)
