@@ -283,8 +283,10 @@ def pmc_counters(config, brute):
 
 
 def roofline_record(config, brute, kernel_name, phase_ms, launch_ms, n_launches, device_ms, executed_cells, useful_laneops,
-                    useful_cells, algorithmic_cells, algorithmic_bytes, extra=None):
-    """One flat record (the driver keeps the scalars of `roofline`): the scoring kernels against the integer-VALU roof."""
+                    useful_cells, algorithmic_cells, algorithmic_bytes, extra=None, share=1.0):
+    """One flat record (the driver keeps the scalars of `roofline`): the scoring kernels against the integer-VALU roof.
+    share < 1 (N > 1, a sharded workload): this rank's part of the job's executed cells -- the counters were counted on
+    the whole workload on one GPU and are scaled to what this rank's GPU ran (cells, times and launches are the rank's own)."""
     kernel_s = phase_ms / 1e3
     pmc, source = pmc_counters(config, brute)
     priced = executed_cells * LANEOPS_PER_CELL / kernel_s / 1e12
@@ -299,12 +301,15 @@ def roofline_record(config, brute, kernel_name, phase_ms, launch_ms, n_launches,
            "algorithmic_bytes_per_step": algorithmic_bytes, "algorithmic_GBps": algorithmic_bytes / kernel_s / 1e9,
            "hbm_peak_GBps": HBM_PEAK_GBPS, "counters": source}
     if pmc is not None:
-        valu = pmc["sweep_kernels"]["valu_wave_instructions_per_step"]
+        scaled = lambda v: None if v is None else v * share
+        valu = pmc["sweep_kernels"]["valu_wave_instructions_per_step"] * share
         issued = valu * 64.0 / kernel_s / 1e12              # lane-op slots the issued VALU instructions fill per second
         rec.update(achieved=issued, frac=issued / VALU_PEAK_TLANEOPS, valu_wave_instructions_per_step=valu,
-                   traffic=pmc.get("hbm_bytes_per_step_sweep_kernels"),
-                   fetch_bytes_per_step=pmc["sweep_kernels"].get("fetch_bytes"),
-                   write_bytes_per_step=pmc["sweep_kernels"].get("write_bytes"))
+                   traffic=scaled(pmc.get("hbm_bytes_per_step_sweep_kernels")),
+                   fetch_bytes_per_step=scaled(pmc["sweep_kernels"].get("fetch_bytes")),
+                   write_bytes_per_step=scaled(pmc["sweep_kernels"].get("write_bytes")))
+        if share != 1.0:
+            rec["counters"] = f"{source}; scaled to this rank's {share:.4f} of the job's executed cells" 
         if rec["traffic"]:
             rec["traffic_GBps"] = rec["traffic"] / kernel_s / 1e9
         cyc, clock = pmc.get("simd_cycles_per_valu_instruction_active"), pmc.get("clock_GHz")
@@ -447,6 +452,7 @@ def bench_1d(args):
     line = None
     dl = stats_delta(warm, st)
     multi = None
+    job_share = 1.0
     if dist is not None:
         # one more pass with NOTHING behind it: the exchange (one all_gather of 32 B per read, padded to the largest shard)
         # exposed, timed between barriers; then every rank's kernel time and executed cells
@@ -463,6 +469,8 @@ def bench_1d(args):
         allr = [torch.empty_like(mine_t) for _ in range(world)]
         dist.all_gather(allr, mine_t)
         allr = np.array([t.cpu().numpy() for t in allr])
+        if scaling == "strong":        # the counters were counted on the whole job on one GPU: this rank ran its share of it
+            job_share = float(st["executed_cells"]) / max(float(allr[:, 1].sum()), 1.0)
         multi = {"per_rank_kernel_ms": [round(float(x), 3) for x in allr[:, 0]],
                  "per_rank_alignments": [int(x) for x in allr[:, 3]],
                  "executed_cells_max_over_mean": float(allr[:, 1].max() / max(allr[:, 1].mean(), 1.0)),
@@ -501,7 +509,8 @@ def bench_1d(args):
             "roofline": roofline_record(args.config, args.brute, kern, dl["phase_ms"], dl["launch_ms"], st["n_score_launches"],
                                         dl["total_ms"], st["executed_cells"], useful * LANEOPS_PACKED_CELL, useful,
                                         st["algorithmic_cells"], st["algorithmic_bytes"],
-                                        {"extent_kernel_ms_per_step": dl["ext_ms"], "junction_snapshot_bytes_per_step": st["intermediate_bytes"]}),
+                                        {"extent_kernel_ms_per_step": dl["ext_ms"], "junction_snapshot_bytes_per_step": st["intermediate_bytes"]},
+                                        share=job_share),
             "extent_tasks_per_step": st["n_extent_tasks"],
             "exact_k_fraction": exact,
         }
