@@ -267,7 +267,8 @@ int nra_launch_sweep_ring32_fwd(int R, int has_n, hipStream_t st, int n_tasks, c
 #define NRA_Q_MAX_PARTS 16
 #define NRA_Q_STEPS 384          // steps of a part (config 2: a reverse sweep in 3 parts, a forward sweep in 7)
 #define NRA_Q_CUT(jfirst) ((jfirst) < 0 ? 0 : (jfirst) / 64 * 64)      /* a forward sweep's first cut: before its first boundary step */
-#define NRA_Q_WHOLE (1 << 20)   // "steps of a part" of a batch too small for more cuts: a reverse sweep, a forward sweep to its first cut, the rest
+#define NRA_Q_WHOLE (1 << 30)   // "steps of a part" of a batch too small for more cuts (longer than any sweep): a reverse sweep, a forward sweep to
+                                // its first cut, the rest
 #define NRA_Q_STEPS_REV(l3, half) ((l3) + ((half) ? 31 : 63))
 #define NRA_Q_STEPS_FWD(l1, m, kmax, half) ((l1) + (m) * (kmax) + ((half) ? 31 : 63) * (m))
 int nra_launch_sweep_ringq(int R, int has_n, hipStream_t st, int n_quanta, const uint32_t* qlist, int qsteps, int n_tasks, int32_t* ticket,
