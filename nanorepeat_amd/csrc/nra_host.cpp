@@ -641,6 +641,7 @@ struct nra_batch {
     bool cells_need_clear = true;               // 2D: some cells are written by no kernel unless found
 
     std::vector<hipStream_t> bstreams;   // one per bucket: the sweep chains of different buckets overlap
+    hipEvent_t mt_rev_ev = nullptr;      // end of the row blocks' reverse launches: buckets of quanta may wait for it (run_1d)
     std::vector<hipEvent_t> bdone;       // bucket chain finished
     hipEvent_t fork_ev = nullptr, fork2_ev = nullptr;
     hipEvent_t phase_ev[2] = {nullptr, nullptr};   // scoring phase start / end (timing)
@@ -663,6 +664,7 @@ struct nra_batch {
         for (hipEvent_t e : bdone) if (e) g_handles.put_event(device, false, e);
         for (hipEvent_t e : warm_ev) if (e) g_handles.put_event(device, false, e);
         if (fork_ev) g_handles.put_event(device, false, fork_ev);
+        if (mt_rev_ev) g_handles.put_event(device, false, mt_rev_ev);
         if (fork2_ev) g_handles.put_event(device, false, fork2_ev);
         for (hipStream_t q : bstreams) if (q) g_handles.put_stream(device, q);
         if (stream) g_handles.put_stream(device, stream);
@@ -1548,10 +1550,24 @@ static int run_1d(nra_batch* b)
         HIP_TRY(hipEventRecord(b->fork_ev, st));
         // (the order the buckets' chains are launched in makes no difference: 5.50 - 5.61 ms either way on config 2;
         // a bucket's tasks as 2 / 3 / 4 groups with chains of their own are slower: 5.65 -> 6.0 / 5.9 / 7.6 ms)
-        for (size_t i = 0; i < nb; ++i) {
+        std::vector<size_t> order;
+        for (size_t i = 0; i < nb; ++i) if (b->buckets[i].mt) order.push_back(i);
+        for (size_t i = 0; i < nb; ++i) if (!b->buckets[i].mt) order.push_back(i);
+        bool mt_rev_recorded = false;
+        // Row-block buckets beside quanta: the launch that is being dispatched keeps the slots its own waves free, so the
+        // quanta, started together with the row blocks' reverse launch, kept the forward launch of the row blocks off the
+        // device until they were through (config 5: it began at 5.7 of 17.7 ms and then ran alone).  Where the row blocks
+        // are the larger share of the work the quanta wait for the reverse launch instead and share the device with the
+        // forward one: 17.9 -> 17.35 ms per step.
+        int64_t cells_mt = 0, cells_q = 0;
+        for (const Bucket& bk : b->buckets) (bk.mt ? cells_mt : cells_q) += bk.quanta || bk.mt ? bk.cells_sweep : 0;
+        const bool mt_first = cells_mt > 0 && cells_q > 0 && cells_mt >= cells_q;
+        for (size_t oi = 0; oi < nb; ++oi) {
+            const size_t i = order[oi];
             const Bucket& bk = b->buckets[i];
             hipStream_t q = b->bstreams[i];
             HIP_TRY(hipStreamWaitEvent(q, b->fork_ev, 0));
+            if (mt_first && bk.quanta && mt_rev_recorded) HIP_TRY(hipStreamWaitEvent(q, b->mt_rev_ev, 0));
             HIP_TRY(hipEventRecord(b->ev[ev++], q));
             int32_t* strips = bk.chain ? b->chain_sweep.p + bk.strip_off : nullptr;
             if (bk.quanta) {
@@ -1599,6 +1615,11 @@ static int run_1d(nra_batch* b)
                                                 b->read_a1d.p, strips, b->chain_cap, bk.n_strips));
             HIP_TRY(hipEventRecord(b->ev[ev++], q));
             HIP_TRY(hipEventRecord(b->ev[ev++], q));
+            if (bk.mt && mt_first) {
+                if (!b->mt_rev_ev) HIP_TRY(g_handles.event(b->device, false, &b->mt_rev_ev));
+                HIP_TRY(hipEventRecord(b->mt_rev_ev, q));
+                mt_rev_recorded = true;
+            }
             if (bk.mt) {
                 for (const auto& g : bk.mt_groups)
                     LAUNCH_TRY(nra_launch_sweep_ringmt_fwd(bk.R, b->has_n, bk.wide ? 1 : 0, q, g.second, b->chain_blocks.p + g.first,
