@@ -1,5 +1,8 @@
 """Host/device timeline of one joint run (config 3): when the session (or each read group's thread, parts > 1) routes a
-grid, waits for the device and reads the results.  python3 tools/joint_timeline.py [parts]"""
+grid, waits for the device and reads the results.  python3 tools/joint_timeline.py [parts]
+Environment: NRA_TIMELINE_READS (5000), NRA_TIMELINE_RUNS (14: every run's wall time is printed -- the bistable state of
+DESIGN 9(2b) shows there), NRA_TIMELINE_FLAGS (batch flags, e.g. 1024 = NRA_F_JOINT_NO_KEEP), NRA_TIMELINE_BALLAST_GB (device
+memory held beside the session, never touched)."""
 import copy, os, sys, threading, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import nanorepeat_amd
