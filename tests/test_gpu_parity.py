@@ -818,6 +818,34 @@ def test_more_chained_tasks_than_scratch_strips(capi, oracle):
         assert np.array_equal(base[k][pick], o[k]), k
 
 
+def test_large_copies_through_the_pinned_stage(capi):
+    """The library copies 256 KB and more through a pinned stage of its own, in pieces of 2 MB (copy_h2d / copy_d2h,
+    nra_host.cpp): one batch of 5400 config-2 reads -- 0.9 MB of packed reads up, 4.2 MB per candidate array down, three
+    pieces with a ragged last one -- against the same reads in batches of 300, whose copies all stay below the threshold and
+    go straight to hipMemcpy; and sizes just below / at the threshold."""
+    d = synth.config2(n_reads=5400)
+    with capi.Batch.create_1d(d["regions"], d["reads"], d["kmin"], d["kmax"], flags=capi.F_TIE_EXTENTS) as b:
+        b.run(); b.sync()
+        big = b.fetch()
+    assert big["cand_score"].nbytes > (4 << 20)
+    keys = ("best_score", "sum_k", "n_ties", "status", "cand_score", "cand_tstart", "cand_tend")
+    parts = []
+    for a in range(0, 5400, 300):
+        sl = slice(a, a + 300)
+        with capi.Batch.create_1d(d["regions"], d["reads"][sl], d["kmin"][sl], d["kmax"][sl], flags=capi.F_TIE_EXTENTS) as b:
+            b.run(); b.sync()
+            parts.append(b.fetch())
+        assert parts[-1]["cand_score"].nbytes < (256 << 10)
+    for k in keys:
+        assert np.array_equal(big[k], np.concatenate([p[k] for p in parts])), k
+    for n in (334, 335):                                    # 196 candidates x 4 B a read: 261 856 / 262 640 B either side of 256 KB
+        sl = slice(0, n)
+        with capi.Batch.create_1d(d["regions"], d["reads"][sl], d["kmin"][sl], d["kmax"][sl]) as b:
+            b.run(); b.sync()
+            got = b.fetch()
+        assert np.array_equal(got["cand_score"], big["cand_score"][:len(got["cand_score"])]), n
+
+
 def test_large_call_streams_region_blocks(capi, oracle):
     """nra_round3_1d cuts a call of >= 131072 reads grouped by region into region blocks and packs / uploads block
     i + 1 while block i's kernels run: same results as the one resident batch, per read and per candidate, also
