@@ -72,8 +72,8 @@ extern "C" {
                                  the column states a coarse grid's sweeps leave at EVERY repeat count of a read's range, from which a
                                  finer grid inside those ranges (the reference's round 3 after round 2) needs no sweep at all */
 #define NRA_F_NO_QUANTA 2048  /* testing / comparison, 1D: a bucket's reverse sweeps and forward sweeps as two launches (k_sweep_ring /
-                                 k_sweep_ring32) instead of one launch of quanta taken by ticket -- reverse sweep, forward sweep up to
-                                 the first unit boundary, forward sweep from there on (k_sweep_ringq) */
+                                 k_sweep_ring32) instead of one launch of quanta taken by ticket -- the sweeps cut into parts of a few
+                                 hundred steps (k_sweep_ringq) */
 #define NRA_F_QUANTA_2L 4096  /* accepted and ignored since the sweeps' quanta became parts of a few hundred steps (it ran the three
                                  quanta of round 4's first form as two launches without tickets: measured no better than no quanta) */
 #define NRA_F_BRUTE_FORCE  4  /* score the K candidates of a read as K independent alignments
