@@ -319,35 +319,22 @@ void device_chunk_put(int device, char* p, size_t bytes) { g_handles.chunk_put(d
 // seconds; 5 of 9 runs against 1 of 9 with the runtime's threshold lifted -- DESIGN.md 9(2b), profiles/r04_keep_cliff*).
 // So the library never hands the runtime a large pageable buffer: it copies through a pinned stage of its own, in
 // pieces, synchronously as before.
-constexpr size_t kStagedFrom = 256u << 10, kStageBytes = 4u << 20;
+// (from 896 KB: below the runtime's 1 MB it stages the copy itself, faster than this file can -- config 3 at 5000 reads, whose
+// task arrays are 300-400 KB: 6.15 ms per step, 6.55 with everything from 256 KB on going through the stage below)
+constexpr size_t kStagedFrom = 896u << 10, kStageBytes = 4u << 20;
 struct CopyStage {
     void* p = nullptr;
     size_t cap = 0;
-    int device = -1;
-    hipStream_t q = nullptr;            // the stage's own stream: the pieces' transfers overlap the host's memcpy of the next piece
-    hipEvent_t ev[2] = {nullptr, nullptr};
     bool deferred = false;              // upload_batch_begin .. _end: transfers are enqueued, not waited for
     size_t used = 0;                    // ... bytes of the stage they hold
-    void drop_handles()
-    {
-        if (q) g_handles.put_stream(device, q);
-        for (hipEvent_t& e : ev) if (e) { g_handles.put_event(device, false, e); e = nullptr; }
-        q = nullptr;
-    }
-    ~CopyStage() { drop_handles(); if (p) g_handles.pinned_put(p, cap); }
-    hipError_t ensure()
-    {
-        int dev = 0;
-        hipError_t e = hipGetDevice(&dev);
-        if (e != hipSuccess) return e;
-        if (dev != device) { drop_handles(); device = dev; }
-        if (!q && (e = g_handles.stream(device, &q)) != hipSuccess) return e;
-        for (hipEvent_t& v : ev) if (!v && (e = g_handles.event(device, false, &v)) != hipSuccess) return e;
-        if (p) return hipSuccess;
-        return g_handles.pinned_get(kStageBytes, &p, &cap);
-    }
+    ~CopyStage() { if (p) g_handles.pinned_put(p, cap); }
+    hipError_t ensure() { return p ? hipSuccess : g_handles.pinned_get(kStageBytes, &p, &cap); }
 };
 thread_local CopyStage g_copy_stage;
+// (The transfers go to the null stream: a stream of the stage's own would be one more for the runtime to map onto its
+// GPU_MAX_HW_QUEUES hardware queues, and two of a batch's streams that end up sharing a queue run one behind the other --
+// measured: config 3 6.15 -> 6.6 ms per step with a stream held by the stage.  The batches' streams are non-blocking, so
+// the null stream orders nothing against them.)
 void upload_batch_begin() { g_copy_stage.deferred = true; g_copy_stage.used = 0; }
 hipError_t upload_batch_end()
 {
@@ -355,7 +342,7 @@ hipError_t upload_batch_end()
     if (!st.deferred) return hipSuccess;
     st.deferred = false;
     st.used = 0;
-    return st.q ? hipStreamSynchronize(st.q) : hipSuccess;
+    return st.p ? hipStreamSynchronize(nullptr) : hipSuccess;
 }
 hipError_t copy_h2d(void* dst, const void* src, size_t bytes)
 {
@@ -366,12 +353,12 @@ hipError_t copy_h2d(void* dst, const void* src, size_t bytes)
         if (e != hipSuccess) return e;
         for (size_t off = 0; off < bytes;) {
             if (st.cap - st.used < std::min<size_t>(bytes - off, 64u << 10)) {      // the stage is full: wait for what it holds
-                if ((e = hipStreamSynchronize(st.q)) != hipSuccess) return e;
+                if ((e = hipStreamSynchronize(nullptr)) != hipSuccess) return e;
                 st.used = 0;
             }
             const size_t n = std::min(bytes - off, st.cap - st.used);
             memcpy((char*)st.p + st.used, (const char*)src + off, n);
-            if ((e = hipMemcpyAsync((char*)dst + off, (char*)st.p + st.used, n, hipMemcpyHostToDevice, st.q)) != hipSuccess) return e;
+            if ((e = hipMemcpyAsync((char*)dst + off, (char*)st.p + st.used, n, hipMemcpyHostToDevice, nullptr)) != hipSuccess) return e;
             st.used += (n + 255) & ~(size_t)255;
             off += n;
         }
@@ -380,17 +367,12 @@ hipError_t copy_h2d(void* dst, const void* src, size_t bytes)
     if (bytes < kStagedFrom) return hipMemcpy(dst, src, bytes, hipMemcpyHostToDevice);
     hipError_t e = st.ensure();
     if (e != hipSuccess) return e;
-    const size_t piece = st.cap / 2;
-    size_t i = 0;
-    for (size_t off = 0; off < bytes; off += piece, ++i) {
-        const size_t n = std::min(piece, bytes - off);
-        char* half = (char*)st.p + (i & 1) * piece;
-        if (i >= 2 && (e = hipEventSynchronize(st.ev[i & 1])) != hipSuccess) return e;      // this half's last transfer is over
-        memcpy(half, (const char*)src + off, n);
-        if ((e = hipMemcpyAsync((char*)dst + off, half, n, hipMemcpyHostToDevice, st.q)) != hipSuccess) return e;
-        if ((e = hipEventRecord(st.ev[i & 1], st.q)) != hipSuccess) return e;
+    for (size_t off = 0; off < bytes; off += st.cap) {
+        const size_t n = std::min(st.cap, bytes - off);
+        memcpy(st.p, (const char*)src + off, n);
+        if ((e = hipMemcpy((char*)dst + off, st.p, n, hipMemcpyHostToDevice)) != hipSuccess) return e;      // (pinned source: no pinning by the runtime)
     }
-    return hipStreamSynchronize(st.q);          // synchronous, like the hipMemcpy it stands for
+    return hipSuccess;
 }
 hipError_t copy_d2h(void* dst, const void* src, size_t bytes)
 {
@@ -398,19 +380,10 @@ hipError_t copy_d2h(void* dst, const void* src, size_t bytes)
     CopyStage& st = g_copy_stage;
     hipError_t e = st.ensure();
     if (e != hipSuccess) return e;
-    const size_t piece = st.cap / 2;
-    const size_t n_pieces = (bytes + piece - 1) / piece;
-    auto start = [&](size_t i) -> hipError_t {
-        const size_t off = i * piece, n = std::min(piece, bytes - off);
-        hipError_t e2 = hipMemcpyAsync((char*)st.p + (i & 1) * piece, (const char*)src + off, n, hipMemcpyDeviceToHost, st.q);
-        return e2 != hipSuccess ? e2 : hipEventRecord(st.ev[i & 1], st.q);
-    };
-    if ((e = start(0)) != hipSuccess) return e;
-    for (size_t i = 0; i < n_pieces; ++i) {
-        if (i + 1 < n_pieces && (e = start(i + 1)) != hipSuccess) return e;       // the next piece travels while this one is copied out
-        if ((e = hipEventSynchronize(st.ev[i & 1])) != hipSuccess) return e;
-        const size_t off = i * piece;
-        memcpy((char*)dst + off, (const char*)st.p + (i & 1) * piece, std::min(piece, bytes - off));
+    for (size_t off = 0; off < bytes; off += st.cap) {
+        const size_t n = std::min(st.cap, bytes - off);
+        if ((e = hipMemcpy(st.p, (const char*)src + off, n, hipMemcpyDeviceToHost)) != hipSuccess) return e;
+        memcpy((char*)dst + off, st.p, n);
     }
     return hipSuccess;
 }

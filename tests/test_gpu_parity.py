@@ -819,10 +819,10 @@ def test_more_chained_tasks_than_scratch_strips(capi, oracle):
 
 
 def test_large_copies_through_the_pinned_stage(capi):
-    """The library copies 256 KB and more through a pinned stage of its own, in pieces of 2 MB (copy_h2d / copy_d2h,
-    nra_host.cpp): one batch of 5400 config-2 reads -- 0.9 MB of packed reads up, 4.2 MB per candidate array down, three
-    pieces with a ragged last one -- against the same reads in batches of 300, whose copies all stay below the threshold and
-    go straight to hipMemcpy; and sizes just below / at the threshold."""
+    """The library copies 896 KB and more through a pinned stage of its own, in pieces of 2 MB (copy_h2d / copy_d2h,
+    nra_host.cpp): one batch of 5400 config-2 reads -- 4.2 MB per candidate array down, three pieces with a ragged last one --
+    against the same reads in batches of 300, whose copies all stay below the threshold and go straight to hipMemcpy; and
+    sizes just below / at the threshold."""
     d = synth.config2(n_reads=5400)
     with capi.Batch.create_1d(d["regions"], d["reads"], d["kmin"], d["kmax"], flags=capi.F_TIE_EXTENTS) as b:
         b.run(); b.sync()
@@ -838,7 +838,7 @@ def test_large_copies_through_the_pinned_stage(capi):
         assert parts[-1]["cand_score"].nbytes < (256 << 10)
     for k in keys:
         assert np.array_equal(big[k], np.concatenate([p[k] for p in parts])), k
-    for n in (334, 335):                                    # 196 candidates x 4 B a read: 261 856 / 262 640 B either side of 256 KB
+    for n in (1170, 1171):                                  # 196 candidates x 4 B a read: 917 280 / 918 064 B either side of 896 KB
         sl = slice(0, n)
         with capi.Batch.create_1d(d["regions"], d["reads"][sl], d["kmin"][sl], d["kmax"][sl]) as b:
             b.run(); b.sync()
